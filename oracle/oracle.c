@@ -1,0 +1,1000 @@
+/*
+ * oracle.c — CPU restatement (plain C11 + OpenMP) of the SANeRF-HQ volumetric
+ * rendering hot path.  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Pinning status (details in oracle/README.md and DESIGN.md §3):
+ *   - ray generation, near/far, spacing, contraction, sample_pdf (incl. the
+ *     integer searchsorted indices), sigma->weights, compositing, the tiny
+ *     MLPs and both heads are PINNED against the reference's own Python
+ *     (nerf/renderer.py, nerf/network.py, nerf/utils.py imported on CPU by
+ *     tools/gen_golden.py; fixtures in tests/golden/).
+ *   - frequency encoding is PINNED against FreqEncoder_torch (encoding.py:6-44).
+ *   - hash-grid and SH arithmetic: the reference ships them only as CUDA
+ *     (gridencoder.cu, shencoder.cu) which cannot be built or run here and the
+ *     reference holds no test vectors for them => "parity unpinned" by the
+ *     reference; pinned instead by closed-form identities in tests/.
+ *
+ * Numerics contract shared with the HIP kernels (bit-identical by construction
+ * wherever an integer result depends on it):
+ *   - compile with -ffp-contract=off; every fused multiply-add is an explicit fmaf
+ *   - exp is orc_expf (range reduction + degree-6 polynomial, fmaf only)
+ *   - prefix sums / sums that feed sample indices accumulate in fp64 and round to
+ *     fp32 once per prefix (= what torch.cumsum does on CPU for fp32 inputs)
+ *   - division and sqrt are IEEE correctly rounded
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------ */
+/* scalar helpers                                                            */
+/* ------------------------------------------------------------------------ */
+
+static inline float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* The build's fp32 exp.  torch.exp / CUDA expf are not bit-reproducible across
+ * platforms, so the CPU oracle and the HIP kernels share this recipe instead:
+ *   k = rint(x*log2e); r = x - k*ln2 (two-step, fmaf); p = Horner degree 6 (fmaf);
+ *   result = (p * 2^(k/2)) * 2^(k - k/2).  <= 1 ulp from the correctly rounded value
+ *   on the tested range; exact special cases exp(-inf)=0, exp(+inf)=inf, NaN->NaN.
+ * Stands in for: torch.exp in activation.py:9 (trunc_exp) and renderer.py:316,321. */
+float orc_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -103.97208404541015625f) return 0.0f;
+    const float k = rintf(x * 1.44269502162933349609375f);
+    float r = fmaf(k, -0.693145751953125f, x);
+    r = fmaf(k, -1.42860676533018704503775e-06f, r);
+    float p = 1.98756915e-4f;
+    p = fmaf(p, r, 1.39819995e-3f);
+    p = fmaf(p, r, 8.33345205e-3f);
+    p = fmaf(p, r, 4.16657962e-2f);
+    p = fmaf(p, r, 1.66666657e-1f);
+    p = fmaf(p, r, 5.00000000e-1f);
+    const float r2 = r * r;
+    p = fmaf(p, r2, r);
+    p = p + 1.0f;
+    const int ki = (int)k;
+    const int k1 = ki / 2;
+    const int k2 = ki - k1;
+    const float s1 = bits_to_float((uint32_t)(k1 + 127) << 23);
+    const float s2 = bits_to_float((uint32_t)(k2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+float orc_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    if (exp == 0) {
+        if (man == 0) return bits_to_float(sign);
+        /* subnormal: normalise */
+        int e = -1;
+        do { man <<= 1; e++; } while ((man & 0x400u) == 0);
+        man &= 0x3ffu;
+        return bits_to_float(sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13));
+    }
+    if (exp == 31) return bits_to_float(sign | 0x7f800000u | (man << 13));
+    return bits_to_float(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+uint16_t orc_float_to_half(float f) { /* round to nearest even */
+    const uint32_t x = float_to_bits(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u : 0));
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            /* >= 65520 rounds to inf */
+    if (ax <= 0x33000000u) return (uint16_t)sign;                          /* <= 2^-25 rounds to 0 */
+    const int e = (int)(ax >> 23) - 127;
+    if (e < -14) {                                                         /* half subnormal: m * 2^-24 */
+        const uint32_t man = (ax & 0x7fffffu) | 0x800000u;
+        const int s = -(e + 1);                                            /* 14..24 */
+        uint32_t hm = man >> s;
+        const uint32_t rem = man & ((1u << s) - 1u), half = 1u << (s - 1);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        return (uint16_t)(sign | hm);                                      /* 1024 == min normal, fine */
+    }
+    const uint32_t man23 = ax & 0x7fffffu;
+    uint32_t h = ((uint32_t)(e + 15) << 10) + (man23 >> 13);
+    const uint32_t rem = man23 & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;                /* carry may bump the exponent */
+    return (uint16_t)(sign | h);
+}
+
+/* gridencoder.cu:133  resolution = (uint32_t)ceil(exp2f(level * S) * H), all fp32 */
+uint32_t orc_level_resolution(uint32_t level, float S, uint32_t H) {
+    const float e = exp2f((float)level * S);
+    return (uint32_t)ceilf(e * (float)H);
+}
+
+static inline float table_load(const void *tab, int dtype, size_t i) {
+    return dtype ? orc_half_to_float(((const uint16_t *)tab)[i]) : ((const float *)tab)[i];
+}
+
+/* ------------------------------------------------------------------------ */
+/* grid encoder                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* gridencoder.cu:45-59 */
+static inline uint32_t grid_fast_hash(const uint32_t *pos_grid, uint32_t D) {
+    static const uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u,
+                                       2097192037u, 1434869437u, 2165219737u};
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < D; ++i) r ^= pos_grid[i] * primes[i];
+    return r;
+}
+
+/* gridencoder.cu:62-79; returns the ROW (the reference returns row*C + ch) */
+static inline uint32_t grid_row(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution,
+                                const uint32_t *pos_grid, uint32_t D) {
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < D && stride <= hashmap_size; d++) {
+        index += pos_grid[d] * stride;
+        stride *= resolution;
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = grid_fast_hash(pos_grid, D);
+    return index % hashmap_size;
+}
+
+static inline float smoothstep_f(float v) { return v * v * (3.0f - 2.0f * v); }
+static inline float smoothstep_d(float v) { return 6 * v * (1.0f - v); }
+
+/* gridencoder.cu:137-159: position inside level; returns 0 if out of [0,1] */
+static inline void grid_locate(const float *in, uint32_t D, uint32_t resolution, int align_corners,
+                               uint32_t interp, float *pos, float *pos_deriv, uint32_t *pos_grid) {
+    for (uint32_t d = 0; d < D; d++) {
+        if (align_corners) {
+            pos[d] = in[d] * (float)(resolution - 1);
+            uint32_t g = (uint32_t)floorf(pos[d]);
+            pos_grid[d] = g < resolution - 2 ? g : resolution - 2;
+        } else {
+            /* nvcc contracts x*res-0.5 into one fma; stated explicitly here */
+            float p = fmaf(in[d], (float)resolution, -0.5f);
+            p = fminf(fmaxf(p, 0.0f), (float)(resolution - 1));
+            pos[d] = p;
+            pos_grid[d] = (uint32_t)floorf(p);
+        }
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) {
+            if (pos_deriv) pos_deriv[d] = smoothstep_d(pos[d]);
+            pos[d] = smoothstep_f(pos[d]);
+        } else if (pos_deriv) {
+            pos_deriv[d] = 1.0f;
+        }
+    }
+}
+
+/* one (sample, level): gridencoder.cu:94-248 */
+static void grid_encode_one(const float *in, const void *emb, int dtype, const int32_t *offsets,
+                            uint32_t level, uint32_t D, uint32_t C, uint32_t resolution,
+                            uint32_t gridtype, int align_corners, uint32_t interp,
+                            float *out /*[C]*/, float *dydx /*[D*C] or NULL*/) {
+    int oob = 0;
+    for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+    if (oob) {
+        for (uint32_t c = 0; c < C; c++) out[c] = 0;
+        if (dydx) for (uint32_t i = 0; i < D * C; i++) dydx[i] = 0;
+        return;
+    }
+    const size_t base = (size_t)(uint32_t)offsets[level] * C;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    float pos[8], pos_deriv[8];
+    uint32_t pos_grid[8];
+    grid_locate(in, D, resolution, align_corners, interp, pos, pos_deriv, pos_grid);
+
+    float results[32];
+    for (uint32_t c = 0; c < C; c++) results[c] = 0;
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+        uint32_t pl[8];
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pl[d] = pos_grid[d] + 1 < resolution - 1 ? pos_grid[d] + 1 : resolution - 1; }
+        }
+        const size_t row = grid_row(gridtype, hashmap_size, resolution, pl, D);
+        for (uint32_t c = 0; c < C; c++)
+            results[c] = fmaf(w, table_load(emb, dtype, base + row * C + c), results[c]);
+    }
+    for (uint32_t c = 0; c < C; c++) out[c] = results[c];
+
+    if (dydx) { /* gridencoder.cu:205-248 */
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[32];
+            for (uint32_t c = 0; c < C; c++) rg[c] = 0;
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = (float)(align_corners ? resolution - 1 : resolution);
+                uint32_t pl[8];
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1 < resolution - 1 ? pos_grid[d] + 1 : resolution - 1; }
+                }
+                pl[gd] = pos_grid[gd];
+                const size_t rl = grid_row(gridtype, hashmap_size, resolution, pl, D);
+                pl[gd] = pos_grid[gd] + 1 < resolution - 1 ? pos_grid[gd] + 1 : resolution - 1;
+                const size_t rr = grid_row(gridtype, hashmap_size, resolution, pl, D);
+                for (uint32_t c = 0; c < C; c++) {
+                    const float diff = table_load(emb, dtype, base + rr * C + c) - table_load(emb, dtype, base + rl * C + c);
+                    rg[c] = fmaf(w * diff, pos_deriv[gd], rg[c]);
+                }
+            }
+            for (uint32_t c = 0; c < C; c++) dydx[gd * C + c] = rg[c];
+        }
+    }
+}
+
+void orc_grid_encode_forward(const float *inputs, const void *embeddings, int table_dtype,
+                             const int32_t *offsets, float *outputs,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                             float S, uint32_t H, float *dy_dx,
+                             uint32_t gridtype, int align_corners, uint32_t interp) {
+    /* levels >= max_level are left untouched, like the launch grid at gridencoder.cu:384 */
+    uint32_t res_tab[ORC_MAX_LEVELS];
+    for (uint32_t l = 0; l < L && l < ORC_MAX_LEVELS; l++) res_tab[l] = orc_level_resolution(l, S, H);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        for (uint32_t l = 0; l < max_level; l++) {
+            float *o = outputs + ((size_t)l * B + (size_t)b) * C;
+            float *g = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)l * D * C : NULL;
+            grid_encode_one(inputs + (size_t)b * D, embeddings, table_dtype, offsets, l, D, C, res_tab[l],
+                            gridtype, align_corners, interp, o, g);
+        }
+    }
+}
+
+void orc_grid_encode_backward(const float *grad, const float *inputs, const void *embeddings, int table_dtype,
+                              const int32_t *offsets, float *grad_embeddings,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                              float S, uint32_t H, const float *dy_dx, float *grad_inputs,
+                              uint32_t gridtype, int align_corners, uint32_t interp) {
+    (void)embeddings; (void)table_dtype;
+    /* gridencoder.cu:252-349.  The reference scatters with float atomics in a
+     * non-deterministic order; this restatement adds in ascending sample order
+     * (one of the orders the reference can produce).  Levels own disjoint rows. */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t lv = 0; lv < (int64_t)max_level; lv++) {
+        const uint32_t level = (uint32_t)lv;
+        float *gg = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const uint32_t resolution = orc_level_resolution(level, S, H);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *in = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[8]; uint32_t pos_grid[8];
+            grid_locate(in, D, resolution, align_corners, interp, pos, NULL, pos_grid);
+            const float *g = grad + ((size_t)level * B + b) * C;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1; uint32_t pl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pl[d] = pos_grid[d] + 1 < resolution - 1 ? pos_grid[d] + 1 : resolution - 1; }
+                }
+                const size_t row = grid_row(gridtype, hashmap_size, resolution, pl, D);
+                for (uint32_t c = 0; c < C; c++) gg[row * C + c] += w * g[c];
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) { /* gridencoder.cu:352-378 */
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)B * D; t++) {
+            const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t % D);
+            const float *dd = dy_dx + (size_t)b * L * D * C;
+            float r = 0;
+            for (uint32_t l = 0; l < L; l++)
+                for (uint32_t c = 0; c < C; c++)
+                    r = fmaf(grad[((size_t)l * B + b) * C + c], dd[(size_t)l * D * C + d * C + c], r);
+            grad_inputs[t] = r;
+        }
+    }
+}
+
+/* gridencoder.cu:525-631 */
+void orc_grad_total_variation(const float *inputs, const float *embeddings, float *grad,
+                              const int32_t *offsets, float weight,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                              float S, uint32_t H, uint32_t gridtype, int align_corners) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t lv = 0; lv < (int64_t)L; lv++) {
+        const uint32_t level = (uint32_t)lv;
+        const float *grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+        float *gr = grad + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const uint32_t resolution = orc_level_resolution(level, S, H);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *in = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) continue;
+            uint32_t pg[8];
+            for (uint32_t d = 0; d < D; d++) {
+                if (align_corners) {
+                    const float p = in[d] * (float)(resolution - 1);
+                    uint32_t g = (uint32_t)floorf(p);
+                    pg[d] = g < resolution - 2 ? g : resolution - 2;
+                } else {
+                    float p = fmaf(in[d], (float)resolution, -0.5f);
+                    p = fminf(fmaxf(p, 0.0f), (float)(resolution - 1));
+                    pg[d] = (uint32_t)floorf(p);
+                }
+            }
+            float results[32], idelta[32];
+            for (uint32_t c = 0; c < C; c++) { results[c] = 0; idelta[c] = 0; }
+            const size_t index = (size_t)grid_row(gridtype, hashmap_size, resolution, pg, D) * C;
+            const float w = weight / (2 * D);
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t cur = pg[d];
+                if (cur < resolution) { /* always true: the reference's guard (gridencoder.cu:593) */
+                    pg[d] = cur + 1;
+                    const size_t ir = (size_t)grid_row(gridtype, hashmap_size, resolution, pg, D) * C;
+                    for (uint32_t c = 0; c < C; c++) {
+                        const float gv = grid[index + c] - grid[ir + c];
+                        results[c] += gv; idelta[c] = fmaf(gv, gv, idelta[c]);
+                    }
+                }
+                if (cur > 0) {
+                    pg[d] = cur - 1;
+                    const size_t il = (size_t)grid_row(gridtype, hashmap_size, resolution, pg, D) * C;
+                    for (uint32_t c = 0; c < C; c++) {
+                        const float gv = grid[index + c] - grid[il + c];
+                        results[c] += gv; idelta[c] = fmaf(gv, gv, idelta[c]);
+                    }
+                }
+                pg[d] = cur;
+            }
+            for (uint32_t c = 0; c < C; c++)
+                gr[index + c] += w * results[c] * (1.0f / sqrtf(idelta[c] + 1e-9f));
+        }
+    }
+}
+
+/* gridencoder.cu:670-703 */
+void orc_grad_weight_decay(const float *embeddings, float *grad, const int32_t *offsets,
+                           float weight, uint32_t B, uint32_t C, uint32_t L) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B * C; b++) {
+        uint32_t level = 0;
+        const uint32_t n = (uint32_t)(b / C);
+        uint32_t l = 0, r = L;
+        while (l < r) {
+            const uint32_t m = (l + r) / 2;
+            if ((uint32_t)offsets[m] <= n) { level = m; l = m + 1; } else { r = m; }
+        }
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        grad[b] += 2 * weight * embeddings[b] / hashmap_size;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* spherical harmonics (shencoder.cu:43-121)                                  */
+/* ------------------------------------------------------------------------ */
+/* One body, instantiated for float (the kernel's arithmetic) and double (used
+ * only to differentiate numerically for dy_dx checks). */
+#define ORC_SH_BODY(R)                                                                            \
+    const R xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;               \
+    const R x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;                                             \
+    const R x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;                                             \
+    o[0] = (R)0.28209479177387814;                                                                \
+    if (C <= 1) return;                                                                           \
+    o[1] = (R)-0.48860251190291987 * y;                                                           \
+    o[2] = (R)0.48860251190291987 * z;                                                            \
+    o[3] = (R)-0.48860251190291987 * x;                                                           \
+    if (C <= 2) return;                                                                           \
+    o[4] = (R)1.0925484305920792 * xy;                                                            \
+    o[5] = (R)-1.0925484305920792 * yz;                                                           \
+    o[6] = (R)0.94617469575755997 * z2 - (R)0.31539156525251999;                                  \
+    o[7] = (R)-1.0925484305920792 * xz;                                                           \
+    o[8] = (R)0.54627421529603959 * x2 - (R)0.54627421529603959 * y2;                             \
+    if (C <= 3) return;                                                                           \
+    o[9] = (R)0.59004358992664352 * y * ((R)-3.0 * x2 + y2);                                      \
+    o[10] = (R)2.8906114426405538 * xy * z;                                                       \
+    o[11] = (R)0.45704579946446572 * y * ((R)1.0 - (R)5.0 * z2);                                  \
+    o[12] = (R)0.3731763325901154 * z * ((R)5.0 * z2 - (R)3.0);                                   \
+    o[13] = (R)0.45704579946446572 * x * ((R)1.0 - (R)5.0 * z2);                                  \
+    o[14] = (R)1.4453057213202769 * z * (x2 - y2);                                                \
+    o[15] = (R)0.59004358992664352 * x * (-x2 + (R)3.0 * y2);                                     \
+    if (C <= 4) return;                                                                           \
+    o[16] = (R)2.5033429417967046 * xy * (x2 - y2);                                               \
+    o[17] = (R)1.7701307697799304 * yz * ((R)-3.0 * x2 + y2);                                     \
+    o[18] = (R)0.94617469575756008 * xy * ((R)7.0 * z2 - (R)1.0);                                 \
+    o[19] = (R)0.66904654355728921 * yz * ((R)3.0 - (R)7.0 * z2);                                 \
+    o[20] = (R)-3.1735664074561294 * z2 + (R)3.7024941420321507 * z4 + (R)0.31735664074561293;    \
+    o[21] = (R)0.66904654355728921 * xz * ((R)3.0 - (R)7.0 * z2);                                 \
+    o[22] = (R)0.47308734787878004 * (x2 - y2) * ((R)7.0 * z2 - (R)1.0);                          \
+    o[23] = (R)1.7701307697799304 * xz * (-x2 + (R)3.0 * y2);                                     \
+    o[24] = (R)-3.7550144126950569 * x2 * y2 + (R)0.62583573544917614 * x4 + (R)0.62583573544917614 * y4; \
+    if (C <= 5) return;                                                                           \
+    o[25] = (R)0.65638205684017015 * y * ((R)10.0 * x2 * y2 - (R)5.0 * x4 - y4);                  \
+    o[26] = (R)8.3026492595241645 * xy * z * (x2 - y2);                                           \
+    o[27] = (R)-0.48923829943525038 * y * ((R)3.0 * x2 - y2) * ((R)9.0 * z2 - (R)1.0);            \
+    o[28] = (R)4.7935367849733241 * xy * z * ((R)3.0 * z2 - (R)1.0);                              \
+    o[29] = (R)0.45294665119569694 * y * ((R)14.0 * z2 - (R)21.0 * z4 - (R)1.0);                  \
+    o[30] = (R)0.1169503224534236 * z * ((R)-70.0 * z2 + (R)63.0 * z4 + (R)15.0);                 \
+    o[31] = (R)0.45294665119569694 * x * ((R)14.0 * z2 - (R)21.0 * z4 - (R)1.0);                  \
+    o[32] = (R)2.3967683924866621 * z * (x2 - y2) * ((R)3.0 * z2 - (R)1.0);                       \
+    o[33] = (R)-0.48923829943525038 * x * (x2 - (R)3.0 * y2) * ((R)9.0 * z2 - (R)1.0);            \
+    o[34] = (R)2.0756623148810411 * z * ((R)-6.0 * x2 * y2 + x4 + y4);                            \
+    o[35] = (R)0.65638205684017015 * x * ((R)10.0 * x2 * y2 - x4 - (R)5.0 * y4);                  \
+    if (C <= 6) return;                                                                           \
+    o[36] = (R)1.3663682103838286 * xy * ((R)-10.0 * x2 * y2 + (R)3.0 * x4 + (R)3.0 * y4);        \
+    o[37] = (R)2.3666191622317521 * yz * ((R)10.0 * x2 * y2 - (R)5.0 * x4 - y4);                  \
+    o[38] = (R)2.0182596029148963 * xy * (x2 - y2) * ((R)11.0 * z2 - (R)1.0);                     \
+    o[39] = (R)-0.92120525951492349 * yz * ((R)3.0 * x2 - y2) * ((R)11.0 * z2 - (R)3.0);          \
+    o[40] = (R)0.92120525951492349 * xy * ((R)-18.0 * z2 + (R)33.0 * z4 + (R)1.0);                \
+    o[41] = (R)0.58262136251873131 * yz * ((R)30.0 * z2 - (R)33.0 * z4 - (R)5.0);                 \
+    o[42] = (R)6.6747662381009842 * z2 - (R)20.024298714302954 * z4 + (R)14.684485723822165 * z6 - (R)0.31784601133814211; \
+    o[43] = (R)0.58262136251873131 * xz * ((R)30.0 * z2 - (R)33.0 * z4 - (R)5.0);                 \
+    o[44] = (R)0.46060262975746175 * (x2 - y2) * ((R)11.0 * z2 * ((R)3.0 * z2 - (R)1.0) - (R)7.0 * z2 + (R)1.0); \
+    o[45] = (R)-0.92120525951492349 * xz * (x2 - (R)3.0 * y2) * ((R)11.0 * z2 - (R)3.0);          \
+    o[46] = (R)0.50456490072872406 * ((R)11.0 * z2 - (R)1.0) * ((R)-6.0 * x2 * y2 + x4 + y4);     \
+    o[47] = (R)2.3666191622317521 * xz * ((R)10.0 * x2 * y2 - x4 - (R)5.0 * y4);                  \
+    o[48] = (R)10.247761577878714 * x2 * y4 - (R)10.247761577878714 * x4 * y2 + (R)0.6831841051919143 * x6 - (R)0.6831841051919143 * y6; \
+    if (C <= 7) return;                                                                           \
+    o[49] = (R)0.70716273252459627 * y * ((R)-21.0 * x2 * y4 + (R)35.0 * x4 * y2 - (R)7.0 * x6 + y6); \
+    o[50] = (R)5.2919213236038001 * xy * z * ((R)-10.0 * x2 * y2 + (R)3.0 * x4 + (R)3.0 * y4);    \
+    o[51] = (R)-0.51891557872026028 * y * ((R)13.0 * z2 - (R)1.0) * ((R)-10.0 * x2 * y2 + (R)5.0 * x4 + y4); \
+    o[52] = (R)4.1513246297620823 * xy * z * (x2 - y2) * ((R)13.0 * z2 - (R)3.0);                 \
+    o[53] = (R)-0.15645893386229404 * y * ((R)3.0 * x2 - y2) * ((R)13.0 * z2 * ((R)11.0 * z2 - (R)3.0) - (R)27.0 * z2 + (R)3.0); \
+    o[54] = (R)0.44253269244498261 * xy * z * ((R)-110.0 * z2 + (R)143.0 * z4 + (R)15.0);         \
+    o[55] = (R)0.090331607582517306 * y * ((R)-135.0 * z2 + (R)495.0 * z4 - (R)429.0 * z6 + (R)5.0); \
+    o[56] = (R)0.068284276912004949 * z * ((R)315.0 * z2 - (R)693.0 * z4 + (R)429.0 * z6 - (R)35.0); \
+    o[57] = (R)0.090331607582517306 * x * ((R)-135.0 * z2 + (R)495.0 * z4 - (R)429.0 * z6 + (R)5.0); \
+    o[58] = (R)0.07375544874083044 * z * (x2 - y2) * ((R)143.0 * z2 * ((R)3.0 * z2 - (R)1.0) - (R)187.0 * z2 + (R)45.0); \
+    o[59] = (R)-0.15645893386229404 * x * (x2 - (R)3.0 * y2) * ((R)13.0 * z2 * ((R)11.0 * z2 - (R)3.0) - (R)27.0 * z2 + (R)3.0); \
+    o[60] = (R)1.0378311574405206 * z * ((R)13.0 * z2 - (R)3.0) * ((R)-6.0 * x2 * y2 + x4 + y4);  \
+    o[61] = (R)-0.51891557872026028 * x * ((R)13.0 * z2 - (R)1.0) * ((R)-10.0 * x2 * y2 + x4 + (R)5.0 * y4); \
+    o[62] = (R)2.6459606618019 * z * ((R)15.0 * x2 * y4 - (R)15.0 * x4 * y2 + x6 - y6);           \
+    o[63] = (R)0.70716273252459627 * x * ((R)-35.0 * x2 * y4 + (R)21.0 * x4 * y2 - x6 + (R)7.0 * y6);
+
+static void sh_eval_f(float x, float y, float z, uint32_t C, float *o) { ORC_SH_BODY(float) }
+static void sh_eval_d(double x, double y, double z, uint32_t C, double *o) { ORC_SH_BODY(double) }
+
+void orc_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D,
+                           uint32_t degree, float *dy_dx) {
+    const uint32_t C2 = degree * degree;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        const float *in = inputs + (size_t)b * D;
+        sh_eval_f(in[0], in[1], in[2], degree, outputs + (size_t)b * C2);
+        if (dy_dx) {
+            /* shencoder.cu:125-353 lists the closed-form partials of the polynomials
+             * above (x, y, z treated as independent).  They are not re-typed here:
+             * the oracle differentiates its own fp64 restatement by a 4th-order
+             * central difference, which is exact to ~1e-11 for these degree<=7
+             * polynomials on [-1,1].  dy_dx layout [B, D, C2] (shencoder.cu:126-128). */
+            const double h = 1e-3;
+            double p2[64], p1[64], m1[64], m2[64];
+            for (uint32_t d = 0; d < 3; d++) {
+                double v[3] = {in[0], in[1], in[2]};
+                const double c = v[d];
+                v[d] = c + 2 * h; sh_eval_d(v[0], v[1], v[2], degree, p2);
+                v[d] = c + h;     sh_eval_d(v[0], v[1], v[2], degree, p1);
+                v[d] = c - h;     sh_eval_d(v[0], v[1], v[2], degree, m1);
+                v[d] = c - 2 * h; sh_eval_d(v[0], v[1], v[2], degree, m2);
+                float *o = dy_dx + (size_t)b * D * C2 + (size_t)d * C2;
+                for (uint32_t k = 0; k < C2; k++)
+                    o[k] = (float)((-p2[k] + 8 * p1[k] - 8 * m1[k] + m2[k]) / (12 * h));
+            }
+        }
+    }
+}
+
+/* shencoder.cu:358-382 (accumulates into grad_inputs, which the caller zero-inits) */
+void orc_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D,
+                            uint32_t degree, const float *dy_dx, float *grad_inputs) {
+    (void)inputs;
+    const uint32_t C2 = degree * degree;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)B * D; t++) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t % D);
+        const float *g = grad + (size_t)b * C2;
+        const float *dd = dy_dx + (size_t)b * D * C2 + (size_t)d * C2;
+        float r = grad_inputs[t];
+        for (uint32_t ch = 0; ch < C2; ch++) r = fmaf(g[ch], dd[ch], r);
+        grad_inputs[t] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* frequency encoding                                                         */
+/* ------------------------------------------------------------------------ */
+/* Output layout freqencoder.cu:30-58: [x | sin f0 | cos f0 | sin f1 | ...].
+ * Values follow FreqEncoder_torch (encoding.py:34-40): sin(x*2^f), cos(x*2^f).
+ * The CUDA kernel's __sinf(v + pi/2) fast-math form is a lower-accuracy
+ * evaluation of the same quantities and is not reproduced. */
+void orc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg,
+                             uint32_t C, float *outputs) {
+    (void)deg;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)B * C; t++) {
+        const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t % C);
+        const float *in = inputs + (size_t)b * D;
+        if (c < D) { outputs[t] = in[c]; continue; }
+        const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
+        const float v = scalbnf(in[d], (int)freq);
+        outputs[t] = (col % 2) ? cosf(v) : sinf(v);
+    }
+}
+
+/* freqencoder.cu:63-94 */
+void orc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D,
+                              uint32_t deg, uint32_t C, float *grad_inputs) {
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)B * D; t++) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t % D);
+        const float *g = grad + (size_t)b * C, *o = outputs + (size_t)b * C;
+        float r = g[d];
+        g += D; o += D;
+        for (uint32_t f = 0; f < deg; f++) {
+            r += scalbnf(1.0f, (int)f) * (g[d] * o[D + d] - g[D + d] * o[d]);
+            g += 2 * D; o += 2 * D;
+        }
+        grad_inputs[t] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* ray generation / near-far / contraction / sampling                         */
+/* ------------------------------------------------------------------------ */
+
+/* torch.linspace on fp32 (scalar path of aten RangeFactoriesKernel, which is
+ * also what the device kernel computes): step=(end-start)/(steps-1);
+ * i<steps/2 ? start+step*i : end-step*(steps-1-i), separate mul and add. */
+void orc_linspace(float start, float end, uint32_t steps, float *out) {
+    if (steps == 1) { out[0] = start; return; }
+    const float step = (end - start) / (float)(steps - 1);
+    const uint32_t half = steps / 2;
+    for (uint32_t i = 0; i < steps; i++) {
+        if (i < half) { const float m = step * (float)i; out[i] = start + m; }
+        else { const float m = step * (float)(steps - i - 1); out[i] = end - m; }
+    }
+}
+
+/* nerf/utils.py:201-205, 269-287 (full-image branch, N=-1) */
+void orc_generate_rays(const float *pose, float fx, float fy, float cx, float cy,
+                       uint32_t H, uint32_t W, float *rays_o, float *rays_d) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)H * W; n++) {
+        const uint32_t row = (uint32_t)(n / W), col = (uint32_t)(n % W);
+        const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+        const float xs = (i - cx) / fx;
+        const float ys = -(j - cy) / fy;
+        const float zs = -1.0f;
+        /* directions @ R^T : d_k = sum_m dir_m * R[k][m], accumulated m = 0,1,2 */
+        for (uint32_t k = 0; k < 3; k++) {
+            float acc = xs * pose[k * 4 + 0];
+            acc = fmaf(ys, pose[k * 4 + 1], acc);
+            acc = fmaf(zs, pose[k * 4 + 2], acc);
+            rays_d[n * 3 + k] = acc;
+            rays_o[n * 3 + k] = pose[k * 4 + 3];
+        }
+    }
+}
+
+/* renderer.py:122-139 */
+static inline void near_far_one(const float *o, const float *d, const float *aabb, float min_near,
+                                float *near_out, float *far_out) {
+    float near = -INFINITY, far = INFINITY;
+    for (int k = 0; k < 3; k++) {
+        const float den = d[k] + 1e-15f;
+        const float tmin = (aabb[k] - o[k]) / den;
+        const float tmax = (aabb[3 + k] - o[k]) / den;
+        const float lo = tmin < tmax ? tmin : tmax;
+        const float hi = tmin > tmax ? tmin : tmax;
+        near = (lo > near || lo != lo) ? lo : near;   /* amax propagates NaN */
+        far = (hi < far || hi != hi) ? hi : far;
+    }
+    if (far < near) { near = 1e9f; far = 1e9f; }
+    if (near < min_near) near = min_near;            /* torch.clamp(min=) */
+    *near_out = near; *far_out = far;
+}
+
+void orc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
+                            float min_near, uint32_t N, float *nears, float *fars) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++)
+        near_far_one(rays_o + n * 3, rays_d + n * 3, aabb, min_near, nears + n, fars + n);
+}
+
+/* renderer.py:60-69 */
+static inline void contract_one(const float *x, float *z) {
+    float mag = fabsf(x[0]); int idx = 0;
+    for (int k = 1; k < 3; k++) { const float a = fabsf(x[k]); if (a > mag || a != a) { if (!(mag != mag)) { mag = a; idx = k; } } }
+    if (mag < 1) { z[0] = x[0]; z[1] = x[1]; z[2] = x[2]; return; }
+    const float inv = 1 / mag;
+    for (int k = 0; k < 3; k++) {
+        const float s = (k == idx) ? (2 - inv) / mag : inv;
+        z[k] = x[k] * s;
+    }
+}
+
+void orc_contract(const float *x, uint32_t N, float *z) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++) contract_one(x + n * 3, z + n * 3);
+}
+
+/* spacing functions, renderer.py:249-252 */
+static inline float spacing_fn(float x) { return x < 1 ? x / 2 : 1 - 1 / (2 * x); }
+static inline float spacing_fn_inv(float x) { return x < 0.5f ? 2 * x : 1 / (2 - 2 * x); }
+
+static inline float nan_to_num_f(float v) {
+    if (v != v) return 0.0f;
+    if (v == INFINITY) return FLT_MAX;
+    if (v == -INFINITY) return -FLT_MAX;
+    return v;
+}
+
+/* renderer.py:84-119 for one ray.  out has T entries. */
+static void sample_pdf_one(const float *bins, const float *weights, uint32_t T0, uint32_t T,
+                           const float *u, float *out, int32_t *inds, float *cdf /* scratch T0+1 */) {
+    double acc = 0;
+    for (uint32_t i = 0; i < T0; i++) acc += (double)(weights[i] + 0.01f);
+    const float wsum = (float)acc;
+    cdf[0] = 0;
+    acc = 0;
+    for (uint32_t i = 0; i < T0; i++) {
+        const float pdf = (weights[i] + 0.01f) / wsum;
+        acc += (double)pdf;
+        float c = (float)acc;
+        cdf[i + 1] = c > 1 ? 1 : c;
+    }
+    uint32_t i = 0; /* cdf and u are both non-decreasing: one merge pass == searchsorted(right=True) */
+    for (uint32_t j = 0; j < T; j++) {
+        const float uj = u[j];
+        while (i <= T0 && cdf[i] <= uj) i++;
+        const int32_t ind = (int32_t)i;
+        int32_t below = ind - 1; if (below < 0) below = 0; if (below > (int32_t)T0) below = (int32_t)T0;
+        int32_t above = ind;     if (above > (int32_t)T0) above = (int32_t)T0;
+        const float c0 = cdf[below], c1 = cdf[above];
+        float t = nan_to_num_f((uj - c0) / (c1 - c0));
+        t = t < 0 ? 0 : (t > 1 ? 1 : t);
+        const float b0 = bins[below], b1 = bins[above];
+        const float m = t * (b1 - b0);
+        out[j] = b0 + m;
+        if (inds) inds[j] = ind;
+    }
+}
+
+void orc_sample_pdf(const float *bins, const float *weights, uint32_t N, uint32_t T0, uint32_t T,
+                    const float *u, float *out_bins, int32_t *inds) {
+    float *utab = NULL;
+    if (!u) {
+        utab = (float *)malloc(sizeof(float) * T);
+        orc_linspace((float)(0.5 / T), (float)(1 - 0.5 / T), T, utab);
+        u = utab;
+    }
+#pragma omp parallel
+    {
+        float *cdf = (float *)malloc(sizeof(float) * (T0 + 1));
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < (int64_t)N; n++)
+            sample_pdf_one(bins + (size_t)n * (T0 + 1), weights + (size_t)n * T0, T0, T, u,
+                           out_bins + (size_t)n * T, inds ? inds + (size_t)n * T : NULL, cdf);
+        free(cdf);
+    }
+    free(utab);
+}
+
+/* renderer.py:308-325 for one ray */
+static void weights_one(const float *real_bins, const float *sigmas, uint32_t T, int last_opaque, float *w) {
+    double cum = 0;
+    for (uint32_t j = 0; j < T; j++) {
+        const float delta = real_bins[j + 1] - real_bins[j];
+        float ds = delta * sigmas[j];
+        if (last_opaque && j == T - 1) ds = INFINITY;
+        const float alpha = 1 - orc_expf(-ds);
+        const float tr = orc_expf(-(float)cum);     /* exclusive prefix, rounded to fp32 */
+        float wj = alpha * tr;
+        if (wj != wj) wj = 0;                        /* nan_to_num_(0); weights are never inf */
+        w[j] = wj;
+        cum += (double)ds;
+    }
+}
+
+void orc_weights_from_sigma(const float *real_bins, const float *sigmas, uint32_t N, uint32_t T,
+                            int last_sample_opaque, float *weights) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++)
+        weights_one(real_bins + (size_t)n * (T + 1), sigmas + (size_t)n * T, T, last_sample_opaque,
+                    weights + (size_t)n * T);
+}
+
+/* ------------------------------------------------------------------------ */
+/* tiny MLPs (network.py:9-66)                                                */
+/* ------------------------------------------------------------------------ */
+#define ORC_MLP_MAXW 512
+
+/* Weights are re-laid out once per call as [in][out] so the loop over output
+ * neurons is the contiguous (vectorisable) one; each neuron still accumulates
+ * bias + sum_k w[o][k]*a[k] as one k-ascending fmaf chain, so results are
+ * bit-identical to the naive [out][in] double loop. */
+typedef struct {
+    float   *wt[ORC_MAX_LAYERS];
+    uint32_t nin[ORC_MAX_LAYERS];
+} mlp_prep;
+
+static void mlp_prepare(const orc_mlp *m, mlp_prep *p) {
+    const uint32_t din = m->dims[0];
+    uint32_t n = din;
+    for (uint32_t l = 0; l < m->num_layers; l++) {
+        if (m->skip_mask & (1u << l)) n += din;
+        const uint32_t nout = m->dims[l + 1];
+        p->nin[l] = n;
+        p->wt[l] = (float *)malloc(sizeof(float) * (size_t)n * nout);
+        for (uint32_t o = 0; o < nout; o++)
+            for (uint32_t k = 0; k < n; k++) p->wt[l][(size_t)k * nout + o] = m->weight[l][(size_t)o * n + k];
+        n = nout;
+    }
+}
+
+static void mlp_release(const orc_mlp *m, mlp_prep *p) {
+    for (uint32_t l = 0; l < m->num_layers; l++) free(p->wt[l]);
+}
+
+static void mlp_forward_one(const orc_mlp *m, const mlp_prep *p, const float *x, float *y) {
+    float a[ORC_MLP_MAXW], b[ORC_MLP_MAXW];
+    const uint32_t din = m->dims[0];
+    uint32_t n = din;
+    memcpy(a, x, sizeof(float) * n);
+    for (uint32_t l = 0; l < m->num_layers; l++) {
+        if (m->skip_mask & (1u << l)) { memcpy(a + n, x, sizeof(float) * din); n += din; } /* cat([h, x_in]) */
+        const uint32_t nout = m->dims[l + 1];
+        const float *Wt = p->wt[l];
+        if (m->bias[l]) memcpy(b, m->bias[l], sizeof(float) * nout);
+        else memset(b, 0, sizeof(float) * nout);
+        for (uint32_t k = 0; k < n; k++) {
+            const float ak = a[k];
+            const float *w = Wt + (size_t)k * nout;
+            for (uint32_t o = 0; o < nout; o++) b[o] = fmaf(w[o], ak, b[o]);
+        }
+        if (l != m->num_layers - 1) {
+            if (m->activation == 0) { for (uint32_t o = 0; o < nout; o++) b[o] = b[o] > 0 ? b[o] : 0.0f; }
+            else { for (uint32_t o = 0; o < nout; o++) b[o] = b[o] > 0 ? b[o] : 0.01f * b[o]; }
+        }
+        memcpy(a, b, sizeof(float) * nout);
+        n = nout;
+    }
+    memcpy(y, a, sizeof(float) * n);
+}
+
+void orc_mlp_forward(const orc_mlp *m, const float *x, uint32_t B, float *y) {
+    const uint32_t din = m->dims[0], dout = m->dims[m->num_layers];
+    mlp_prep p;
+    mlp_prepare(m, &p);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) mlp_forward_one(m, &p, x + (size_t)b * din, y + (size_t)b * dout);
+    mlp_release(m, &p);
+}
+
+/* ------------------------------------------------------------------------ */
+/* whole path (renderer.py:221-385, network.py:146-186)                       */
+/* ------------------------------------------------------------------------ */
+
+static void grid_res_table(const orc_grid *g, uint32_t *res_tab) {
+    for (uint32_t l = 0; l < g->L; l++) res_tab[l] = orc_level_resolution(l, g->S, g->H);
+}
+
+static void grid_encode_point(const orc_grid *g, const uint32_t *res_tab, const float *xyz, float bound,
+                              float *feat /*[L*C]*/) {
+    float x01[8];
+    for (uint32_t d = 0; d < g->D; d++) x01[d] = (xyz[d] + bound) / (2 * bound);   /* grid.py:156 */
+    for (uint32_t l = 0; l < g->L; l++)
+        grid_encode_one(x01, g->embeddings, g->table_dtype, g->offsets, l, g->D, g->C, res_tab[l],
+                        g->gridtype, (int)g->align_corners, g->interp, feat + (size_t)l * g->C, NULL);
+}
+
+#define ORC_MAX_T 1024
+
+void orc_render_rays(const orc_render_cfg *cfg, const float *rays_o, const float *rays_d, uint32_t N,
+                     const float *cam_near_far,
+                     float *image, float *depth, float *weights_sum,
+                     float *samvit, float *mask_logits,
+                     orc_render_debug *dbg) {
+    const uint32_t S = cfg->num_stages;
+    const uint32_t geo = cfg->grid_mlp.dims[cfg->grid_mlp.num_layers] - 1;
+    const uint32_t nsh = cfg->sh_degree * cfg->sh_degree;
+    const uint32_t ncol = geo + nsh;
+
+    /* per-stage tables */
+    float *bins0 = (float *)malloc(sizeof(float) * (cfg->num_steps[0] + 1));
+    if (dbg && dbg->bins0_table) memcpy(bins0, dbg->bins0_table, sizeof(float) * (cfg->num_steps[0] + 1));
+    else orc_linspace(0.0f, 1.0f, cfg->num_steps[0] + 1, bins0);
+    uint32_t rt_prop[ORC_MAX_STAGES][ORC_MAX_LEVELS], rt_grid[ORC_MAX_LEVELS], rt_s[ORC_MAX_LEVELS], rt_m[ORC_MAX_LEVELS];
+    for (uint32_t k = 0; k + 1 < S; k++) grid_res_table(&cfg->prop_grid[k], rt_prop[k]);
+    grid_res_table(&cfg->grid, rt_grid);
+    if (cfg->with_sam) grid_res_table(&cfg->s_grid, rt_s);
+    if (cfg->with_mask) grid_res_table(&cfg->m_grid, rt_m);
+    mlp_prep pp_prop[ORC_MAX_STAGES], pp_grid, pp_view, pp_sam, pp_mask;
+    for (uint32_t k = 0; k + 1 < S; k++) mlp_prepare(&cfg->prop_mlp[k], &pp_prop[k]);
+    mlp_prepare(&cfg->grid_mlp, &pp_grid);
+    mlp_prepare(&cfg->view_mlp, &pp_view);
+    if (cfg->with_sam) mlp_prepare(&cfg->samvit_mlp, &pp_sam);
+    if (cfg->with_mask) mlp_prepare(&cfg->mask_mlp, &pp_mask);
+    float *utab[ORC_MAX_STAGES] = {0};
+    for (uint32_t k = 1; k < S; k++) {
+        const uint32_t T = cfg->num_steps[k] + 1;
+        utab[k] = (float *)malloc(sizeof(float) * T);
+        if (dbg && dbg->u_table[k]) memcpy(utab[k], dbg->u_table[k], sizeof(float) * T);
+        else orc_linspace((float)(0.5 / T), (float)(1 - 0.5 / T), T, utab[k]);
+    }
+
+#pragma omp parallel
+    {
+        float *bins = (float *)malloc(sizeof(float) * (ORC_MAX_T + 1));
+        float *nbins = (float *)malloc(sizeof(float) * (ORC_MAX_T + 1));
+        float *rbins = (float *)malloc(sizeof(float) * (ORC_MAX_T + 1));
+        float *sig = (float *)malloc(sizeof(float) * ORC_MAX_T);
+        float *wts = (float *)malloc(sizeof(float) * ORC_MAX_T);
+        float *cdf = (float *)malloc(sizeof(float) * (ORC_MAX_T + 1));
+        int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (ORC_MAX_T + 1));
+        float *xyz = (float *)malloc(sizeof(float) * ORC_MAX_T * 3);
+        float *tmid = (float *)malloc(sizeof(float) * ORC_MAX_T);
+        float feat[ORC_MAX_LEVELS * 32], h[ORC_MLP_MAXW], sfeat[ORC_MAX_LEVELS * 32];
+        float fimg[128], fsam[ORC_MAX_LEVELS * 32], minp[ORC_MLP_MAXW], mout[64], macc[64];
+
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t n = 0; n < (int64_t)N; n++) {
+            const float *o = rays_o + n * 3, *d = rays_d + n * 3;
+            float near, far;
+            near_far_one(o, d, cfg->aabb, cfg->min_near, &near, &far);
+            if (cam_near_far) {  /* renderer.py:233-235 */
+                if (cam_near_far[n * 2] > near) near = cam_near_far[n * 2];
+                if (cam_near_far[n * 2 + 1] < far) far = cam_near_far[n * 2 + 1];
+            }
+            if (dbg && dbg->nears) dbg->nears[n] = near;
+            if (dbg && dbg->fars) dbg->fars[n] = far;
+            const float s_near = spacing_fn(near), s_far = spacing_fn(far);
+
+            uint32_t T = 0, Tprev = 0;
+            for (uint32_t k = 0; k < S; k++) {
+                Tprev = T;
+                T = cfg->num_steps[k];
+                if (k == 0) {
+                    memcpy(bins, bins0, sizeof(float) * (T + 1));
+                } else {
+                    sample_pdf_one(bins, wts, Tprev, T + 1, utab[k], nbins, ind, cdf);
+                    memcpy(bins, nbins, sizeof(float) * (T + 1));
+                    if (dbg && dbg->inds[k]) memcpy(dbg->inds[k] + (size_t)n * (T + 1), ind, sizeof(int32_t) * (T + 1));
+                }
+                if (dbg && dbg->bins[k]) memcpy(dbg->bins[k] + (size_t)n * (T + 1), bins, sizeof(float) * (T + 1));
+                /* renderer.py:277-285 */
+                for (uint32_t j = 0; j <= T; j++) {
+                    const float a = s_near * (1 - bins[j]);
+                    const float b = s_far * bins[j];
+                    rbins[j] = spacing_fn_inv(a + b);
+                }
+                if (dbg && dbg->real_bins[k]) memcpy(dbg->real_bins[k] + (size_t)n * (T + 1), rbins, sizeof(float) * (T + 1));
+                for (uint32_t j = 0; j < T; j++) {
+                    tmid[j] = (rbins[j + 1] + rbins[j]) / 2;
+                    float p[3];
+                    for (int c = 0; c < 3; c++) { const float m = d[c] * tmid[j]; p[c] = o[c] + m; }
+                    if (cfg->contract) contract_one(p, xyz + j * 3);
+                    else { xyz[j * 3] = p[0]; xyz[j * 3 + 1] = p[1]; xyz[j * 3 + 2] = p[2]; }
+                }
+                const int last = (k == S - 1);
+                if (!last) { /* network.py:174-186 density(proposal=k) */
+                    const orc_grid *g = &cfg->prop_grid[k];
+                    for (uint32_t j = 0; j < T; j++) {
+                        grid_encode_point(g, rt_prop[k], xyz + j * 3, cfg->bound, feat);
+                        mlp_forward_one(&cfg->prop_mlp[k], &pp_prop[k], feat, h);
+                        sig[j] = orc_expf(h[0]);
+                    }
+                    weights_one(rbins, sig, T, cfg->last_sample_opaque, wts);
+                    if (dbg && dbg->sigmas[k]) memcpy(dbg->sigmas[k] + (size_t)n * T, sig, sizeof(float) * T);
+                    if (dbg && dbg->weights[k]) memcpy(dbg->weights[k] + (size_t)n * T, wts, sizeof(float) * T);
+                    continue;
+                }
+                /* last stage: full field, ordered compositing (renderer.py:293-357) */
+                float dirn[3];
+                {
+                    const float a = d[0] * d[0], b = d[1] * d[1], c = d[2] * d[2];
+                    const float nrm = sqrtf((a + b) + c);
+                    for (int c3 = 0; c3 < 3; c3++) dirn[c3] = d[c3] / nrm;      /* renderer.py:294 */
+                    const float a2 = dirn[0] * dirn[0], b2 = dirn[1] * dirn[1], c2 = dirn[2] * dirn[2];
+                    const float nrm2 = sqrtf((a2 + b2) + c2);
+                    for (int c3 = 0; c3 < 3; c3++) dirn[c3] = dirn[c3] / nrm2;  /* sphere_harmonics.py:82 */
+                }
+                float sh[64];
+                sh_eval_f(dirn[0], dirn[1], dirn[2], cfg->sh_degree, sh);
+                for (uint32_t c = 0; c < ncol; c++) fimg[c] = 0;
+                if (cfg->with_sam) for (uint32_t c = 0; c < cfg->s_grid.L * cfg->s_grid.C; c++) fsam[c] = 0;
+                const uint32_t ninst = cfg->with_mask ? cfg->mask_mlp.dims[cfg->mask_mlp.num_layers] : 0;
+                for (uint32_t c = 0; c < ninst; c++) macc[c] = 0;
+                double cum = 0, wsum = 0;
+                float dep = 0;
+                for (uint32_t j = 0; j < T; j++) {
+                    grid_encode_point(&cfg->grid, rt_grid, xyz + j * 3, cfg->bound, feat);
+                    mlp_forward_one(&cfg->grid_mlp, &pp_grid, feat, h);
+                    const float sigma = orc_expf(h[0]);                              /* network.py:151 */
+                    sig[j] = sigma;
+                    const float delta = rbins[j + 1] - rbins[j];
+                    float ds = delta * sigma;
+                    if (cfg->last_sample_opaque && j == T - 1) ds = INFINITY;
+                    const float alpha = 1 - orc_expf(-ds);
+                    const float tr = orc_expf(-(float)cum);
+                    float w = alpha * tr;
+                    if (w != w) w = 0;
+                    wts[j] = w;
+                    cum += (double)ds;
+                    wsum += (double)w;
+                    dep = fmaf(w, tmid[j], dep);
+                    for (uint32_t c = 0; c < geo; c++) fimg[c] = fmaf(w, h[1 + c], fimg[c]);
+                    for (uint32_t c = 0; c < nsh; c++) fimg[geo + c] = fmaf(w, sh[c], fimg[geo + c]);
+                    if (cfg->with_sam) { /* renderer.py:301-302, 361 */
+                        grid_encode_point(&cfg->s_grid, rt_s, xyz + j * 3, cfg->bound, sfeat);
+                        for (uint32_t c = 0; c < cfg->s_grid.L * cfg->s_grid.C; c++) fsam[c] = fmaf(w, sfeat[c], fsam[c]);
+                    }
+                    if (cfg->with_mask && mask_logits) { /* renderer.py:304-305, 376-385 */
+                        const uint32_t md = cfg->m_grid.L * cfg->m_grid.C;
+                        grid_encode_point(&cfg->m_grid, rt_m, xyz + j * 3, cfg->bound, minp);
+                        for (uint32_t c = 0; c < geo; c++) minp[md + c] = h[1 + c];
+                        mlp_forward_one(&cfg->mask_mlp, &pp_mask, minp, mout);
+                        for (uint32_t c = 0; c < ninst; c++) macc[c] = fmaf(w, mout[c], macc[c]);
+                    }
+                }
+                if (dbg && dbg->sigmas[k]) memcpy(dbg->sigmas[k] + (size_t)n * T, sig, sizeof(float) * T);
+                if (dbg && dbg->weights[k]) memcpy(dbg->weights[k] + (size_t)n * T, wts, sizeof(float) * T);
+                if (dbg && dbg->xyzs_last) memcpy(dbg->xyzs_last + (size_t)n * T * 3, xyz, sizeof(float) * T * 3);
+                if (dbg && dbg->f_image) memcpy(dbg->f_image + (size_t)n * ncol, fimg, sizeof(float) * ncol);
+                const float ws = (float)wsum;
+                float rgb[8];
+                mlp_forward_one(&cfg->view_mlp, &pp_view, fimg, rgb);
+                for (int c = 0; c < 3; c++) {
+                    const float sg = 1.0f / (1.0f + orc_expf(-rgb[c]));
+                    const float bgm = (1 - ws) * cfg->bg_color;
+                    rgb[c] = sg + bgm;
+                    image[n * 3 + c] = rgb[c];
+                }
+                depth[n] = dep;
+                weights_sum[n] = ws;
+                if (cfg->with_sam && samvit) { /* renderer.py:359-374, sam_use_view_direction=True wiring */
+                    const uint32_t sd = cfg->s_grid.L * cfg->s_grid.C;
+                    float *f = minp;
+                    memcpy(f, fsam, sizeof(float) * sd);
+                    memcpy(f + sd, fimg, sizeof(float) * ncol);
+                    f[sd + ncol] = rgb[0]; f[sd + ncol + 1] = rgb[1]; f[sd + ncol + 2] = rgb[2];
+                    f[sd + ncol + 3] = dep;
+                    const uint32_t od = cfg->samvit_mlp.dims[cfg->samvit_mlp.num_layers];
+                    float outv[ORC_MLP_MAXW];
+                    mlp_forward_one(&cfg->samvit_mlp, &pp_sam, f, outv);
+                    if (cfg->ln_weight) { /* nn.LayerNorm(256), network.py:115 */
+                        double mu = 0, var = 0;
+                        for (uint32_t c = 0; c < od; c++) mu += outv[c];
+                        mu /= od;
+                        for (uint32_t c = 0; c < od; c++) { const double t = outv[c] - mu; var += t * t; }
+                        var /= od;
+                        const float rstd = (float)(1.0 / sqrt(var + (double)cfg->ln_eps));
+                        for (uint32_t c = 0; c < od; c++)
+                            outv[c] = (outv[c] - (float)mu) * rstd * cfg->ln_weight[c] + cfg->ln_bias[c];
+                    }
+                    memcpy(samvit + (size_t)n * od, outv, sizeof(float) * od);
+                }
+                if (cfg->with_mask && mask_logits) memcpy(mask_logits + (size_t)n * ninst, macc, sizeof(float) * ninst);
+            }
+        }
+        free(bins); free(nbins); free(rbins); free(sig); free(wts); free(cdf); free(ind); free(xyz); free(tmid);
+    }
+    free(bins0);
+    for (uint32_t k = 1; k < S; k++) free(utab[k]);
+    for (uint32_t k = 0; k + 1 < S; k++) mlp_release(&cfg->prop_mlp[k], &pp_prop[k]);
+    mlp_release(&cfg->grid_mlp, &pp_grid);
+    mlp_release(&cfg->view_mlp, &pp_view);
+    if (cfg->with_sam) mlp_release(&cfg->samvit_mlp, &pp_sam);
+    if (cfg->with_mask) mlp_release(&cfg->mask_mlp, &pp_mask);
+}
