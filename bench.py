@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the full forward render (BASELINE.json `metric`).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): 800x800 rays per GPU, hash grid L=16 T=2^19 F=2, 2x64
+sigma/colour MLP, synthetic camera + random-init (hash-generated) weights, rays resident in HBM.
+  --schedule flat128 (default): num_steps=[128]  = "128 samples/ray through the L=16 grid", configs[1] literally
+  --schedule ref              : num_steps=[128,64,32] with both proposal grids = the reference's own default
+One "step" = one whole-image render: sn_rm_render_rays over this rank's row band (+ at N>1 the
+RCCL all-gather that assembles the image on every rank).  Weak scaling: the image grows to
+800 x (800*N) rows, each rank renders an 800-row band.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     — dominant kernel (final stage) timed with HIP events inside the timed region,
+                 algorithmic gather bytes per ray / measured time vs 8 TB/s
+  cpu_baseline — the CPU oracle (a port, oracle/) on a bounded sample of the same rays, N=1 only
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table
+MFMA_F32_PEAK = 157.3e12   # FLOP/s dense f32-input MFMA
+
+
+def algorithmic_bytes_per_ray(steps, s_bytes):
+    """sum_stages T_k * L_k * 2^D * F_k * s + 24 (o,d in) + 20 (rgb, depth, wsum out)."""
+    L = [5] * (len(steps) - 1) + [16]
+    return sum(t * l * 8 * 2 * s_bytes for t, l in zip(steps, L)) + 44
+
+
+def flops_per_ray(steps):
+    macs = sum(t * 176 for t in steps[:-1]) + steps[-1] * 7168 + 2112
+    return 2 * macs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--schedule", choices=["flat128", "ref"], default="flat128")
+    ap.add_argument("--hw", type=int, default=800)
+    ap.add_argument("--tables", choices=["f32", "f16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from helpers import product_model, synthetic_params
+    from sanerf_hq_amd import _lib, raymarching as rm, synth
+    from sanerf_hq_amd.dist import gather_image, shard_rows
+
+    steps = [128] if args.schedule == "flat128" else [128, 64, 32]
+    params = synthetic_params(steps, seed=0)
+    model = product_model(params, steps, False, dev)
+    tdt = torch.float16 if args.tables == "f16" else torch.float32
+    plan = rm.RenderPlan(model, steps, tdt)
+
+    W = args.hw
+    H = args.hw * world                      # weak scaling: one hw x hw band per rank
+    b, e = shard_rows(H, world, rank)
+    pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    intr = synth.pinhole_intrinsics(args.hw, W)   # same focal length at every N
+    rays_o, rays_d = rm.generate_rays(pose, (intr[0], intr[1], W / 2.0, H / 2.0), H, W, device=dev, row_begin=b, row_end=e)
+    n_local = rays_o.shape[0]
+    out = {}
+
+    def step():
+        rm.render_rays(plan, rays_o, rays_d, tile_w=W, out=out)
+        if world > 1:
+            band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
+            return gather_image(band, H, W)
+        return out["image"]
+
+    for _ in range(args.warmup):
+        step()
+    lib = _lib.lib()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.sn_rm_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_float * 8)()
+    cnt = (C.c_int32 * 8)()
+    _lib.check(lib.sn_rm_profile_read(ms, cnt, 8), "profile_read")
+    lib.sn_rm_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_rays = H * W
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (final stage = class 4) on this rank ----
+    s_bytes = 2 if args.tables == "f16" else 4
+    final_ms = ms[4] / max(cnt[4], 1)
+    final_steps = [steps[-1]]
+    bytes_final = n_local * (steps[-1] * 16 * 8 * 2 * s_bytes + 44)
+    flops_final = n_local * 2 * (steps[-1] * 7168 + 2112)
+    achieved = bytes_final / (final_ms * 1e-3)
+    roofline = {
+        "kernel": "k_final_stage", "bound": "hbm",
+        "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+        "avg_kernel_ms": round(final_ms, 4), "launches": int(cnt[4]),
+        "algorithmic_bytes_per_launch": int(bytes_final),
+        "mfma_f32": {"achieved_tflops": round(flops_final / (final_ms * 1e-3) / 1e12, 2), "peak_tflops": MFMA_F32_PEAK / 1e12,
+                     "frac": round(flops_final / (final_ms * 1e-3) / MFMA_F32_PEAK, 4)},
+        "other_kernels_ms": {"pack": round(ms[0] / max(cnt[0], 1), 4),
+                             "prop0": round(ms[1] / max(cnt[1], 1), 4) if cnt[1] else None,
+                             "prop1": round(ms[2] / max(cnt[2], 1), 4) if cnt[2] else None},
+        "whole_path": {"algorithmic_bytes_per_ray": algorithmic_bytes_per_ray(steps, s_bytes),
+                       "achieved_GBps": round(value / world * algorithmic_bytes_per_ray(steps, s_bytes) / 1e9, 2),
+                       "frac": round(value / world * algorithmic_bytes_per_ray(steps, s_bytes) / HBM_PEAK, 4),
+                       "flops_per_ray": flops_per_ray(steps)},
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        from helpers import oracle_cfg
+        cfg = oracle_cfg(orc, params, steps, table_f16=(args.tables == "f16"))
+        ro_h = rays_o.cpu().numpy()
+        rd_h = rays_d.cpu().numpy()
+        pick = (synth.hash_u01(1024, 77) * n_local).astype(np.int64)       # calibration sample
+        t0 = time.perf_counter(); orc.render(cfg, ro_h[pick], rd_h[pick]); t_cal = time.perf_counter() - t0
+        n_cpu = int(min(n_local, max(2048, args.cpu_seconds * 1024 / max(t_cal, 1e-6))))
+        pick = (synth.hash_u01(n_cpu, 78) * n_local).astype(np.int64)
+        t0 = time.perf_counter(); ref = orc.render(cfg, ro_h[pick], rd_h[pick]); t_cpu = time.perf_counter() - t0
+        err = float(np.abs(out["image"][torch.from_numpy(pick).to(dev)].cpu().numpy() - ref["image"]).max())
+        cpu_baseline = {"value": round(n_cpu / t_cpu, 1), "unit": "rays/s", "cores": orc.num_threads(), "kind": "port",
+                        "sample": f"{n_cpu} pseudo-random rays of the same {W}x{H} image, same weights, oracle/liboracle.so (C11+OpenMP), {t_cpu:.1f} s",
+                        "max_abs_rgb_diff_vs_gpu": err}
+
+    if rank == 0:
+        line = {
+            "metric": "rays/s full render (800x800, hashgrid L=16 + 2x64 MLP)", "value": round(value, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {W}x{args.hw} rays per GPU ({W}x{H} image), hashgrid L=16 T=2^19 F=2, "
+                                   f"32-64-64-16 + 31-32-32-3 MLPs, num_steps={steps} ({args.schedule}), tables {args.tables}, "
+                                   "arithmetic fp32, random-init weights, orbit camera",
+                       "rays_per_gpu": n_local, "image": [H, W], "schedule": args.schedule,
+                       "parallelism": f"ray-tile row bands x{world}" + (" + RCCL all-gather of rgb|depth|wsum" if world > 1 else "")},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,207 @@
+/*
+ * sanerf_hip.h — C ABI of libsanerf_hip.so, the MI355X (gfx950) implementation of
+ * SANeRF-HQ's volumetric-rendering hot path.
+ *
+ * Boundary contract
+ *   - plain `extern "C"`, raw DEVICE pointers + sizes + a hipStream_t passed as void*;
+ *     no torch / ATen types.  Small per-level / per-layer tables (offsets, dims) are
+ *     HOST data, as noted per argument.
+ *   - the caller allocates every output (the reference does the same:
+ *     gridencoder/grid.py:49,55,83,86); functions write in place.
+ *   - every function returns 0 on success or a negative sn_status; it never throws.
+ *     sn_last_error() returns a thread-local message for the last failure
+ *     (the reference raises RuntimeError through TORCH_CHECK, gridencoder.cu:15-18,392).
+ *   - all work is enqueued on `stream` (the reference launches on the legacy default
+ *     stream, gridencoder.cu:386); nothing synchronises.
+ *
+ * Each entry point names the reference interface (file:line under /root/reference)
+ * it replaces.  INTEGRATION.md shows the ctypes binding the reference side would add.
+ */
+#ifndef SANERF_HIP_H
+#define SANERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_MAX_LEVELS 32
+#define SN_MAX_LAYERS 8
+#define SN_MAX_STAGES 4
+#define SN_ABI_VERSION 1
+
+typedef void *sn_stream_t; /* hipStream_t */
+
+typedef enum {
+    SN_OK = 0,
+    SN_ERR_INVALID = -1,     /* bad argument (null pointer, unsupported D/C, ...) */
+    SN_ERR_UNSUPPORTED = -2, /* valid in the reference but not built here */
+    SN_ERR_HIP = -3,         /* HIP runtime error (launch failed, no device) */
+    SN_ERR_WORKSPACE = -4    /* workspace too small */
+} sn_status;
+
+enum { SN_F32 = 0, SN_F16 = 1 };                 /* table storage type */
+enum { SN_LAYOUT_LBC = 0, SN_LAYOUT_BLC = 1 };   /* [L,B,C] (reference kernel) or [B,L*C] (what grid.py:63 returns) */
+
+int sn_abi_version(void);
+const char *sn_last_error(void);
+/* number of HIP devices visible; <0 on error.  Lets hosts fail loudly before any launch. */
+int sn_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * gridencoder  — replaces gridencoder/src/gridencoder.h:12-16 (pybind: bindings.cpp:5-9)
+ * inputs  [B,D] f32 in [0,1] (device);  embeddings [rows,C] (device, table_dtype);
+ * offsets [L+1] int32 on the HOST (the reference keeps them on the device and re-reads them in
+ * every thread; here the per-level table — resolution per gridencoder.cu:133, size, dense/hash —
+ * is computed once on the host and passed by value);  S = (float)log2(per_level_scale);
+ * outputs f32, layout per `layout`;  dy_dx [B,L,D,C] f32 or NULL.
+ * ------------------------------------------------------------------------------------------ */
+int sn_grid_encode_forward(const float *inputs, const void *embeddings, int table_dtype,
+                           const int32_t *offsets_host, float *outputs,
+                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                           float S, uint32_t H, float *dy_dx,
+                           uint32_t gridtype, int align_corners, uint32_t interp,
+                           int layout, sn_stream_t stream);
+/* grad f32 in `layout`; grad_embeddings [rows,C] f32, zero-initialised by the caller
+ * (grid.py:83); grad_inputs [B,D] f32 written when dy_dx != NULL. */
+int sn_grid_encode_backward(const float *grad, const float *inputs, const void *embeddings, int table_dtype,
+                            const int32_t *offsets_host, float *grad_embeddings,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                            float S, uint32_t H, const float *dy_dx, float *grad_inputs,
+                            uint32_t gridtype, int align_corners, uint32_t interp,
+                            int layout, sn_stream_t stream);
+/* gridencoder.h:15 / grid.py:170-191 */
+int sn_grad_total_variation(const float *inputs, const float *embeddings, float *grad,
+                            const int32_t *offsets_host, float weight,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            float S, uint32_t H, uint32_t gridtype, int align_corners,
+                            sn_stream_t stream);
+/* gridencoder.h:16 / grid.py:193-204.  B = number of table rows. */
+int sn_grad_weight_decay(const float *embeddings, float *grad, const int32_t *offsets_host,
+                         float weight, uint32_t B, uint32_t C, uint32_t L, sn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * shencoder — replaces shencoder/src/shencoder.h:9-10.  inputs [B,3] f32 (unit vectors),
+ * outputs [B,degree^2], dy_dx [B,3,degree^2] or NULL; degree in 1..8.
+ * ------------------------------------------------------------------------------------------ */
+int sn_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t degree,
+                         float *dy_dx, sn_stream_t stream);
+/* accumulates into grad_inputs [B,3] (zero-initialised by the caller, sphere_harmonics.py:50) */
+int sn_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t degree,
+                          const float *dy_dx, float *grad_inputs, sn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * freqencoder — replaces freqencoder/src/freqencoder.h:6-9.  C = D + 2*D*deg.
+ * ------------------------------------------------------------------------------------------ */
+int sn_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                           float *outputs, sn_stream_t stream);
+int sn_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg,
+                            uint32_t C, float *grad_inputs, sn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * raymarching — the reference has no native twin for these (README.md:32-34 mentions a
+ * `raymarching` extension that is not in the tree); each replaces a block of torch ops.
+ * ------------------------------------------------------------------------------------------ */
+/* nerf/utils.py:201-205,269-287 (full image).  pose: 16 floats row-major cam2world, HOST. */
+int sn_rm_generate_rays(const float *pose_host, float fx, float fy, float cx, float cy,
+                        uint32_t H, uint32_t W, uint32_t row_begin, uint32_t row_end,
+                        float *rays_o, float *rays_d, sn_stream_t stream);
+/* nerf/renderer.py:122-139.  aabb: 6 floats, HOST.  nears/fars [N]. */
+int sn_rm_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb_host,
+                             float min_near, uint32_t N, float *nears, float *fars, sn_stream_t stream);
+/* nerf/renderer.py:60-69.  x,z [N,3]. */
+int sn_rm_contract(const float *x, uint32_t N, float *z, sn_stream_t stream);
+/* nerf/renderer.py:84-119.  bins [N,T0+1], weights [N,T0] -> out_bins [N,T];
+ * inds int32 [N,T] or NULL (the torch.searchsorted result);
+ * u: NULL (the linspace of renderer.py:98), a shared device table [T] (u_stride = 0), or per-ray
+ * rows [N,T] (u_stride = T; what perturb=True needs, renderer.py:101-102). */
+int sn_rm_sample_pdf(const float *bins, const float *weights, uint32_t N, uint32_t T0, uint32_t T,
+                     const float *u, uint32_t u_stride, float *out_bins, int32_t *inds, sn_stream_t stream);
+/* nerf/renderer.py:308-325.  real_bins [N,T+1], sigmas [N,T] -> weights [N,T]. */
+int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32_t N, uint32_t T,
+                             int last_sample_opaque, float *weights, sn_stream_t stream);
+/* nerf/renderer.py:333-338,361,384: out[n,k] = sum_t weights[n,t] * values[n,t,k]  (K may be 1). */
+int sn_rm_composite(const float *weights, const float *values, uint32_t N, uint32_t T, uint32_t K,
+                    float *out, sn_stream_t stream);
+/* backward of sn_rm_composite w.r.t. values: grad_values[n,t,k] = weights[n,t] * grad_out[n,k] */
+int sn_rm_composite_backward(const float *weights, const float *grad_out, uint32_t N, uint32_t T, uint32_t K,
+                             float *grad_values, sn_stream_t stream);
+
+/* ---- fused whole-path render: nerf/renderer.py:221-357 + network.py:146-186 ---- */
+typedef struct sn_grid_desc {
+    const void *embeddings;                 /* device */
+    int32_t     table_dtype;                /* SN_F32 / SN_F16 */
+    int32_t     offsets[SN_MAX_LEVELS + 1]; /* host values */
+    uint32_t    D, C, L;
+    float       S;                          /* (float)log2(per_level_scale) */
+    uint32_t    H;                          /* base resolution */
+    uint32_t    gridtype, align_corners, interp;
+} sn_grid_desc;
+
+typedef struct sn_mlp_desc {
+    const float *weight[SN_MAX_LAYERS];     /* device, [out,in] row-major = nn.Linear.weight */
+    const float *bias[SN_MAX_LAYERS];       /* device or NULL */
+    uint32_t     dims[SN_MAX_LAYERS + 1];
+    uint32_t     num_layers;
+    uint32_t     activation;                /* 0 relu, 1 leaky_relu(0.01) */
+    uint32_t     skip_mask;
+} sn_mlp_desc;
+
+typedef struct sn_render_cfg {
+    uint32_t     num_stages;                /* len(opt.num_steps), 1..SN_MAX_STAGES */
+    uint32_t     num_steps[SN_MAX_STAGES];
+    sn_grid_desc prop_grid[SN_MAX_STAGES];  /* stages 0..num_stages-2 (network.py:131-143) */
+    sn_mlp_desc  prop_mlp[SN_MAX_STAGES];
+    sn_grid_desc grid;                      /* network.py:93 */
+    sn_mlp_desc  grid_mlp;                  /* network.py:94: -> [sigma_raw | geo_feat] */
+    sn_mlp_desc  view_mlp;                  /* network.py:98: per ray, after compositing */
+    uint32_t     sh_degree;                 /* network.py:97 */
+    float        aabb[6];
+    float        min_near;
+    float        bound;                     /* grid bound: 2 when opt.contract */
+    int32_t      contract;
+    int32_t      last_sample_opaque;        /* opt.background == 'last_sample' */
+    float        bg_color;
+} sn_render_cfg;
+
+typedef struct sn_render_io {
+    /* inputs */
+    const float *rays_o, *rays_d;           /* [N,3] device */
+    const float *cam_near_far;              /* [N,2] device or NULL */
+    uint32_t     N;
+    uint32_t     tile_w;                    /* >0: rays are a row-major image of this width; lanes map to 8x8 pixel tiles */
+    const float *bins0_table;               /* device [num_steps[0]+1] or NULL (-> linspace recipe) */
+    const float *u_table[SN_MAX_STAGES];    /* device [num_steps[k]+1] for k>=1 or NULL */
+    /* outputs */
+    float       *image;                     /* [N,3] */
+    float       *depth;                     /* [N] */
+    float       *weights_sum;               /* [N] */
+    /* optional per-stage outputs, [N, ...] row-major like the reference tensors; NULL = not wanted */
+    float       *bins[SN_MAX_STAGES];       /* [N,T_k+1] */
+    float       *weights[SN_MAX_STAGES];    /* [N,T_k]   */
+    float       *sigmas[SN_MAX_STAGES];     /* [N,T_k]   */
+    int32_t     *inds[SN_MAX_STAGES];       /* [N,T_k+1], k>=1 */
+    float       *xyzs_last;                 /* [N,T_last,3] contracted positions of the last stage */
+    float       *geo_feat_last;             /* [N,T_last,geo] per-sample geometry features (feeds the mask head) */
+    float       *f_image;                   /* [N, geo+sh] composited colour features (feeds the SAM head) */
+    /* workspace */
+    void        *workspace;                 /* device, >= sn_rm_render_workspace_bytes() */
+    size_t       workspace_bytes;
+} sn_render_io;
+
+/* bytes of device workspace sn_rm_render_rays needs for N rays (tile_w as in sn_render_io) */
+size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w);
+int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream);
+
+/* Measurement hook (bench.py): bracket every kernel sn_rm_render_rays launches with hipEvents on the
+ * caller's stream.  Classes: 0 weight pack, 1..3 proposal stage k, 4 final stage.  profile_read
+ * synchronises, returns summed device milliseconds and launch counts per class, and resets. */
+void sn_rm_profile_enable(int on);
+int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SANERF_HIP_H */

@@ -1,0 +1,143 @@
+"""ctypes binding of libsanerf_hip.so (the C ABI declared in include/sanerf_hip.h).
+
+This is the only place the product touches native code.  There is no CPU or
+eager-torch fallback: if the library is missing, or an operator is handed a
+tensor that is not on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsanerf_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+MAX_LEVELS, MAX_LAYERS, MAX_STAGES = 32, 8, 4
+SN_F32, SN_F16 = 0, 1
+LAYOUT_LBC, LAYOUT_BLC = 0, 1
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("embeddings", C.c_void_p), ("table_dtype", C.c_int32), ("offsets", C.c_int32 * (MAX_LEVELS + 1)),
+                ("D", C.c_uint32), ("C", C.c_uint32), ("L", C.c_uint32), ("S", C.c_float), ("H", C.c_uint32),
+                ("gridtype", C.c_uint32), ("align_corners", C.c_uint32), ("interp", C.c_uint32)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("weight", C.c_void_p * MAX_LAYERS), ("bias", C.c_void_p * MAX_LAYERS),
+                ("dims", C.c_uint32 * (MAX_LAYERS + 1)), ("num_layers", C.c_uint32),
+                ("activation", C.c_uint32), ("skip_mask", C.c_uint32)]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("num_stages", C.c_uint32), ("num_steps", C.c_uint32 * MAX_STAGES),
+                ("prop_grid", GridDesc * MAX_STAGES), ("prop_mlp", MlpDesc * MAX_STAGES),
+                ("grid", GridDesc), ("grid_mlp", MlpDesc), ("view_mlp", MlpDesc),
+                ("sh_degree", C.c_uint32), ("aabb", C.c_float * 6), ("min_near", C.c_float), ("bound", C.c_float),
+                ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float)]
+
+
+class RenderIO(C.Structure):
+    _fields_ = [("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("cam_near_far", C.c_void_p),
+                ("N", C.c_uint32), ("tile_w", C.c_uint32),
+                ("bins0_table", C.c_void_p), ("u_table", C.c_void_p * MAX_STAGES),
+                ("image", C.c_void_p), ("depth", C.c_void_p), ("weights_sum", C.c_void_p),
+                ("bins", C.c_void_p * MAX_STAGES), ("weights", C.c_void_p * MAX_STAGES),
+                ("sigmas", C.c_void_p * MAX_STAGES), ("inds", C.c_void_p * MAX_STAGES),
+                ("xyzs_last", C.c_void_p), ("geo_feat_last", C.c_void_p), ("f_image", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+_u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
+
+_SIGNATURES = {
+    "sn_abi_version": (_int, []),
+    "sn_last_error": (C.c_char_p, []),
+    "sn_device_count": (_int, []),
+    "sn_grid_encode_forward": (_int, [_vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _int, _u32, _int, _vp]),
+    "sn_grid_encode_backward": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _int, _u32, _int, _vp]),
+    "sn_grad_total_variation": (_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp]),
+    "sn_grad_weight_decay": (_int, [_vp, _vp, _vp, _f32, _u32, _u32, _u32, _vp]),
+    "sn_sh_encode_forward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    "sn_sh_encode_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "sn_freq_encode_forward": (_int, [_vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "sn_freq_encode_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "sn_rm_generate_rays": (_int, [_vp, _f32, _f32, _f32, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "sn_rm_near_far_from_aabb": (_int, [_vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp]),
+    "sn_rm_contract": (_int, [_vp, _u32, _vp, _vp]),
+    "sn_rm_sample_pdf": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp]),
+    "sn_rm_weights_from_sigma": (_int, [_vp, _vp, _u32, _u32, _int, _vp, _vp]),
+    "sn_rm_composite": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    "sn_rm_composite_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    "sn_rm_render_workspace_bytes": (C.c_size_t, [C.POINTER(RenderCfg), _u32, _u32]),
+    "sn_rm_render_rays": (_int, [C.POINTER(RenderCfg), C.POINTER(RenderIO), _vp]),
+    "sn_rm_profile_enable": (None, [_int]),
+    "sn_rm_profile_read": (_int, [_vp, _vp, _int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "sanerf_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j4"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it was never built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for these operators.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().sn_last_error().decode()
+        raise RuntimeError(f"{what}: {msg}" if what else msg)
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
+    """Device pointer of a contiguous tensor on the HIP device (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")          # gridencoder.cu:15
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")    # gridencoder.cu:16
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be a {dtype} tensor, got {t.dtype}")
+    return t.data_ptr()
+
+
+def host_i32(values):
+    arr = (C.c_int32 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def host_f32(values):
+    return (C.c_float * len(values))(*[float(v) for v in values])

@@ -1,0 +1,238 @@
+// raymarch.hip — stand-alone ray-marching operators for gfx950.
+//
+// The reference has no native twin for these (its README mentions a `raymarching`
+// extension that is not in the tree); each kernel replaces a block of torch ops in
+// nerf/utils.py:get_rays and nerf/renderer.py (near_far_from_aabb, contract, sample_pdf,
+// the sigma->weights scan and the weighted sums).  One lane per ray; tensors keep the
+// reference's [N, T] row-major layout so they interoperate with torch code on either side.
+// The fused renderer (render.hip) inlines the same arithmetic with a [T, N] scratch layout.
+#include "sn_common.h"
+
+#include <float.h>
+
+namespace sn {
+
+struct Pose { float m[16]; };
+struct Aabb { float v[6]; };
+
+// nerf/utils.py:201-205, 269-287
+__global__ __launch_bounds__(256) void k_generate_rays(Pose pose, float fx, float fy, float cx, float cy,
+                                                       uint32_t W, uint32_t first, uint32_t count,
+                                                       float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t n = first + t;
+    const uint32_t row = n / W, col = n - row * W;
+    const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+    const float xs = (i - cx) / fx;
+    const float ys = -(j - cy) / fy;
+    const float zs = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float acc = xs * pose.m[k * 4 + 0];
+        acc = __builtin_fmaf(ys, pose.m[k * 4 + 1], acc);
+        acc = __builtin_fmaf(zs, pose.m[k * 4 + 2], acc);
+        rays_d[(size_t)t * 3 + k] = acc;
+        rays_o[(size_t)t * 3 + k] = pose.m[k * 4 + 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                  Aabb ab, float min_near, uint32_t N,
+                                                  float *__restrict__ nears, float *__restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float o[3] = {rays_o[(size_t)n * 3], rays_o[(size_t)n * 3 + 1], rays_o[(size_t)n * 3 + 2]};
+    const float d[3] = {rays_d[(size_t)n * 3], rays_d[(size_t)n * 3 + 1], rays_d[(size_t)n * 3 + 2]};
+    float near, far;
+    near_far_one(o, d, ab.v, min_near, near, far);
+    nears[n] = near; fars[n] = far;
+}
+
+__global__ __launch_bounds__(256) void k_contract(const float *__restrict__ x, uint32_t N, float *__restrict__ z) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float a = x[(size_t)n * 3], b = x[(size_t)n * 3 + 1], c = x[(size_t)n * 3 + 2];
+    contract3(a, b, c);
+    z[(size_t)n * 3] = a; z[(size_t)n * 3 + 1] = b; z[(size_t)n * 3 + 2] = c;
+}
+
+__device__ __forceinline__ float nan_to_num(float v) {
+    if (v != v) return 0.0f;
+    if (v == __builtin_inff()) return FLT_MAX;
+    if (v == -__builtin_inff()) return -FLT_MAX;
+    return v;
+}
+
+// nerf/renderer.py:84-119.  cdf and u are both non-decreasing, so searchsorted(right=True)
+// is one merge pass; the cdf is a running fp64 sum rounded to fp32 per prefix (= torch.cumsum
+// on CPU) and the normaliser is the fp64-accumulated sum.
+__global__ __launch_bounds__(256) void k_sample_pdf(const float *__restrict__ bins, const float *__restrict__ weights,
+                                                    uint32_t N, uint32_t T0, uint32_t T, const float *__restrict__ u,
+                                                    uint32_t u_stride, float *__restrict__ out_bins, int32_t *__restrict__ inds) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *w = weights + (size_t)n * T0;
+    const float *b = bins + (size_t)n * (T0 + 1);
+    double acc = 0;
+    for (uint32_t i = 0; i < T0; ++i) acc += (double)(w[i] + 0.01f);
+    const float wsum = (float)acc;
+    const float ustart = (float)(0.5 / T), uend = (float)(1 - 0.5 / T);
+    const float ustep = T > 1 ? (uend - ustart) / (float)(T - 1) : 0.0f;
+
+    uint32_t i = 0;          // next cdf index to test
+    acc = 0;
+    float c_prev = 0.0f;     // cdf[i-1]
+    float c_cur = 0.0f;      // cdf[i]   (cdf[0] = 0)
+    float b_prev = b[0], b_cur = b[0];
+    for (uint32_t j = 0; j < T; ++j) {
+        const float uj = u ? u[(size_t)n * u_stride + j] : linspace_at(ustart, uend, ustep, T, j);
+        while (i <= T0 && c_cur <= uj) {   // advance: cdf[i] <= u
+            c_prev = c_cur; b_prev = b_cur;
+            ++i;
+            if (i <= T0) {
+                const float pdf = (w[i - 1] + 0.01f) / wsum;
+                acc += (double)pdf;
+                const float c = (float)acc;
+                c_cur = c > 1.0f ? 1.0f : c;
+                b_cur = b[i];
+            }
+        }
+        // ind = i ; below = clamp(i-1, 0, T0) ; above = clamp(i, 0, T0)
+        float c0, c1, b0, b1;
+        if (i == 0) { c0 = c_cur; b0 = b_cur; c1 = c_cur; b1 = b_cur; }
+        else if (i > T0) { c0 = c_prev; b0 = b_prev; c1 = c_prev; b1 = b_prev; }
+        else { c0 = c_prev; b0 = b_prev; c1 = c_cur; b1 = b_cur; }
+        float t = nan_to_num((uj - c0) / (c1 - c0));
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        const float m = t * (b1 - b0);
+        out_bins[(size_t)n * T + j] = b0 + m;
+        if (inds) inds[(size_t)n * T + j] = (int32_t)i;
+    }
+}
+
+// nerf/renderer.py:308-325
+__global__ __launch_bounds__(256) void k_weights(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
+                                                 uint32_t N, uint32_t T, int last_opaque, float *__restrict__ weights) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *rb = real_bins + (size_t)n * (T + 1);
+    const float *sg = sigmas + (size_t)n * T;
+    double cum = 0;
+    float prev = rb[0];
+    for (uint32_t j = 0; j < T; ++j) {
+        const float next = rb[j + 1];
+        const float delta = next - prev;
+        prev = next;
+        float ds = delta * sg[j];
+        if (last_opaque && j == T - 1) ds = __builtin_inff();
+        const float alpha = 1.0f - expf_det(-ds);
+        const float tr = expf_det(-(float)cum);
+        float w = alpha * tr;
+        if (w != w) w = 0.0f;
+        weights[(size_t)n * T + j] = w;
+        cum += (double)ds;
+    }
+}
+
+// out[n,k] = sum_t w[n,t] * v[n,t,k], sequential fmaf over t (renderer.py:333-338,361,384)
+__global__ __launch_bounds__(256) void k_composite(const float *__restrict__ weights, const float *__restrict__ values,
+                                                   uint32_t N, uint32_t T, uint32_t K, float *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)N * K) return;
+    const uint32_t n = (uint32_t)(t / K), k = (uint32_t)(t - (uint64_t)n * K);
+    const float *w = weights + (size_t)n * T;
+    const float *v = values + (size_t)n * T * K + k;
+    float acc = 0;
+    for (uint32_t j = 0; j < T; ++j) acc = __builtin_fmaf(w[j], v[(size_t)j * K], acc);
+    out[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_composite_backward(const float *__restrict__ weights, const float *__restrict__ grad_out,
+                                                            uint32_t N, uint32_t T, uint32_t K, float *__restrict__ grad_values) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)N * T * K) return;
+    const uint32_t k = (uint32_t)(t % K);
+    const uint64_t nt = t / K;
+    const uint32_t n = (uint32_t)(nt / T);
+    grad_values[t] = weights[nt] * grad_out[(size_t)n * K + k];
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+extern "C" {
+
+int sn_rm_generate_rays(const float *pose_host, float fx, float fy, float cx, float cy,
+                        uint32_t H, uint32_t W, uint32_t row_begin, uint32_t row_end,
+                        float *rays_o, float *rays_d, sn_stream_t stream) {
+    SN_REQUIRE(pose_host && rays_o && rays_d, "generate_rays: NULL pointer");
+    SN_REQUIRE(row_begin <= row_end && row_end <= H, "generate_rays: rows [%u,%u) outside image height %u", row_begin, row_end, H);
+    Pose p;
+    for (int i = 0; i < 16; ++i) p.m[i] = pose_host[i];
+    const uint32_t first = row_begin * W, count = (row_end - row_begin) * W;
+    if (count == 0) return SN_OK;
+    hipLaunchKernelGGL(k_generate_rays, dim3(div_up(count, 256)), dim3(256), 0, (hipStream_t)stream, p, fx, fy, cx, cy, W, first, count, rays_o, rays_d);
+    SN_LAUNCH_CHECK("k_generate_rays");
+    return SN_OK;
+}
+
+int sn_rm_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb_host,
+                             float min_near, uint32_t N, float *nears, float *fars, sn_stream_t stream) {
+    SN_REQUIRE(rays_o && rays_d && aabb_host && nears && fars, "near_far_from_aabb: NULL pointer");
+    Aabb ab;
+    for (int i = 0; i < 6; ++i) ab.v[i] = aabb_host[i];
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_near_far, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, ab, min_near, N, nears, fars);
+    SN_LAUNCH_CHECK("k_near_far");
+    return SN_OK;
+}
+
+int sn_rm_contract(const float *x, uint32_t N, float *z, sn_stream_t stream) {
+    SN_REQUIRE(x && z, "contract: NULL pointer");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_contract, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, x, N, z);
+    SN_LAUNCH_CHECK("k_contract");
+    return SN_OK;
+}
+
+int sn_rm_sample_pdf(const float *bins, const float *weights, uint32_t N, uint32_t T0, uint32_t T,
+                     const float *u, uint32_t u_stride, float *out_bins, int32_t *inds, sn_stream_t stream) {
+    SN_REQUIRE(bins && weights && out_bins, "sample_pdf: NULL pointer");
+    SN_REQUIRE(T0 >= 1 && T >= 1, "sample_pdf: T0=%u T=%u must be >= 1", T0, T);
+    SN_REQUIRE(u_stride == 0 || u_stride == T, "sample_pdf: u_stride must be 0 (shared table) or T (per-ray rows)");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_sample_pdf, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, bins, weights, N, T0, T, u, u_stride, out_bins, inds);
+    SN_LAUNCH_CHECK("k_sample_pdf");
+    return SN_OK;
+}
+
+int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32_t N, uint32_t T,
+                             int last_sample_opaque, float *weights, sn_stream_t stream) {
+    SN_REQUIRE(real_bins && sigmas && weights, "weights_from_sigma: NULL pointer");
+    if (N == 0 || T == 0) return SN_OK;
+    hipLaunchKernelGGL(k_weights, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, N, T, last_sample_opaque, weights);
+    SN_LAUNCH_CHECK("k_weights");
+    return SN_OK;
+}
+
+int sn_rm_composite(const float *weights, const float *values, uint32_t N, uint32_t T, uint32_t K,
+                    float *out, sn_stream_t stream) {
+    SN_REQUIRE(weights && values && out, "composite: NULL pointer");
+    if (N == 0 || K == 0) return SN_OK;
+    hipLaunchKernelGGL(k_composite, dim3(div_up((uint64_t)N * K, 256)), dim3(256), 0, (hipStream_t)stream, weights, values, N, T, K, out);
+    SN_LAUNCH_CHECK("k_composite");
+    return SN_OK;
+}
+
+int sn_rm_composite_backward(const float *weights, const float *grad_out, uint32_t N, uint32_t T, uint32_t K,
+                             float *grad_values, sn_stream_t stream) {
+    SN_REQUIRE(weights && grad_out && grad_values, "composite_backward: NULL pointer");
+    if (N == 0 || K == 0 || T == 0) return SN_OK;
+    hipLaunchKernelGGL(k_composite_backward, dim3(div_up((uint64_t)N * T * K, 256)), dim3(256), 0, (hipStream_t)stream, weights, grad_out, N, T, K, grad_values);
+    SN_LAUNCH_CHECK("k_composite_backward");
+    return SN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,921 @@
+// render.hip — fused whole-path renderer for gfx950 (sn_rm_render_rays).
+//
+// Replaces the torch op chain of NeRFRenderer.run (nerf/renderer.py:221-357) together with
+// NeRFNetwork.density / forward (nerf/network.py:146-186) for perturb=False rendering.
+//
+// Mapping: ONE LANE = ONE RAY for the whole march.  A wave owns an 8x8 pixel
+// tile, a 256-thread workgroup a 16x16 tile, and all 64 lanes step through the samples in
+// lock-step, so at step j the wave's 64 gathers per corner land in one small 3-D patch:
+// coarse levels collapse to a handful of cache lines and fine levels share vertices between
+// neighbouring pixels.  Per-ray state (transmittance, colour accumulators, cdf merge
+// cursors) lives in registers, in order, so the fp64 prefix sums that decide the sample
+// indices are sequential exactly like the CPU oracle's.
+//
+//   k_prop_stage   stage k < last: bins -> xyz -> contract -> hash grid (L<=8,C=2) ->
+//                  tiny MLP (VALU fmaf chains, weights in SGPRs) -> sigma -> weights
+//                  (scratch [T][Npad]) -> in-kernel sample_pdf merge -> next bins (scratch).
+//   k_final_stage  last stage: hash grid (L=16,C=2) -> 32->64->64->16 MLP on the matrix
+//                  cores (v_mfma_f32_32x32x2_f32, exact fp32; operands exchanged between the
+//                  two half-waves with v_permlane32_swap, weights pre-packed in LDS in
+//                  A-operand order) -> sigma/geo features -> ordered compositing in
+//                  registers -> per-ray view MLP -> sigmoid -> image/depth/weights_sum.
+#include "sn_common.h"
+#include "sh_basis.inc"
+
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace sn {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct RayCommon {
+    const float *rays_o, *rays_d, *cnf;
+    uint32_t N;        // rays in this launch
+    uint32_t W;        // image width (tile mode) or 0
+    uint32_t rows;     // image rows in this launch (tile mode)
+    uint32_t Npad;     // scratch row stride = gridDim.x * 256
+    float aabb[6];
+    float min_near, bound;
+    int contract, last_opaque;
+    float bg;
+};
+
+// lane -> ray.  Tile mode: block = 16x16 pixels, wave = 8x8.
+__device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t &n) {
+    const uint32_t tid = threadIdx.x;
+    if (rc.W) {
+        const uint32_t tiles_x = (rc.W + 15u) >> 4;
+        const uint32_t by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+        const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+        const bool ok = px < rc.W && py < rc.rows;
+        n = ok ? py * rc.W + px : 0u;
+        return ok;
+    }
+    n = blockIdx.x * 256u + tid;
+    const bool ok = n < rc.N;
+    if (!ok) n = 0;
+    return ok;
+}
+
+struct RaySetup {
+    float o[3], d[3];
+    float s_near, s_far;
+};
+
+__device__ __forceinline__ void setup_ray(const RayCommon &rc, uint32_t n, RaySetup &rs) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rs.o[k] = rc.rays_o[(size_t)n * 3 + k]; rs.d[k] = rc.rays_d[(size_t)n * 3 + k]; }
+    float near, far;
+    near_far_one(rs.o, rs.d, rc.aabb, rc.min_near, near, far);
+    if (rc.cnf) {  // renderer.py:233-235
+        const float cn = rc.cnf[(size_t)n * 2], cf = rc.cnf[(size_t)n * 2 + 1];
+        near = cn > near ? cn : near;
+        far = cf < far ? cf : far;
+    }
+    rs.s_near = spacing_fn(near);
+    rs.s_far = spacing_fn(far);
+}
+
+// renderer.py:277 — normalised bin -> distance along the ray
+__device__ __forceinline__ float real_bin(const RaySetup &rs, float b) {
+    const float a = rs.s_near * (1.0f - b);
+    const float c = rs.s_far * b;
+    return spacing_inv(a + c);
+}
+
+// renderer.py:279-285 + grid.py:156: sample position -> table coordinate in [0,1]
+__device__ __forceinline__ void sample_x01(const RayCommon &rc, const RaySetup &rs, float tmid, float (&p)[3], float (&x01)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float m = rs.d[k] * tmid; p[k] = rs.o[k] + m; }
+    if (rc.contract) contract3(p[0], p[1], p[2]);
+    const float den = 2.0f * rc.bound;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x01[k] = (p[k] + rc.bound) / den;
+}
+
+// Row indices of the 8 corners of one cell.  One wave-uniform branch per LEVEL (hashed vs dense)
+// instead of one per corner, so the eight gathers of a level issue back to back.
+// Fast-path assumption checked on the host (levels_fast): hashed levels have a power-of-two
+// size, dense levels index all three dimensions and need no modulo.
+__device__ __forceinline__ void corner_rows(const uint32_t (&cell)[3], uint32_t res, uint32_t size, uint32_t mode,
+                                            uint32_t (&rows)[8]) {
+    const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
+    const uint32_t x1 = umin(x0 + 1u, res - 1u), y1 = umin(y0 + 1u, res - 1u), z1 = umin(z0 + 1u, res - 1u);
+    if (mode & 1u) {   // gridencoder.cu:45-59
+        const uint32_t m = size - 1u;
+        const uint32_t hy0 = y0 * 2654435761u, hy1 = y1 * 2654435761u;
+        const uint32_t hz0 = z0 * 805459861u, hz1 = z1 * 805459861u;
+        rows[0] = (x0 ^ hy0 ^ hz0) & m; rows[1] = (x1 ^ hy0 ^ hz0) & m;
+        rows[2] = (x0 ^ hy1 ^ hz0) & m; rows[3] = (x1 ^ hy1 ^ hz0) & m;
+        rows[4] = (x0 ^ hy0 ^ hz1) & m; rows[5] = (x1 ^ hy0 ^ hz1) & m;
+        rows[6] = (x0 ^ hy1 ^ hz1) & m; rows[7] = (x1 ^ hy1 ^ hz1) & m;
+    } else {           // gridencoder.cu:66-70 with all three dimensions in the walk
+        const uint32_t r2 = res * res;
+        const uint32_t dy0 = y0 * res, dy1 = y1 * res, dz0 = z0 * r2, dz1 = z1 * r2;
+        rows[0] = x0 + dy0 + dz0; rows[1] = x1 + dy0 + dz0;
+        rows[2] = x0 + dy1 + dz0; rows[3] = x1 + dy1 + dz0;
+        rows[4] = x0 + dy0 + dz1; rows[5] = x1 + dy0 + dz1;
+        rows[6] = x0 + dy1 + dz1; rows[7] = x1 + dy1 + dz1;
+    }
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void level_interp(const T *__restrict__ tab, const uint32_t (&rows)[8], const float (&pos)[3], float (&acc)[C]) {
+    // issue the 8 gathers first (32-bit byte offsets from a wave-uniform base: saddr-form loads)
+    float v[8][C];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const T *row = reinterpret_cast<const T *>(reinterpret_cast<const char *>(tab) + rows[i] * (uint32_t)(C * sizeof(T)));
+        if constexpr (C == 2 && sizeof(T) == 4) {
+            const float2 t = *reinterpret_cast<const float2 *>(row);
+            v[i][0] = t.x; v[i][1] = t.y;
+        } else if constexpr (C == 2 && sizeof(T) == 2) {
+            const __half2 t = *reinterpret_cast<const __half2 *>(row);
+            v[i][0] = __low2float(t); v[i][1] = __high2float(t);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[i][c] = table_ld<T>(row + c);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; ++idx) {   // corner order and weight products exactly as gridencoder.cu:171-192
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, v[idx][c], acc[c]);
+    }
+}
+
+// all levels of one grid at one position; D = 3.  gridencoder.cu:94-201 per level.
+template <typename T, int L, int C>
+__device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
+                                              float (&feat)[L * C]) {
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) oob |= (x01[d] < 0.0f || x01[d] > 1.0f);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
+        const T *tab = table + (size_t)g.off[l] * C;
+        float pos[3], deriv[3];
+        uint32_t cell[3];
+        grid_locate<3>(x01, res, g.align_corners != 0, g.interp, pos, deriv, cell);
+        float acc[C];
+        uint32_t rows[8];
+        corner_rows(cell, res, size, mode, rows);
+        level_interp<T, C>(tab, rows, pos, acc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) feat[l * C + c] = oob ? 0.0f : acc[c];
+    }
+}
+
+// y = act(W x), W [OUT][IN] row-major at a wave-uniform address (SGPR / scalar-cache loads);
+// each output is one k-ascending fmaf chain (the oracle's order).
+template <int IN, int OUT, int ACT>
+__device__ __forceinline__ void dense_uniform(const float *__restrict__ W, const float (&x)[IN], float (&y)[OUT]) {
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < IN; ++k) acc = __builtin_fmaf(W[o * IN + k], x[k], acc);
+        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        y[o] = acc;
+    }
+}
+
+// An always-zero offset the optimiser cannot see through.  Adding it to an LDS index inside the
+// sample loop stops loop-invariant code motion from hoisting every (loop-invariant) weight
+// read out of the loop and pinning hundreds of VGPRs for the whole march.
+__device__ __forceinline__ uint32_t opaque_zero() {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
+// Tiny-MLP weights are staged once per workgroup in LDS with rows padded to a multiple of 4
+// floats, and read back at wave-uniform addresses (LDS broadcast, one ds_read_b128 per 4
+// weights).  Reading them through global pointers makes hipcc hoist hundreds of vector loads
+// (it cannot prove the buffers read-only next to the kernel's stores) and wrecks occupancy.
+template <int IN> struct PadIn { static constexpr int value = (IN + 3) & ~3; };
+
+template <int IN, int OUT>
+__device__ __forceinline__ void stage_weights(float *__restrict__ dst, const float *__restrict__ src) {
+    constexpr int INP = PadIn<IN>::value;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(OUT * INP); i += blockDim.x) {
+        const uint32_t o = i / INP, k = i - o * INP;
+        dst[i] = k < (uint32_t)IN ? src[o * IN + k] : 0.0f;
+    }
+}
+
+// y = act(W x) with W in LDS (padded rows), fully unrolled; k-ascending fmaf chain per output.
+template <int IN, int OUT, int ACT>
+__device__ __forceinline__ void dense_ldsw(const float *__restrict__ Wl, const float (&x)[IN], float (&y)[OUT]) {
+    constexpr int INP = PadIn<IN>::value;
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < INP / 4; ++k4) {
+            const float4 w = *reinterpret_cast<const float4 *>(Wl + o * INP + 4 * k4);
+            if (4 * k4 + 0 < IN) acc = __builtin_fmaf(w.x, x[4 * k4 + 0], acc);
+            if (4 * k4 + 1 < IN) acc = __builtin_fmaf(w.y, x[4 * k4 + 1], acc);
+            if (4 * k4 + 2 < IN) acc = __builtin_fmaf(w.z, x[4 * k4 + 2], acc);
+            if (4 * k4 + 3 < IN) acc = __builtin_fmaf(w.w, x[4 * k4 + 3], acc);
+        }
+        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        y[o] = acc;
+    }
+}
+
+// same, but the output loop stays rolled and activations travel through an LDS column
+// (xin[k*stride] -> yout[o*stride]); x is read completely before the first write, so
+// xin == yout is allowed.
+template <int IN, int OUT, int ACT>
+__device__ __forceinline__ void dense_ldsw_col(const float *__restrict__ Wl, const float *xin, float *yout, uint32_t stride) {
+    constexpr int INP = PadIn<IN>::value;
+    float x[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = xin[k * stride];
+#pragma unroll 1
+    for (int o = 0; o < OUT; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < INP / 4; ++k4) {
+            const float4 w = *reinterpret_cast<const float4 *>(Wl + o * INP + 4 * k4);
+            if (4 * k4 + 0 < IN) acc = __builtin_fmaf(w.x, x[4 * k4 + 0], acc);
+            if (4 * k4 + 1 < IN) acc = __builtin_fmaf(w.y, x[4 * k4 + 1], acc);
+            if (4 * k4 + 2 < IN) acc = __builtin_fmaf(w.z, x[4 * k4 + 2], acc);
+            if (4 * k4 + 3 < IN) acc = __builtin_fmaf(w.w, x[4 * k4 + 3], acc);
+        }
+        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        yout[o * stride] = acc;
+    }
+}
+
+// degree-4 real SH (16 values) of a unit vector; basis generated by tools/gen_sh.py
+__device__ __forceinline__ void sh_degree4(float x, float y, float z, float (&o)[16]) {
+    const uint32_t C = 4u;
+    SN_SH_POWERS
+    (void)x4; (void)x5; (void)x6; (void)x7; (void)y4; (void)y5; (void)y6; (void)y7; (void)z4; (void)z5; (void)z6; (void)z7;
+    SN_SH_VALUES(o);
+}
+
+__device__ __forceinline__ float nan_to_num(float v) {
+    if (v != v) return 0.0f;
+    if (v == __builtin_inff()) return FLT_MAX;
+    if (v == -__builtin_inff()) return -FLT_MAX;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// proposal stage
+// ------------------------------------------------------------------------------------------
+struct PropArgs {
+    RayCommon rc;
+    GridLevels g;
+    const void *table;
+    const float *w0, *w1;        // MLP weights (device), [HID][IN], [1][HID]
+    uint32_t T, Tn;              // steps of this stage; bins of the next stage = Tn + 1
+    const float *bins_in;        // scratch [T+1][Npad] or NULL (stage 0)
+    const float *bins0_tab;      // device [T+1] or NULL (stage 0 only)
+    const float *u_tab;          // device [Tn+1] or NULL
+    float *w_scr;                // scratch [T][Npad]
+    float *bins_out;             // scratch [Tn+1][Npad]
+    float *dbg_bins, *dbg_w, *dbg_sigma;  // [N,T+1], [N,T], [N,T] or NULL
+    int32_t *dbg_inds;                    // [N,Tn+1] or NULL
+};
+
+template <typename TT, int L, int C, int HID>
+__global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
+    constexpr int IN = L * C;
+    __shared__ __attribute__((aligned(16))) float lds_w0[HID * PadIn<IN>::value];
+    __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];
+    stage_weights<IN, HID>(lds_w0, a.w0);
+    stage_weights<HID, 1>(lds_w1, a.w1);
+    __syncthreads();
+    uint32_t n;
+    const bool ok = ray_of_lane(a.rc, n);
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;   // scratch column
+    const uint32_t Npad = a.rc.Npad;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    const uint32_t T = a.T;
+    const float b0step = 1.0f / (float)T;                 // (1-0)/(steps-1), steps = T+1
+
+    auto bin_at = [&](uint32_t j) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
+        if (a.bins0_tab) return a.bins0_tab[j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+
+    // ---- pass 1: sigma -> weights (renderer.py:277-325) ----
+    float bprev = bin_at(0);
+    float rb_prev = real_bin(rs, bprev);
+    if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
+    double cum = 0.0, wacc = 0.0;
+    const TT *table = reinterpret_cast<const TT *>(a.table);
+    for (uint32_t j = 0; j < T; ++j) {
+        const float bnext = bin_at(j + 1);
+        const float rb_next = real_bin(rs, bnext);
+        const float tmid = (rb_next + rb_prev) / 2.0f;
+        float p[3], x01[3];
+        sample_x01(a.rc, rs, tmid, p, x01);
+        float feat[L * C];
+        encode_levels<TT, L, C>(table, a.g, x01, feat);
+        float h[HID], raw[1];
+        const uint32_t oz = opaque_zero();
+        dense_ldsw<IN, HID, 1>(lds_w0 + oz, feat, h);
+        dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, raw);
+        const float sigma = expf_det(raw[0]);                // trunc_exp forward (activation.py:9)
+        const float delta = rb_next - rb_prev;
+        float ds = delta * sigma;
+        if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+        const float alpha = 1.0f - expf_det(-ds);
+        const float tr = expf_det(-(float)cum);
+        float w = alpha * tr;
+        if (w != w) w = 0.0f;
+        a.w_scr[(size_t)j * Npad + r] = w;
+        cum += (double)ds;
+        wacc += (double)(w + 0.01f);
+        if (ok) {
+            if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
+            if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
+            if (a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
+        }
+        rb_prev = rb_next;
+    }
+
+    // ---- pass 2: sample_pdf (renderer.py:84-119) as one merge of cdf against u ----
+    const float wsum = (float)wacc;
+    const uint32_t Tq = a.Tn + 1u;
+    const float ustart = (float)(0.5 / Tq), uend = (float)(1 - 0.5 / Tq);
+    const float ustep = (uend - ustart) / (float)(Tq - 1u);
+    uint32_t i = 0;
+    double acc = 0.0;
+    float c_prev = 0.0f, c_cur = 0.0f;
+    float b_cur = bin_at(0), b_prev = b_cur;
+    for (uint32_t j = 0; j < Tq; ++j) {
+        const float uj = a.u_tab ? a.u_tab[j] : linspace_at(ustart, uend, ustep, Tq, j);
+        while (i <= T && c_cur <= uj) {
+            c_prev = c_cur; b_prev = b_cur;
+            ++i;
+            if (i <= T) {
+                const float pdf = (a.w_scr[(size_t)(i - 1) * Npad + r] + 0.01f) / wsum;
+                acc += (double)pdf;
+                const float c = (float)acc;
+                c_cur = c > 1.0f ? 1.0f : c;
+                b_cur = bin_at(i);
+            }
+        }
+        float c0, c1, bb0, bb1;
+        if (i == 0) { c0 = c_cur; bb0 = b_cur; c1 = c_cur; bb1 = b_cur; }
+        else if (i > T) { c0 = c_prev; bb0 = b_prev; c1 = c_prev; bb1 = b_prev; }
+        else { c0 = c_prev; bb0 = b_prev; c1 = c_cur; bb1 = b_cur; }
+        float t = nan_to_num((uj - c0) / (c1 - c0));
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        const float m = t * (bb1 - bb0);
+        a.bins_out[(size_t)j * Npad + r] = bb0 + m;
+        if (ok && a.dbg_inds) a.dbg_inds[(size_t)n * Tq + j] = (int32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// final stage
+// ------------------------------------------------------------------------------------------
+struct FinalArgs {
+    RayCommon rc;
+    GridLevels g;
+    const void *table;
+    const float *mlp_pack;       // MFMA path: A-operand-ordered weights (floats, PACK_FLOATS)
+    const float *w[3];           // VALU path: raw [out][in] weights of grid_mlp
+    const float *vw[3];          // view_mlp weights
+    uint32_t T;
+    const float *bins_in;        // scratch [T+1][Npad] or NULL (single-stage)
+    const float *bins0_tab;
+    uint32_t sh_degree;
+    float *image, *depth, *wsum;
+    float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
+};
+
+// A-operand packing for the 32->64->64->16 MLP on v_mfma_f32_32x32x2_f32.
+//   D[m][j] += sum_k A[m][k] * B[k][j],  A = weights (m = output neuron), B = activations
+//   (j = sample).  Lane l supplies A[m = l&31][k = l>>5] and B[k = l>>5][j = l&31]; the
+//   accumulator register r of lane l holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+//   Because that accumulator layout IS a valid B-operand layout (low half-wave: row h0(r),
+//   high half-wave: row h0(r)+4), layer n+1 consumes layer n's accumulators in place; only
+//   the weights are permuted, once, here.
+constexpr int PACK_L1 = 0;                       // [mt 2][step 16][64]
+constexpr int PACK_L2 = PACK_L1 + 2 * 16 * 64;   // [mt 2][step 32][64]
+constexpr int PACK_L3 = PACK_L2 + 2 * 32 * 64;   // [step 32][64]
+constexpr int PACK_FLOATS = PACK_L3 + 32 * 64;   // 8192 floats = 32 KiB
+
+__global__ void k_pack_grid_mlp(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
+                                float *__restrict__ pack) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)PACK_FLOATS) return;
+    const uint32_t lane = t & 63u, vec = t >> 6;
+    const uint32_t m = lane & 31u, hi = lane >> 5;
+    float v;
+    if (vec < 32u) {                       // layer 1: in 32 -> out 64
+        const uint32_t mt = vec >> 4, s = vec & 15u;
+        v = w1[(mt * 32u + m) * 32u + 2u * s + hi];
+    } else if (vec < 96u) {                // layer 2: in 64 -> out 64
+        const uint32_t q = vec - 32u, mt = q >> 5, s = q & 31u, src_mt = s >> 4, r = s & 15u;
+        const uint32_t h = src_mt * 32u + (r & 3u) + 8u * (r >> 2) + 4u * hi;
+        v = w2[(mt * 32u + m) * 64u + h];
+    } else {                               // layer 3: in 64 -> out 16 (rows 16..31 are zero padding)
+        const uint32_t s = vec - 96u, src_mt = s >> 4, r = s & 15u;
+        const uint32_t h = src_mt * 32u + (r & 3u) + 8u * (r >> 2) + 4u * hi;
+        v = m < 16u ? w3[m * 64u + h] : 0.0f;
+    }
+    pack[t] = v;
+}
+
+__device__ __forceinline__ floatx16 relu16(floatx16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+    return v;
+}
+
+// 32 -> 64 -> 64 -> 16 for the wave's 64 samples (lane = sample).
+// Features arrive through the wave's LDS slab fe[k][lane] (written by encode_levels_lds), which
+// is already a B-operand image: step s of sample tile t reads fe[2s + (lane>>5)][32t + (lane&31)].
+__device__ __forceinline__ void grid_mlp_mfma(const float *__restrict__ lds_pack, const float *__restrict__ fe, float (&out)[16]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = lane & 31u, hi = lane >> 5;
+    float res[2][8];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        floatx16 h1[2], h2[2], o3;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_pack[PACK_L1 + (mt * 16 + s) * 64 + lane],
+                                                           fe[(2 * s + hi) * 64 + tile * 32 + lo], acc, 0, 0, 0);
+            h1[mt] = relu16(acc);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_pack[PACK_L2 + (mt * 32 + s) * 64 + lane], h1[s >> 4][s & 15], acc, 0, 0, 0);
+            h2[mt] = relu16(acc);
+        }
+        {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_pack[PACK_L3 + s * 64 + lane], h2[s >> 4][s & 15], acc, 0, 0, 0);
+            o3 = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) res[tile][r] = o3[r];
+    }
+    // bring every sample's 16 outputs to its own lane: accumulator reg r of tile t holds rows
+    // base(r) [low half-wave] / base(r)+4 [high half-wave] of sample 32t + (lane&31)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(res[0][r]), __float_as_uint(res[1][r]), false, false);
+        const int base = (r & 3) + 8 * (r >> 2);
+        out[base] = __uint_as_float(rr[0]);
+        out[base + 4] = __uint_as_float(rr[1]);
+    }
+}
+
+// Scalar-pipe fallback of the same MLP (SN_RENDER_MLP=valu): activations live in per-thread LDS
+// columns act[k][tid]; every neuron is one k-ascending fmaf chain (the oracle's order).
+template <int IN, int OUT, int ACT>
+__device__ __forceinline__ void dense_lds(const float *__restrict__ W, const float *__restrict__ xin, float *__restrict__ yout, uint32_t stride) {
+    float x[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = xin[k * stride];
+#pragma unroll 1
+    for (int o = 0; o < OUT; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < IN; ++k) acc = __builtin_fmaf(W[o * IN + k], x[k], acc);
+        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        yout[o * stride] = acc;
+    }
+}
+
+// hash-grid features of one position written to an LDS column fe[k * stride]; levels are
+// issued in groups of GROUP so at most GROUP*8 gathers are in flight per lane.
+template <typename T, int L, int C, int GROUP>
+__device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
+                                                  float *__restrict__ fe, uint32_t stride) {
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) oob |= (x01[d] < 0.0f || x01[d] > 1.0f);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
+        const T *tab = table + (size_t)g.off[l] * C;
+        float pos[3], deriv[3];
+        uint32_t cell[3];
+        grid_locate<3>(x01, res, g.align_corners != 0, g.interp, pos, deriv, cell);
+        float acc[C];
+        uint32_t rows[8];
+        corner_rows(cell, res, size, mode, rows);
+        level_interp<T, C>(tab, rows, pos, acc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) fe[(l * C + c) * stride] = oob ? 0.0f : acc[c];
+        if ((l % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, bool MFMA>
+__global__ __launch_bounds__(256, MFMA ? 2 : 1) void k_final_stage(FinalArgs a) {
+    constexpr int IN = L * C;
+    constexpr int GEO = NOUT - 1;
+    constexpr int NSH = 16;                       // sh degree 4 (network.py:97)
+    constexpr int NCOL = GEO + NSH;
+    static_assert(!MFMA || (IN == 32 && H1 == 64 && H2 == 64 && NOUT == 16), "MFMA path is the 32-64-64-16 MLP");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // ---- LDS carve-up ----
+    //  MFMA : [ packed weights 32 KiB | per-wave feature slabs fe[IN][64] x 4 ]
+    //  VALU : [ activation columns actA[64][256] | actB[64][256] ]  (weights read through the scalar cache)
+    float *fe;            // this lane's feature column base
+    uint32_t fstride;     // distance between consecutive features of one lane
+    float *actB = nullptr;
+    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value, VW2 = 3 * PadIn<VH>::value;
+    float *lds_vw;        // view_mlp weights (padded rows), all three layers back to back
+    if constexpr (MFMA) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)PACK_FLOATS / 4u; i += 256u)
+            reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(a.mlp_pack)[i];
+        fe = lds + PACK_FLOATS + (threadIdx.x >> 6) * (IN * 64) + (threadIdx.x & 63u);
+        fstride = 64u;
+        lds_vw = lds + PACK_FLOATS + 4 * IN * 64;
+    } else {
+        fe = lds + threadIdx.x;
+        actB = lds + 64 * 256 + threadIdx.x;
+        fstride = 256u;
+        lds_vw = lds + 2 * 64 * 256;
+    }
+    stage_weights<NCOL, VH>(lds_vw, a.vw[0]);
+    stage_weights<VH, VH>(lds_vw + VW0, a.vw[1]);
+    stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
+    __syncthreads();
+
+    uint32_t n;
+    const bool ok = ray_of_lane(a.rc, n);
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t Npad = a.rc.Npad;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    const uint32_t T = a.T;
+    const float b0step = 1.0f / (float)T;
+    auto bin_at = [&](uint32_t j) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
+        if (a.bins0_tab) return a.bins0_tab[j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+
+    // view direction, normalised twice like the reference (renderer.py:294, sphere_harmonics.py:82)
+    float dirn[3] = {rs.d[0], rs.d[1], rs.d[2]};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float aa = dirn[0] * dirn[0], bb = dirn[1] * dirn[1], cc = dirn[2] * dirn[2];
+        const float nrm = sqrtf((aa + bb) + cc);
+        dirn[0] = dirn[0] / nrm; dirn[1] = dirn[1] / nrm; dirn[2] = dirn[2] / nrm;
+    }
+
+    float fimg[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) fimg[c] = 0.0f;
+    float dep = 0.0f;
+    double cum = 0.0, wsum = 0.0;
+    const TT *table = reinterpret_cast<const TT *>(a.table);
+
+    float bprev = bin_at(0);
+    float rb_prev = real_bin(rs, bprev);
+    if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
+    for (uint32_t j = 0; j < T; ++j) {
+        const float bnext = bin_at(j + 1);
+        const float rb_next = real_bin(rs, bnext);
+        const float tmid = (rb_next + rb_prev) / 2.0f;
+        float p[3], x01[3];
+        sample_x01(a.rc, rs, tmid, p, x01);
+        encode_levels_lds<TT, L, C, 2>(table, a.g, x01, fe, fstride);
+        float h[NOUT];
+        if constexpr (MFMA) {
+            // the slab is private to this wave and LDS serves a wave's requests in order
+            __builtin_amdgcn_wave_barrier();
+            grid_mlp_mfma(lds + opaque_zero(), fe - (threadIdx.x & 63u), h);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            dense_lds<IN, H1, 1>(a.w[0], fe, actB, fstride);
+            dense_lds<H1, H2, 1>(a.w[1], actB, fe, fstride);
+            dense_lds<H2, NOUT, 0>(a.w[2], fe, actB, fstride);
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) h[k] = actB[k * fstride];
+        }
+        const float sigma = expf_det(h[0]);                  // network.py:151
+        const float delta = rb_next - rb_prev;
+        float ds = delta * sigma;
+        if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+        const float alpha = 1.0f - expf_det(-ds);
+        const float tr = expf_det(-(float)cum);
+        float w = alpha * tr;
+        if (w != w) w = 0.0f;
+        cum += (double)ds;
+        wsum += (double)w;
+        dep = __builtin_fmaf(w, tmid, dep);
+#pragma unroll
+        for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, h[1 + c], fimg[c]);
+        if (ok) {
+            if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
+            if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
+            if (a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
+            if (a.dbg_xyz) { float *q = a.dbg_xyz + ((size_t)n * T + j) * 3; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            if (a.dbg_geo) { float *q = a.dbg_geo + ((size_t)n * T + j) * GEO;
+#pragma unroll
+                for (int c = 0; c < GEO; ++c) q[c] = h[1 + c]; }
+        }
+        rb_prev = rb_next;
+    }
+
+    // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
+    static_assert(VH <= IN && NCOL <= IN, "view MLP activations reuse the feature column");
+    float rgb[3];
+    const float ws = (float)wsum;
+    {   // sum_t w_t * SH_c(d) = SH_c(d) * sum_t w_t: the direction is constant along the ray
+        // (renderer.py:293-295 evaluates it per sample), so the basis is evaluated once per ray.
+        float sh[NSH];
+        sh_degree4(dirn[0], dirn[1], dirn[2], sh);
+#pragma unroll
+        for (int c = 0; c < NSH; ++c) fimg[GEO + c] = sh[c] * ws;
+    }
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) fe[c * fstride] = fimg[c];
+    dense_ldsw_col<NCOL, VH, 1>(lds_vw, fe, fe, fstride);
+    dense_ldsw_col<VH, VH, 1>(lds_vw + VW0, fe, fe, fstride);
+    {
+        float v2[VH];
+#pragma unroll
+        for (int k = 0; k < VH; ++k) v2[k] = fe[k * fstride];
+        dense_ldsw<VH, 3, 0>(lds_vw + VW0 + VW1, v2, rgb);
+    }
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float sg = 1.0f / (1.0f + expf_det(-rgb[c]));
+            const float bgm = (1.0f - ws) * a.rc.bg;
+            a.image[(size_t)n * 3 + c] = sg + bgm;
+        }
+        a.depth[n] = dep;
+        a.wsum[n] = ws;
+        if (a.dbg_fimg) {
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+// ---- optional per-kernel timing (bench.py's roofline leg) ---------------------------------
+// When enabled, every kernel launched by sn_rm_render_rays is bracketed by hipEvents recorded
+// on the caller's stream; sn_rm_profile_read() synchronises them and returns, per kernel class,
+// the launch count and the summed device time.  Off by default (no events, no overhead).
+enum { PK_PACK = 0, PK_PROP0, PK_PROP1, PK_PROP2, PK_FINAL, PK_CLASSES };
+struct ProfSpan { hipEvent_t a, b; int cls; };
+static bool g_prof_on = false;
+static std::vector<ProfSpan> g_prof;
+
+struct ProfScope {
+    hipStream_t st; int idx = -1;
+    ProfScope(hipStream_t s, int cls) : st(s) {
+        if (!g_prof_on) return;
+        ProfSpan sp; sp.cls = cls;
+        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return;
+        hipEventRecord(sp.a, st);
+        g_prof.push_back(sp); idx = (int)g_prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(g_prof[idx].b, st); }
+};
+
+static int to_levels(GridLevels *g, const sn_grid_desc *d) {
+    SN_REQUIRE(d->D == 3, "render: grids must be 3-D (got D=%u)", d->D);
+    return build_grid_levels(g, d->offsets, d->D, d->C, d->L, d->S, d->H, d->gridtype, (int)d->align_corners, d->interp);
+}
+
+// fused kernels assume: hashed levels have power-of-two size; dense levels walk all 3 dims, no modulo
+static bool levels_fast(const GridLevels &g) {
+    for (uint32_t l = 0; l < g.L; ++l) {
+        const uint32_t mode = g.mode[l], mk = (mode >> 1) & 3u, nd = (mode >> 4) & 15u;
+        if (mode & 1u) { if (mk != 1u) return false; }
+        else if (mk != 0u || nd != 3u) return false;
+    }
+    return g.align_corners == 0 || true;
+}
+
+static bool mlp_is(const sn_mlp_desc *m, uint32_t nl, const uint32_t *dims) {
+    if (m->num_layers != nl || m->activation != 0 || m->skip_mask != 0) return false;
+    for (uint32_t l = 0; l <= nl; ++l) if (m->dims[l] != dims[l]) return false;
+    for (uint32_t l = 0; l < nl; ++l) if (m->bias[l] != nullptr || m->weight[l] == nullptr) return false;
+    return true;
+}
+
+static uint32_t chunk_rays(uint32_t N, uint32_t W) {
+    // keep a launch's scratch bounded; image mode splits on 16-row boundaries
+    const uint32_t cap = 1u << 21;
+    if (N <= cap) return N;
+    if (W) { uint32_t rows = (cap / W) & ~15u; if (rows < 16) rows = 16; return rows * W; }
+    return cap;
+}
+
+static uint32_t blocks_for(uint32_t n, uint32_t W) {
+    if (W) { const uint32_t rows = (n + W - 1) / W; return ((W + 15u) >> 4) * ((rows + 15u) >> 4); }
+    return div_up(n, 256);
+}
+
+static size_t stage_scratch_floats(const sn_render_cfg *cfg, uint32_t Npad) {
+    size_t f = 0;
+    for (uint32_t k = 0; k + 1 < cfg->num_stages; ++k) f += (size_t)cfg->num_steps[k] * Npad;          // weights
+    for (uint32_t k = 1; k < cfg->num_stages; ++k) f += (size_t)(cfg->num_steps[k] + 1) * Npad;       // bins
+    return f;
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+extern "C" {
+
+void sn_rm_profile_enable(int on) {
+    g_prof_on = on != 0;
+    if (!g_prof_on) {
+        for (auto &sp : g_prof) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+        g_prof.clear();
+    }
+}
+
+int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_classes) {
+    SN_REQUIRE(ms_per_class && launches_per_class && n_classes >= PK_CLASSES, "profile_read: need %d classes", (int)PK_CLASSES);
+    for (int i = 0; i < n_classes; ++i) { ms_per_class[i] = 0.0f; launches_per_class[i] = 0; }
+    for (auto &sp : g_prof) {
+        SN_HIP_OK(hipEventSynchronize(sp.b));
+        float ms = 0.0f;
+        SN_HIP_OK(hipEventElapsedTime(&ms, sp.a, sp.b));
+        ms_per_class[sp.cls] += ms; launches_per_class[sp.cls] += 1;
+        hipEventDestroy(sp.a); hipEventDestroy(sp.b);
+    }
+    g_prof.clear();
+    return SN_OK;
+}
+
+size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w) {
+    if (!cfg || N == 0) return (size_t)PACK_FLOATS * sizeof(float);
+    const uint32_t nc = chunk_rays(N, tile_w);
+    const size_t npad = (size_t)blocks_for(nc, tile_w) * 256u;
+    return (stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS) * sizeof(float);
+}
+
+int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
+    SN_REQUIRE(cfg && io, "render_rays: cfg/io is NULL");
+    SN_REQUIRE(io->rays_o && io->rays_d && io->image && io->depth && io->weights_sum, "render_rays: rays/outputs must be device pointers");
+    const uint32_t S = cfg->num_stages;
+    SN_REQUIRE(S >= 1 && S <= SN_MAX_STAGES, "render_rays: num_stages=%u outside 1..%d", S, SN_MAX_STAGES);
+    for (uint32_t k = 0; k < S; ++k) SN_REQUIRE(cfg->num_steps[k] >= 1, "render_rays: num_steps[%u] must be >= 1", k);
+    SN_REQUIRE(cfg->sh_degree == 4, "render_rays: fused path is built for SH degree 4 (network.py:97), got %u", cfg->sh_degree);
+    if (io->N == 0) return SN_OK;
+    if (io->tile_w) SN_REQUIRE(io->N % io->tile_w == 0, "render_rays: N=%u is not a multiple of tile_w=%u", io->N, io->tile_w);
+    hipStream_t st = (hipStream_t)stream;
+
+    // ---- which kernel instantiations does this configuration map to? ----
+    static const uint32_t d_prop[3] = {10, 16, 1};
+    static const uint32_t d_main[4] = {32, 64, 64, 16};
+    static const uint32_t d_view[4] = {31, 32, 32, 3};
+    static const uint32_t d_c1[3] = {16, 32, 16};
+    static const uint32_t d_c1v[3] = {31, 32, 3};
+    GridLevels gl_prop[SN_MAX_STAGES], gl_main;
+    for (uint32_t k = 0; k + 1 < S; ++k) {
+        int rc = to_levels(&gl_prop[k], &cfg->prop_grid[k]);
+        if (rc) return rc;
+        if (!(cfg->prop_grid[k].L == 5 && cfg->prop_grid[k].C == 2 && mlp_is(&cfg->prop_mlp[k], 2, d_prop) && levels_fast(gl_prop[k]))) {
+            set_error("render_rays: proposal stage %u is not the L=5,F=2 grid + 10-16-1 bias-free ReLU MLP this build fuses (network.py:135-143)", k);
+            return SN_ERR_UNSUPPORTED;
+        }
+    }
+    {
+        int rc = to_levels(&gl_main, &cfg->grid);
+        if (rc) return rc;
+    }
+    const bool is_main = cfg->grid.L == 16 && cfg->grid.C == 2 && mlp_is(&cfg->grid_mlp, 3, d_main) && mlp_is(&cfg->view_mlp, 3, d_view) && levels_fast(gl_main);
+    const bool is_c1 = cfg->grid.L == 8 && cfg->grid.C == 2 && mlp_is(&cfg->grid_mlp, 2, d_c1) && mlp_is(&cfg->view_mlp, 2, d_c1v);
+    if (!is_main && !is_c1) {
+        set_error("render_rays: field is neither the L=16,F=2 grid + 32-64-64-16 / 31-32-32-3 MLPs (network.py:93-98) nor the C1 test field");
+        return SN_ERR_UNSUPPORTED;
+    }
+    if (is_c1) {
+        set_error("render_rays: the C1 plumbing field is a CPU-only configuration (BASELINE.json configs[0]); not instantiated for the GPU");
+        return SN_ERR_UNSUPPORTED;
+    }
+    const char *mode = getenv("SN_RENDER_MLP");
+    const bool use_mfma = !(mode && strcmp(mode, "valu") == 0);
+
+    SN_REQUIRE(io->workspace != nullptr, "render_rays: workspace is NULL");
+    float *pack = reinterpret_cast<float *>(io->workspace);
+    float *scratch = pack + PACK_FLOATS;
+    const size_t scratch_floats_avail = io->workspace_bytes / sizeof(float) > (size_t)PACK_FLOATS ? io->workspace_bytes / sizeof(float) - PACK_FLOATS : 0;
+    if (use_mfma) {
+        ProfScope ps(st, PK_PACK);
+        hipLaunchKernelGGL(k_pack_grid_mlp, dim3(PACK_FLOATS / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0], cfg->grid_mlp.weight[1], cfg->grid_mlp.weight[2], pack);
+        SN_LAUNCH_CHECK("k_pack_grid_mlp");
+    }
+
+    const uint32_t W = io->tile_w;
+    const uint32_t chunk = chunk_rays(io->N, W);
+    for (uint32_t first = 0; first < io->N; first += chunk) {
+        const uint32_t n = (io->N - first) < chunk ? (io->N - first) : chunk;
+        const uint32_t nblk = blocks_for(n, W);
+        const uint32_t Npad = nblk * 256u;
+        if (stage_scratch_floats(cfg, Npad) > scratch_floats_avail) {
+            set_error("render_rays: workspace too small (%zu bytes, need %zu)", io->workspace_bytes,
+                      (stage_scratch_floats(cfg, Npad) + PACK_FLOATS) * sizeof(float));
+            return SN_ERR_WORKSPACE;
+        }
+        RayCommon rc;
+        rc.rays_o = io->rays_o + (size_t)first * 3; rc.rays_d = io->rays_d + (size_t)first * 3;
+        rc.cnf = io->cam_near_far ? io->cam_near_far + (size_t)first * 2 : nullptr;
+        rc.N = n; rc.W = W; rc.rows = W ? n / W : 0; rc.Npad = Npad;
+        for (int i = 0; i < 6; ++i) rc.aabb[i] = cfg->aabb[i];
+        rc.min_near = cfg->min_near; rc.bound = cfg->bound; rc.contract = cfg->contract;
+        rc.last_opaque = cfg->last_sample_opaque; rc.bg = cfg->bg_color;
+
+        // scratch carve-up
+        float *w_scr[SN_MAX_STAGES] = {nullptr}, *b_scr[SN_MAX_STAGES] = {nullptr};
+        float *cur = scratch;
+        for (uint32_t k = 0; k + 1 < S; ++k) { w_scr[k] = cur; cur += (size_t)cfg->num_steps[k] * Npad; }
+        for (uint32_t k = 1; k < S; ++k) { b_scr[k] = cur; cur += (size_t)(cfg->num_steps[k] + 1) * Npad; }
+
+        for (uint32_t k = 0; k + 1 < S; ++k) {
+            PropArgs pa;
+            pa.rc = rc; pa.g = gl_prop[k]; pa.table = cfg->prop_grid[k].embeddings;
+            pa.w0 = cfg->prop_mlp[k].weight[0]; pa.w1 = cfg->prop_mlp[k].weight[1];
+            pa.T = cfg->num_steps[k]; pa.Tn = cfg->num_steps[k + 1];
+            pa.bins_in = b_scr[k]; pa.bins0_tab = k == 0 ? io->bins0_table : nullptr;
+            pa.u_tab = io->u_table[k + 1];
+            pa.w_scr = w_scr[k]; pa.bins_out = b_scr[k + 1];
+            pa.dbg_bins = io->bins[k] ? io->bins[k] + (size_t)first * (pa.T + 1) : nullptr;
+            pa.dbg_w = io->weights[k] ? io->weights[k] + (size_t)first * pa.T : nullptr;
+            pa.dbg_sigma = io->sigmas[k] ? io->sigmas[k] + (size_t)first * pa.T : nullptr;
+            pa.dbg_inds = io->inds[k + 1] ? io->inds[k + 1] + (size_t)first * (pa.Tn + 1) : nullptr;
+            {
+                ProfScope ps(st, PK_PROP0 + (int)k);
+                if (cfg->prop_grid[k].table_dtype == SN_F32)
+                    hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16>), dim3(nblk), dim3(256), 0, st, pa);
+                else
+                    hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16>), dim3(nblk), dim3(256), 0, st, pa);
+            }
+            SN_LAUNCH_CHECK("k_prop_stage");
+        }
+        FinalArgs fa;
+        fa.rc = rc; fa.g = gl_main; fa.table = cfg->grid.embeddings; fa.mlp_pack = pack;
+        for (int l = 0; l < 3; ++l) { fa.w[l] = cfg->grid_mlp.weight[l]; fa.vw[l] = cfg->view_mlp.weight[l]; }
+        fa.T = cfg->num_steps[S - 1];
+        fa.bins_in = b_scr[S - 1]; fa.bins0_tab = S == 1 ? io->bins0_table : nullptr;
+        fa.sh_degree = cfg->sh_degree;
+        fa.image = io->image + (size_t)first * 3; fa.depth = io->depth + first; fa.wsum = io->weights_sum + first;
+        fa.dbg_bins = io->bins[S - 1] ? io->bins[S - 1] + (size_t)first * (fa.T + 1) : nullptr;
+        fa.dbg_w = io->weights[S - 1] ? io->weights[S - 1] + (size_t)first * fa.T : nullptr;
+        fa.dbg_sigma = io->sigmas[S - 1] ? io->sigmas[S - 1] + (size_t)first * fa.T : nullptr;
+        fa.dbg_xyz = io->xyzs_last ? io->xyzs_last + (size_t)first * fa.T * 3 : nullptr;
+        fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * 15 : nullptr;
+        fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
+        const bool f16 = cfg->grid.table_dtype == SN_F16;
+        ProfScope ps_final(st, PK_FINAL);
+        if (use_mfma) {
+            const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 32 * 64 + 32 * 32 + 32 * 32 + 3 * 32) * sizeof(float);   // 72.4 KiB
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            if (f16) hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, true>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+            else hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, true>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+        } else {
+            const size_t lds_bytes = (size_t)(2 * 64 * 256 + 32 * 32 + 32 * 32 + 3 * 32) * sizeof(float);   // 136 KiB: needs the opt-in attribute
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            if (f16) hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, false>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+            else hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, false>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+        }
+        SN_LAUNCH_CHECK("k_final_stage");
+    }
+    return SN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Volume renderer with the reference's `NeRFRenderer` contract (nerf/renderer.py:142-385):
+`render(rays_o, rays_d, staged=False, cam_near_far=None, **kw)` / `run(...)` returning the
+same result keys (`image`, `depth`, `weights_sum`, `samvit`, `instance_mask_logits`,
+`weights`, `num_points`, `proposal_loss`, `distort_loss`), same buffers (`aabb_train`,
+`aabb_infer`) and the same `opt` fields.
+
+Two execution paths:
+  * fused (default whenever no gradient has to reach the radiance field): one
+    `raymarching.render_rays` call = sn_rm_render_rays, which runs proposal resampling, the
+    hash-grid field, the MLPs and compositing on the GPU without materialising per-sample
+    tensors; the SAM-feature and mask heads then consume its last-stage samples.
+  * differentiable (RGB training, perturb=True): the stage loop in torch autograd with the
+    HIP encoders / `sample_pdf` / `composite` as building blocks.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import raymarching as rm
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.05):
+    return rm.near_far_from_aabb(rays_o, rays_d, aabb, min_near)
+
+
+def contract(x):
+    return rm.contract(x)
+
+
+def sample_pdf(bins, weights, T, perturb=False):
+    return rm.sample_pdf(bins, weights, T, perturb)
+
+
+def proposal_loss(all_bins, all_weights):
+    """Inter-level proposal loss (nerf/renderer.py:30-57)."""
+    ref_bins = all_bins[-1].detach()
+    ref_w = all_weights[-1].detach()
+    total = 0
+    for bins, w in zip(all_bins[:-1], all_weights[:-1]):
+        cum = torch.cat([torch.zeros_like(w[..., :1]), torch.cumsum(w, dim=-1)], dim=-1)
+        last = w.shape[-1] - 1
+        lo = (torch.searchsorted(bins[..., :-1].contiguous(), ref_bins[..., :-1].contiguous(), right=True) - 1).clamp(0, last)
+        hi = torch.searchsorted(bins[..., 1:].contiguous(), ref_bins[..., 1:].contiguous(), right=True).clamp(0, last)
+        bound = torch.take_along_dim(cum[..., 1:], hi, dim=-1) - torch.take_along_dim(cum[..., :-1], lo, dim=-1)
+        total = total + ((ref_w - bound).clamp(min=0) ** 2 / (ref_w + 1e-8)).mean()
+    return total
+
+
+def distort_loss(bins, weights):
+    """Mip-NeRF-360 distortion loss, O(T) per ray (what the reference gets from the third-party
+    `eff_distloss`, nerf/renderer.py:17-27): sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 d_i, mean over rays."""
+    d = bins[..., 1:] - bins[..., :-1]
+    m = bins[..., :-1] + d / 2
+    wm = weights * m
+    cw = torch.cumsum(weights, dim=-1) - weights          # exclusive prefix
+    cwm = torch.cumsum(wm, dim=-1) - wm
+    inter = 2 * (wm * cw - weights * cwm).sum(-1)
+    intra = (weights * weights * d).sum(-1) / 3
+    return (inter + intra).mean()
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.real_bound = opt.bound                         # world-space marching bound
+        self.bound = 2 if opt.contract else opt.bound       # grid-query bound (renderer.py:152-155)
+        self.cascade = 1 + math.ceil(math.log2(self.bound))
+        self.min_near = opt.min_near
+        self.density_thresh = opt.density_thresh
+        b = float(self.real_bound)
+        aabb = torch.FloatTensor([-b, -b, -b, b, b, b])
+        self.register_buffer("aabb_train", aabb)
+        self.register_buffer("aabb_infer", aabb.clone())
+        self._plan = None
+        self._plan_key = None
+        self.render_table_dtype = torch.float32             # torch.float16: render from half-precision table copies
+
+    def forward(self, x, d, **kwargs):
+        raise NotImplementedError()
+
+    def density(self, x, **kwargs):
+        raise NotImplementedError()
+
+    def update_aabb(self, aabb):
+        if not torch.is_tensor(aabb):
+            aabb = torch.as_tensor(aabb).float()
+        self.aabb_train = aabb.clamp(-self.real_bound, self.real_bound).to(self.aabb_train.device)
+        self.aabb_infer = self.aabb_train.clone()
+        self._plan = None
+        print(f"[INFO] update_aabb: {self.aabb_train.cpu().numpy().tolist()}")
+
+    # ---------------------------------------------------------------------------------------
+    def render(self, rays_o, rays_d, staged=False, cam_near_far=None, **kwargs):
+        if not staged:
+            return self.run(rays_o, rays_d, cam_near_far=cam_near_far, **kwargs)
+        # staged inference (renderer.py:185-219): chunks of max_ray_batch, results scattered into place
+        N = rays_o.shape[0]
+        results: Dict[str, torch.Tensor] = {}
+        step = self.opt.max_ray_batch
+        for head in range(0, N, step):
+            tail = min(head + step, N)
+            cnf = cam_near_far if cam_near_far is None or cam_near_far.shape[0] == 1 else cam_near_far[head:tail]
+            part = self.run(rays_o[head:tail], rays_d[head:tail], cam_near_far=cnf, **kwargs)
+            for k, v in part.items():
+                if v is None:
+                    continue
+                if torch.is_tensor(v):
+                    if k not in results:
+                        results[k] = torch.empty(N, *v.shape[1:], device=rays_o.device)
+                    results[k][head:tail] = v
+                else:
+                    results[k] = v
+        return results
+
+    # ---------------------------------------------------------------------------------------
+    def _core_parameters(self):
+        for name, p in self.named_parameters():
+            if name.startswith(("grid", "view_mlp", "prop_")):
+                yield p
+
+    def _needs_field_grad(self, update_proposal: bool) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return any(p.requires_grad for p in self._core_parameters())
+
+    def _get_plan(self):
+        key = (self.grid.embeddings.data_ptr(), self.grid.embeddings.device, tuple(self.opt.num_steps),
+               self.render_table_dtype, self.training)
+        if self._plan is None or self._plan_key != key:
+            self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype)
+            ab = (self.aabb_train if self.training else self.aabb_infer).detach().cpu().tolist()
+            for i in range(6):
+                self._plan.cfg.aabb[i] = ab[i]
+            self._plan_key = key
+        return self._plan
+
+    def run(self, rays_o, rays_d, bg_color=None, perturb=False, cam_near_far=None, update_proposal=True,
+            return_feats=0, return_mask=0, H=None, W=None, tile_w=0, **kwargs):
+        if self.opt.render_mesh:
+            return {}                                       # the reference's mesh branch is commented out (renderer.py:257,386)
+        if bg_color is None:
+            bg_color = 1
+        if perturb or self._needs_field_grad(update_proposal):
+            return self._run_autograd(rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
+                                      return_feats, return_mask, H, W)
+        return self._run_fused(rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w)
+
+    # ---------------------------------------------------------------------------------------
+    def _heads(self, results, weights, xyzs, geo_feat, f_image, image, depth, return_feats, return_mask, H, W):
+        opt = self.opt
+        if opt.with_sam:                                    # renderer.py:301-302, 359-374
+            features = self.s_grid(xyzs, bound=self.bound)
+            f_sam = rm.composite(weights, features)
+            if opt.sam_use_view_direction:
+                f = torch.cat([f_sam, f_image, image, depth.unsqueeze(-1)], dim=-1)
+            else:
+                f = torch.cat([f_sam, rm.composite(weights, geo_feat), image, depth.unsqueeze(-1)], dim=-1)
+            samvit = self.samvit_mlp(f)
+            if return_feats > 0:
+                results["samvit"] = samvit.view(H, W, -1)
+        if return_mask > 0:                                 # renderer.py:304-305, 376-385
+            masks = self.m_grid(xyzs, bound=self.bound)
+            if opt.mask_mlp_type == "default":
+                point_masks = self.mask_mlp(torch.cat([masks, geo_feat.detach()], dim=-1))
+            else:
+                raise RuntimeError("mask_mlp_type='lightweight_mask' is dimensionally inconsistent in the reference "
+                                   "(renderer.py:381 feeds 63 features into a 35-input MLP, network.py:128)")
+            results["instance_mask_logits"] = rm.composite(weights.detach(), point_masks)
+
+    def _run_fused(self, rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w):
+        opt = self.opt
+        need_heads = opt.with_sam or return_mask > 0
+        want = ["weights_last", "xyzs_last", "geo_feat_last", "f_image"] if need_heads else []
+        plan = self._get_plan()
+        bg = float(bg_color) if not torch.is_tensor(bg_color) else 0.0
+        with torch.no_grad():
+            out = rm.render_rays(plan, rays_o, rays_d, cam_near_far=cam_near_far, bg_color=bg, tile_w=tile_w, want=want)
+            image = out["image"]
+            if torch.is_tensor(bg_color):                   # per-ray / rgb background (renderer.py:353)
+                image = image + (1 - out["weights_sum"]).unsqueeze(-1) * bg_color
+        results = {"weights_sum": out["weights_sum"], "depth": out["depth"], "image": image}
+        if need_heads:
+            self._heads(results, out["weights_last"], out["xyzs_last"], out["geo_feat_last"], out["f_image"],
+                        image, out["depth"], return_feats, return_mask, H, W)
+        return results
+
+    # ---------------------------------------------------------------------------------------
+    def _run_autograd(self, rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
+                      return_feats, return_mask, H, W):
+        """The stage loop of renderer.py:261-357 in torch autograd over the HIP encoders."""
+        opt = self.opt
+        rays_o = rays_o.contiguous()
+        rays_d = rays_d.contiguous()
+        N = rays_o.shape[0]
+        device = rays_o.device
+        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if cam_near_far is not None:
+            nears = torch.maximum(nears, cam_near_far[:, [0]])
+            fars = torch.minimum(fars, cam_near_far[:, [1]])
+
+        def spacing(x):
+            return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
+
+        def spacing_inv(x):
+            return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
+
+        s_near, s_far = spacing(nears), spacing(fars)
+        all_bins, all_weights = [], []
+        steps = opt.num_steps
+        bins = weights = None
+        for k, T in enumerate(steps):
+            if k == 0:
+                bins = torch.linspace(0, 1, T + 1, device=device).unsqueeze(0).expand(N, -1)
+                if perturb:
+                    bins = (bins + (torch.rand_like(bins) - 0.5) / T).clamp(0, 1)
+            else:
+                bins = rm.sample_pdf(bins, weights, T + 1, perturb)
+            real_bins = spacing_inv(s_near * (1 - bins) + s_far * bins)
+            rays_t = (real_bins[..., 1:] + real_bins[..., :-1]) / 2
+            xyzs = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * rays_t.unsqueeze(2)
+            if opt.contract:
+                xyzs = rm.contract(xyzs)
+            if k != len(steps) - 1:
+                with torch.set_grad_enabled(update_proposal and torch.is_grad_enabled()):
+                    sigmas = self.density(xyzs, proposal=k)["sigma"]
+            else:
+                dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+                dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
+                field = self(xyzs, dirs)
+                sigmas, colors, geo_feat = field["sigma"], field["color"], field["geo_feat"]
+            ds = (real_bins[..., 1:] - real_bins[..., :-1]) * sigmas
+            if opt.background == "last_sample":
+                ds = torch.cat([ds[..., :-1], torch.full_like(ds[..., -1:], torch.inf)], dim=-1)
+            alphas = 1 - torch.exp(-ds)
+            trans = torch.cumsum(ds[..., :-1], dim=-1)
+            trans = torch.exp(-torch.cat([torch.zeros_like(trans[..., :1]), trans], dim=-1))
+            weights = (alphas * trans).nan_to_num(0)
+            if self.training:
+                all_bins.append(bins)
+                all_weights.append(weights)
+
+        weights_sum = weights.sum(dim=-1)
+        depth = (weights * rays_t).sum(dim=-1)
+        f_image = rm.composite(weights, colors)
+        image = torch.sigmoid(self.view_mlp(f_image))
+        results = {}
+        if self.training and not opt.with_mask and not opt.with_sam:
+            results["num_points"] = xyzs.shape[0] * xyzs.shape[1]
+            results["weights"] = weights
+            if opt.lambda_proposal > 0 and update_proposal:
+                results["proposal_loss"] = proposal_loss(all_bins, all_weights)
+            if opt.lambda_distort > 0:
+                results["distort_loss"] = distort_loss(bins, weights)
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        results["weights_sum"] = weights_sum
+        results["depth"] = depth
+        results["image"] = image
+        if opt.with_sam or return_mask > 0:
+            self._heads(results, weights, xyzs, geo_feat, f_image, image, depth, return_feats, return_mask, H, W)
+        return results

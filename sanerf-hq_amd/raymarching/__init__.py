@@ -1,0 +1,4 @@
+from .raymarching import (  # noqa: F401
+    composite, contract, generate_rays, near_far_from_aabb, render_rays, sample_pdf, weights_from_sigma,
+    RenderPlan,
+)

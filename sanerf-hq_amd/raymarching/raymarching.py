@@ -1,0 +1,285 @@
+"""`raymarching` operators on MI355X.
+
+The reference's README (README.md:32-34) mentions a `raymarching` extension that is not in
+its tree; the ray-marching maths lives as torch code in nerf/utils.py and nerf/renderer.py.
+This module is that operator surface, implemented over libsanerf_hip.so:
+
+    generate_rays        nerf/utils.py:182-304 (full image branch)
+    near_far_from_aabb   nerf/renderer.py:122-139
+    contract             nerf/renderer.py:60-69
+    sample_pdf           nerf/renderer.py:84-119   (+ the integer searchsorted result)
+    weights_from_sigma   nerf/renderer.py:308-325
+    composite            nerf/renderer.py:333-338, 361, 384  (autograd w.r.t. both operands)
+    render_rays          nerf/renderer.py:221-357 + nerf/network.py:146-186, fused
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _flat3(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, 3).contiguous().float()
+
+
+def generate_rays(pose, intrinsics, H: int, W: int, device="cuda", row_begin: int = 0, row_end: Optional[int] = None):
+    """Rays of image rows [row_begin, row_end): rays_o, rays_d of shape [(rows)*W, 3].
+    pose: 4x4 cam2world (array-like / tensor), intrinsics: (fx, fy, cx, cy)."""
+    row_end = H if row_end is None else row_end
+    pose = np.asarray(pose.detach().cpu() if torch.is_tensor(pose) else pose, dtype=np.float32).reshape(4, 4)
+    fx, fy, cx, cy = [float(v) for v in (intrinsics.tolist() if hasattr(intrinsics, "tolist") else intrinsics)]
+    n = (row_end - row_begin) * W
+    rays_o = torch.empty(n, 3, device=device, dtype=torch.float32)
+    rays_d = torch.empty(n, 3, device=device, dtype=torch.float32)
+    _lib.check(_lib.lib().sn_rm_generate_rays(_lib.host_f32(pose.reshape(-1)), fx, fy, cx, cy, H, W, row_begin, row_end,
+                                              _lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.stream()),
+               "generate_rays")
+    return rays_o, rays_d
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.05):
+    rays_o, rays_d = _flat3(rays_o), _flat3(rays_d)
+    N = rays_o.shape[0]
+    nears = torch.empty(N, 1, device=rays_o.device, dtype=torch.float32)
+    fars = torch.empty(N, 1, device=rays_o.device, dtype=torch.float32)
+    ab = aabb.detach().cpu().tolist() if torch.is_tensor(aabb) else list(aabb)
+    _lib.check(_lib.lib().sn_rm_near_far_from_aabb(_lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.host_f32(ab),
+                                                   float(min_near), N, _lib.dev(nears, "nears"), _lib.dev(fars, "fars"),
+                                                   _lib.stream()), "near_far_from_aabb")
+    return nears, fars
+
+
+def contract(x):
+    shape = x.shape
+    flat = _flat3(x)
+    z = torch.empty_like(flat)
+    _lib.check(_lib.lib().sn_rm_contract(_lib.dev(flat, "x"), flat.shape[0], _lib.dev(z, "z"), _lib.stream()), "contract")
+    return z.view(shape)
+
+
+def sample_pdf(bins, weights, T: int, perturb: bool = False, return_inds: bool = False, u: Optional[torch.Tensor] = None):
+    """bins [N,T0+1], weights [N,T0] -> [N,T] (no gradient, like the `.detach()` at renderer.py:274)."""
+    bins = bins.detach().contiguous().float()
+    weights = weights.detach().contiguous().float()
+    N, T0 = weights.shape
+    out = torch.empty(N, T, device=bins.device, dtype=torch.float32)
+    inds = torch.empty(N, T, device=bins.device, dtype=torch.int32) if return_inds else None
+    u_stride = 0
+    if perturb:   # renderer.py:98-102
+        base = torch.linspace(0.5 / T, 1 - 0.5 / T, steps=T, device=bins.device)
+        u = (base.expand(N, T) + (torch.rand(N, T, device=bins.device) - 0.5) / T).contiguous()
+    if u is not None:
+        u = u.contiguous().float()
+        u_stride = 0 if u.dim() == 1 else T
+    _lib.check(_lib.lib().sn_rm_sample_pdf(_lib.dev(bins, "bins"), _lib.dev(weights, "weights"), N, T0, T,
+                                           _lib.dev(u, "u"), u_stride, _lib.dev(out, "out_bins"),
+                                           _lib.dev(inds, "inds", torch.int32), _lib.stream()), "sample_pdf")
+    return (out, inds) if return_inds else out
+
+
+def weights_from_sigma(real_bins, sigmas, last_sample_opaque: bool = True):
+    """real_bins [N,T+1], sigmas [N,T] -> weights [N,T] (forward only; training uses torch's scan)."""
+    real_bins = real_bins.detach().contiguous().float()
+    sigmas = sigmas.detach().contiguous().float()
+    N, T = sigmas.shape
+    w = torch.empty(N, T, device=sigmas.device, dtype=torch.float32)
+    _lib.check(_lib.lib().sn_rm_weights_from_sigma(_lib.dev(real_bins, "real_bins"), _lib.dev(sigmas, "sigmas"), N, T,
+                                                   int(last_sample_opaque), _lib.dev(w, "weights"), _lib.stream()),
+               "weights_from_sigma")
+    return w
+
+
+class _composite(Function):
+    """out[n,k] = sum_t w[n,t] * v[n,t,k]."""
+
+    @staticmethod
+    def forward(ctx, weights, values):
+        weights = weights.contiguous().float()
+        values = values.contiguous().float()
+        N, T = weights.shape
+        K = values.shape[-1]
+        out = torch.empty(N, K, device=values.device, dtype=torch.float32)
+        _lib.check(_lib.lib().sn_rm_composite(_lib.dev(weights, "weights"), _lib.dev(values, "values"), N, T, K,
+                                              _lib.dev(out, "out"), _lib.stream()), "composite")
+        ctx.save_for_backward(weights, values)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        weights, values = ctx.saved_tensors
+        N, T = weights.shape
+        K = values.shape[-1]
+        grad_out = grad_out.contiguous().float()
+        gv = gw = None
+        if ctx.needs_input_grad[1]:
+            gv = torch.empty_like(values)
+            _lib.check(_lib.lib().sn_rm_composite_backward(_lib.dev(weights, "weights"), _lib.dev(grad_out, "grad_out"), N, T, K,
+                                                           _lib.dev(gv, "grad_values"), _lib.stream()), "composite_backward")
+        if ctx.needs_input_grad[0]:
+            gw = (values * grad_out.unsqueeze(1)).sum(-1)
+        return gw, gv
+
+
+def composite(weights, values):
+    """weights [N,T], values [N,T,K] or [N,T] -> [N,K] or [N]."""
+    if values.dim() == 2:
+        return _composite.apply(weights, values.unsqueeze(-1)).squeeze(-1)
+    return _composite.apply(weights, values)
+
+
+# --------------------------------------------------------------------------------------------
+# fused renderer
+# --------------------------------------------------------------------------------------------
+def _fill_grid(desc: _lib.GridDesc, enc, table: torch.Tensor) -> None:
+    from ..gridencoder.grid import _host_offsets
+    offs = _host_offsets(enc.offsets)
+    desc.embeddings = table.data_ptr()
+    desc.table_dtype = _lib.SN_F16 if table.dtype == torch.float16 else _lib.SN_F32
+    for i, o in enumerate(offs):
+        desc.offsets[i] = o
+    desc.D, desc.C, desc.L = enc.input_dim, enc.level_dim, enc.num_levels
+    desc.S = float(np.float32(np.log2(enc.per_level_scale)))
+    desc.H = int(enc.base_resolution)
+    desc.gridtype, desc.align_corners, desc.interp = enc.gridtype_id, int(enc.align_corners), enc.interp_id
+
+
+def _fill_mlp(desc: _lib.MlpDesc, layers: Sequence[torch.nn.Linear], dim_in: int, keep: list) -> None:
+    desc.num_layers = len(layers)
+    desc.activation = 0
+    desc.skip_mask = 0
+    desc.dims[0] = dim_in
+    for l, lin in enumerate(layers):
+        w = lin.weight.detach().contiguous().float()
+        keep.append(w)
+        desc.weight[l] = w.data_ptr()
+        desc.dims[l + 1] = w.shape[0]
+        if lin.bias is not None:
+            b = lin.bias.detach().contiguous().float()
+            keep.append(b)
+            desc.bias[l] = b.data_ptr()
+        else:
+            desc.bias[l] = None
+
+
+class RenderPlan:
+    """Everything sn_rm_render_rays needs from a NeRFNetwork-shaped module, built once and reused:
+    the config struct (device pointers of tables / MLP weights) and a cached workspace.
+
+    table_dtype=torch.float16 renders from half-precision copies of the hash tables (made here,
+    the module keeps its fp32 parameters); arithmetic stays fp32 either way."""
+
+    def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32):
+        self.keep: list = []
+        cfg = _lib.RenderCfg()
+        S = len(num_steps)
+        if not 1 <= S <= _lib.MAX_STAGES:
+            raise RuntimeError(f"num_steps must have 1..{_lib.MAX_STAGES} entries")
+        cfg.num_stages = S
+        for k, t in enumerate(num_steps):
+            cfg.num_steps[k] = int(t)
+
+        def table_of(enc):
+            t = enc.embeddings.detach()
+            t = t.to(table_dtype) if t.dtype != table_dtype else t
+            t = t.contiguous()
+            self.keep.append(t)
+            return t
+
+        for k in range(S - 1):
+            enc = model.prop_encoders[k]
+            _fill_grid(cfg.prop_grid[k], enc, table_of(enc))
+            _fill_mlp(cfg.prop_mlp[k], list(model.prop_mlp[k].net), model.prop_mlp[k].dim_in, self.keep)
+        _fill_grid(cfg.grid, model.grid, table_of(model.grid))
+        _fill_mlp(cfg.grid_mlp, list(model.grid_mlp.net), model.grid_mlp.dim_in, self.keep)
+        _fill_mlp(cfg.view_mlp, list(model.view_mlp.net), model.view_mlp.dim_in, self.keep)
+        cfg.sh_degree = model.view_encoder.degree
+        ab = model.aabb_infer.detach().cpu().tolist()
+        for i in range(6):
+            cfg.aabb[i] = ab[i]
+        cfg.min_near = float(model.min_near)
+        cfg.bound = float(model.bound)
+        cfg.contract = int(bool(model.opt.contract))
+        cfg.last_sample_opaque = int(model.opt.background == "last_sample")
+        cfg.bg_color = 1.0
+        self.cfg = cfg
+        self.num_steps = [int(t) for t in num_steps]
+        self.geo = model.geom_feat_dim
+        self.ncol = model.geom_feat_dim + model.view_encoder.output_dim
+        self._ws: Optional[torch.Tensor] = None
+
+    def workspace(self, N: int, tile_w: int, device) -> torch.Tensor:
+        need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(self.cfg), N, tile_w))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(device):
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+
+def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: float = 1.0, tile_w: int = 0,
+                want: Sequence[str] = (), u_tables: Optional[Dict[int, torch.Tensor]] = None,
+                bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None):
+    """Fused render of N rays.  Returns dict(image [N,3], depth [N], weights_sum [N]) plus the
+    per-stage tensors named in `want`: 'bins', 'weights', 'sigmas', 'inds' (all stages),
+    'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'."""
+    rays_o, rays_d = _flat3(rays_o), _flat3(rays_d)
+    N = rays_o.shape[0]
+    device = rays_o.device
+    io = _lib.RenderIO()
+    res: Dict[str, torch.Tensor] = {} if out is None else out
+    keep: List[torch.Tensor] = []
+
+    def buf(name, shape, dtype=torch.float32):
+        t = res.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = torch.empty(shape, device=device, dtype=dtype)
+            res[name] = t
+        return t
+
+    io.rays_o, io.rays_d = _lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d")
+    if cam_near_far is not None:
+        cnf = cam_near_far.float()
+        if cnf.shape[0] == 1:
+            cnf = cnf.expand(N, 2)
+        cnf = cnf.contiguous()
+        keep.append(cnf)
+        io.cam_near_far = _lib.dev(cnf, "cam_near_far")
+    io.N, io.tile_w = N, int(tile_w)
+    if bins0_table is not None:
+        b0 = bins0_table.to(device).contiguous().float(); keep.append(b0); io.bins0_table = b0.data_ptr()
+    if u_tables:
+        for k, u in u_tables.items():
+            u = u.to(device).contiguous().float(); keep.append(u); io.u_table[k] = u.data_ptr()
+    io.image = _lib.dev(buf("image", (N, 3)), "image")
+    io.depth = _lib.dev(buf("depth", (N,)), "depth")
+    io.weights_sum = _lib.dev(buf("weights_sum", (N,)), "weights_sum")
+    S = plan.cfg.num_stages
+    want = set(want)
+    for k in range(S):
+        T = plan.num_steps[k]
+        if "bins" in want:
+            io.bins[k] = buf(f"bins{k}", (N, T + 1)).data_ptr()
+        if "weights" in want or (k == S - 1 and "weights_last" in want):
+            io.weights[k] = buf(f"weights{k}", (N, T)).data_ptr()
+        if "sigmas" in want:
+            io.sigmas[k] = buf(f"sigmas{k}", (N, T)).data_ptr()
+        if "inds" in want and k >= 1:
+            io.inds[k] = buf(f"inds{k}", (N, T + 1), torch.int32).data_ptr()
+    Tl = plan.num_steps[S - 1]
+    if "xyzs_last" in want:
+        io.xyzs_last = buf("xyzs_last", (N, Tl, 3)).data_ptr()
+    if "geo_feat_last" in want:
+        io.geo_feat_last = buf("geo_feat_last", (N, Tl, plan.geo)).data_ptr()
+    if "f_image" in want:
+        io.f_image = buf("f_image", (N, plan.ncol)).data_ptr()
+    ws = plan.workspace(N, int(tile_w), device)
+    io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+    plan.cfg.bg_color = float(bg_color)
+    _lib.check(_lib.lib().sn_rm_render_rays(C.byref(plan.cfg), C.byref(io), _lib.stream()), "render_rays")
+    if "weights_last" in want:
+        res["weights_last"] = res[f"weights{S - 1}"]
+    return res

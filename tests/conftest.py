@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import sanerf_hq_amd
+    from sanerf_hq_amd import _lib
+    # the product path must be the native library: fail loudly if it is not there
+    assert os.path.exists(_lib.LIB_PATH), f"{_lib.LIB_PATH} missing on the GPU box"
+    assert _lib.lib().sn_device_count() >= 1, _lib.lib().sn_last_error()
+    return torch.device("cuda:0")

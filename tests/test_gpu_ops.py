@@ -1,0 +1,239 @@
+"""GPU: every stand-alone operator of the C ABI (through the Python operator modules, which are
+thin ctypes callers) against the CPU oracle on the same seeded inputs.
+Bars: bit-exact for integer outputs (sample indices) and for arithmetic that follows the shared
+fp32 recipe; <= a few ulp where device libm (sin/cos) or atomics ordering is involved."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+GRID_CASES = [
+    dict(L=16, C=2, log2T=19, desired=4096, gridtype=0, ac=False, interp=0),   # main field
+    dict(L=16, C=8, log2T=19, desired=512, gridtype=0, ac=False, interp=0),    # SAM / mask grids
+    dict(L=5, C=2, log2T=17, desired=128, gridtype=0, ac=False, interp=0),     # proposal 0
+    dict(L=8, C=2, log2T=14, desired=2048, gridtype=0, ac=False, interp=0),    # config C1
+    dict(L=4, C=4, log2T=10, desired=64, gridtype=1, ac=False, interp=0),      # tiled, generic modulo
+    dict(L=4, C=1, log2T=12, desired=100, gridtype=0, ac=True, interp=1),      # align_corners + smoothstep
+]
+
+
+def _grid_setup(orc, cfg, B, seed, dev):
+    rng = np.random.default_rng(seed)
+    offs, pls = orc.grid_layout(3, cfg["L"], cfg["C"], 2, 16, cfg["log2T"], cfg["desired"])
+    emb = rng.uniform(-1, 1, (int(offs[-1]), cfg["C"])).astype(np.float32)
+    x = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    x[0] = 0; x[1] = 1; x[2] = [0.5, 0.5, 0.5]; x[3] = [1.25, 0.5, 0.5]; x[4] = [0.2, -0.01, 0.3]   # corners + out of range
+    return offs, pls, emb, x
+
+
+@pytest.mark.parametrize("cfg", GRID_CASES)
+def test_grid_forward_matches_oracle(gpu, orc, cfg):
+    from sanerf_hq_amd.gridencoder import grid_encode
+    offs, pls, emb, x = _grid_setup(orc, cfg, 4099, 11, gpu)
+    want, want_dd = orc.grid_encode_forward(x, emb, offs, pls, 16, True, cfg["gridtype"], cfg["ac"], cfg["interp"])
+    xt = T(x, gpu).requires_grad_(True)
+    got = grid_encode(xt, T(emb, gpu), T(offs, gpu), pls, 16, True, cfg["gridtype"], cfg["ac"], cfg["interp"])
+    assert got.shape == (4099, cfg["L"] * cfg["C"])
+    assert np.array_equal(got.detach().cpu().numpy(), want), "same fmaf chain => bit-identical"
+    # input gradient through dy_dx (kernel_input_backward)
+    g = np.random.default_rng(12).standard_normal(want.shape).astype(np.float32)
+    got.backward(T(g, gpu))
+    _, gi = orc.grid_encode_backward(g, x, emb, offs, pls, 16, want_dd, cfg["gridtype"], cfg["ac"], cfg["interp"])
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), gi, rtol=1e-5, atol=1e-4)
+
+
+def test_grid_forward_fp16_table_and_max_level(gpu, orc):
+    from sanerf_hq_amd.gridencoder import grid_encode
+    cfg = GRID_CASES[0]
+    offs, pls, emb, x = _grid_setup(orc, cfg, 2050, 13, gpu)
+    emb16 = emb.astype(np.float16)
+    want, _ = orc.grid_encode_forward(x, emb16, offs, pls, 16)
+    got = grid_encode(T(x, gpu), T(emb16, gpu), T(offs, gpu), pls, 16)
+    assert got.dtype == torch.float16                                   # grid.py:49: outputs take the table's dtype
+    assert np.array_equal(got.float().cpu().numpy(), want.astype(np.float16).astype(np.float32))
+    want, _ = orc.grid_encode_forward(x, emb, offs, pls, 16, max_level=5)
+    got = grid_encode(T(x, gpu), T(emb, gpu), T(offs, gpu), pls, 16, False, 0, False, 0, 5)
+    assert np.array_equal(got.cpu().numpy(), want) and float(got[:, 10:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [GRID_CASES[1], GRID_CASES[2], GRID_CASES[4]])
+def test_grid_backward_matches_oracle(gpu, orc, cfg):
+    from sanerf_hq_amd.gridencoder import grid_encode
+    offs, pls, emb, x = _grid_setup(orc, cfg, 3001, 21, gpu)
+    g = np.random.default_rng(22).standard_normal((3001, cfg["L"] * cfg["C"])).astype(np.float32)
+    want, _ = orc.grid_encode_backward(g, x, emb, offs, pls, 16, None, cfg["gridtype"], cfg["ac"], cfg["interp"])
+    et = T(emb, gpu).requires_grad_(True)
+    out = grid_encode(T(x, gpu), et, T(offs, gpu), pls, 16, False, cfg["gridtype"], cfg["ac"], cfg["interp"])
+    out.backward(T(g, gpu))
+    got = et.grad.cpu().numpy()
+    # float atomics commute only up to rounding: compare with a tolerance scaled by the row's |grad| mass
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+    assert np.array_equal(got == 0, want == 0), "exactly the same rows are touched"
+
+
+def test_grid_empty_and_ragged_batches(gpu, orc):
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    enc = GridEncoder(num_levels=4, log2_hashmap_size=10, desired_resolution=64).to(gpu)
+    assert enc(torch.empty(0, 3, device=gpu)).shape == (0, 8)
+    for B in (1, 63, 64, 65, 257):
+        x = torch.rand(B, 3, device=gpu) * 2 - 1
+        y = enc(x, bound=1)
+        want, _ = orc.grid_encode_forward(((x + 1) / 2).cpu().numpy(), enc.embeddings.detach().cpu().numpy(),
+                                          enc.offsets.cpu().numpy(), enc.per_level_scale, 16)
+        assert np.array_equal(y.detach().cpu().numpy(), want)
+    # leading dimensions are preserved (grid.py:159-163)
+    assert enc(torch.rand(5, 7, 3, device=gpu)).shape == (5, 7, 8)
+
+
+def test_grid_tv_and_weight_decay(gpu, orc):
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    enc = GridEncoder(num_levels=6, level_dim=2, log2_hashmap_size=12, desired_resolution=256).to(gpu)
+    rng = np.random.default_rng(31)
+    emb = rng.uniform(-1, 1, tuple(enc.embeddings.shape)).astype(np.float32)
+    enc.embeddings.data.copy_(T(emb, gpu))
+    with pytest.raises(ValueError):
+        enc.grad_weight_decay(0.1)                       # grid.py:200-201: needs a grad first
+    g0 = rng.standard_normal(emb.shape).astype(np.float32)
+    enc.embeddings.grad = T(g0, gpu)
+    enc.grad_weight_decay(0.1)
+    want = orc.grad_weight_decay(emb, g0.copy(), enc.offsets.cpu().numpy(), 0.1)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    x = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    enc.embeddings.grad = T(g0, gpu)
+    enc.grad_total_variation(1e-3, T(x, gpu), bound=1)
+    want = orc.grad_total_variation((x + 1) / 2, emb, g0.copy(), enc.offsets.cpu().numpy(), 1e-3, enc.per_level_scale, 16)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+    enc.embeddings.grad = T(g0, gpu)
+    enc.grad_total_variation(1e-7)                       # default: 1e6 random points (grid.py:172)
+    assert torch.isfinite(enc.embeddings.grad).all()
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_matches_oracle(gpu, orc, degree):
+    from sanerf_hq_amd.shencoder import sh_encode
+    rng = np.random.default_rng(40 + degree)
+    d = rng.standard_normal((1000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    want, want_dd = orc.sh_encode_forward(d, degree, True)
+    dt = T(d, gpu).requires_grad_(True)
+    got = sh_encode(dt, degree, True)
+    # the kernel sums monomials (tools/gen_sh.py), the oracle evaluates the reference's factored forms
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=0, atol=4e-6)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    got.backward(T(g, gpu))
+    gi = orc.sh_encode_backward(g, d, degree, want_dd)
+    np.testing.assert_allclose(dt.grad.cpu().numpy(), gi, rtol=1e-4, atol=2e-4)
+
+
+def test_sh_encoder_module_normalises(gpu, orc):
+    from sanerf_hq_amd.shencoder import SHEncoder
+    v = torch.randn(17, 5, 3, device=gpu) * 3
+    y = SHEncoder(degree=4)(v)
+    assert y.shape == (17, 5, 16)
+    n = (v / v.norm(dim=-1, keepdim=True)).reshape(-1, 3).cpu().numpy()
+    want, _ = orc.sh_encode_forward(n, 4)
+    np.testing.assert_allclose(y.reshape(-1, 16).cpu().numpy(), want, atol=3e-6)
+
+
+@pytest.mark.parametrize("deg", [1, 4, 6, 10])
+def test_freq_matches_oracle(gpu, orc, deg):
+    from sanerf_hq_amd.freqencoder import FreqEncoder
+    rng = np.random.default_rng(50)
+    x = rng.uniform(-1, 1, (513, 3)).astype(np.float32)
+    enc = FreqEncoder(3, deg)
+    xt = T(x, gpu).requires_grad_(True)
+    y = enc(xt)
+    want = orc.freq_encode_forward(x, deg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, rtol=0, atol=2e-6)   # device vs host sinf/cosf
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    y.backward(T(g, gpu))
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), orc.freq_encode_backward(g, want, 3, deg), rtol=1e-4, atol=1e-3)
+
+
+def test_generate_rays_and_get_rays(gpu, orc):
+    from sanerf_hq_amd import synth
+    from sanerf_hq_amd.nerf import get_rays
+    from sanerf_hq_amd.raymarching import generate_rays
+    H, W = 37, 53
+    pose = synth.orbit_pose(1.3, 35.0, -50.0)
+    intr = synth.pinhole_intrinsics(H, W)
+    ro, rd = generate_rays(pose, intr, H, W, device=gpu)
+    wo, wd = orc.generate_rays(pose, *intr, H, W)
+    assert np.array_equal(ro.cpu().numpy(), wo) and np.array_equal(rd.cpu().numpy(), wd)
+    ro2, rd2 = generate_rays(pose, intr, H, W, device=gpu, row_begin=16, row_end=32)     # a rank's band
+    assert torch.equal(rd2, rd[16 * W:32 * W]) and torch.equal(ro2, ro[16 * W:32 * W])
+    res = get_rays(torch.from_numpy(pose)[None].to(gpu), np.array(intr, dtype=np.float32), H, W, -1)
+    assert torch.equal(res["rays_d"], rd) and res["inds_coarse"].shape == (H * W,)
+    sub = get_rays(torch.from_numpy(pose)[None].to(gpu), np.array(intr, dtype=np.float32), H, W, 64, random_sample=True)
+    idx = sub["j"] * W + sub["i"]
+    assert torch.equal(sub["rays_d"], rd[idx])
+
+
+def test_near_far_contract_bit_exact(gpu, orc):
+    from sanerf_hq_amd import raymarching as rm
+    from helpers import golden
+    g = golden("units")
+    for tag in ("big", "small"):
+        n, f = rm.near_far_from_aabb(T(g["nf_o"], gpu), T(g["nf_d"], gpu), torch.from_numpy(g[f"nf_{tag}_aabb"]), 0.2)
+        assert np.array_equal(n.cpu().numpy(), g[f"nf_{tag}_near"]) and np.array_equal(f.cpu().numpy(), g[f"nf_{tag}_far"])
+    z = rm.contract(T(g["contract_x"], gpu))
+    assert np.array_equal(z.cpu().numpy(), g["contract_z"])             # equals the REFERENCE's torch output
+    assert rm.contract(torch.rand(3, 5, 3, device=gpu)).shape == (3, 5, 3)
+
+
+@pytest.mark.parametrize("tag,T_", [("a", 65), ("b", 33), ("c", 17), ("d", 33)])
+def test_sample_pdf_indices_bit_exact_vs_oracle(gpu, orc, tag, T_):
+    from sanerf_hq_amd import raymarching as rm
+    from helpers import golden
+    g = golden("units")
+    bins, w, u = g[f"pdf_{tag}_bins"], g[f"pdf_{tag}_w"], g[f"pdf_{tag}_u"]
+    want_b, want_i = orc.sample_pdf(bins, w, T_, u=u)
+    got_b, got_i = rm.sample_pdf(T(bins, gpu), T(w, gpu), T_, return_inds=True, u=T(u, gpu))
+    assert np.array_equal(got_i.cpu().numpy(), want_i), "sample indices must be bit-exact"
+    assert np.array_equal(got_b.cpu().numpy(), want_b)
+    got_b2, got_i2 = rm.sample_pdf(T(bins, gpu), T(w, gpu), T_, return_inds=True)      # kernel's own linspace recipe
+    want_b2, want_i2 = orc.sample_pdf(bins, w, T_)
+    assert np.array_equal(got_i2.cpu().numpy(), want_i2) and np.array_equal(got_b2.cpu().numpy(), want_b2)
+    # against the reference's torch.searchsorted: equal up to the enumerated ties (oracle/README.md)
+    assert (got_i.cpu().numpy() != g[f"pdf_{tag}_inds"]).sum() <= 2
+    # perturb=True draws per-ray u: results stay sorted and inside the bin range
+    pb = rm.sample_pdf(T(bins, gpu), T(w, gpu), T_, perturb=True)
+    assert bool((pb[:, 1:] >= pb[:, :-1]).all()) and float(pb.min()) >= float(bins.min()) and float(pb.max()) <= float(bins.max())
+
+
+def test_sample_pdf_large_random(gpu, orc):
+    from sanerf_hq_amd import raymarching as rm
+    rng = np.random.default_rng(60)
+    N, T0, T_ = 20000, 128, 65
+    w = (rng.uniform(0, 1, (N, T0)) ** 6).astype(np.float32)
+    b = np.sort(rng.uniform(0, 1, (N, T0 + 1)), axis=1).astype(np.float32)
+    want_b, want_i = orc.sample_pdf(b, w, T_)
+    got_b, got_i = rm.sample_pdf(T(b, gpu), T(w, gpu), T_, return_inds=True)
+    assert np.array_equal(got_i.cpu().numpy(), want_i) and np.array_equal(got_b.cpu().numpy(), want_b)
+
+
+def test_weights_and_composite(gpu, orc):
+    from sanerf_hq_amd import raymarching as rm
+    rng = np.random.default_rng(70)
+    rb = np.sort(rng.uniform(0.2, 50, (3000, 33)), axis=1).astype(np.float32)
+    sg = np.exp(rng.uniform(-5, 5, (3000, 32))).astype(np.float32)
+    for opaque in (True, False):
+        w = rm.weights_from_sigma(T(rb, gpu), T(sg, gpu), opaque)
+        assert np.array_equal(w.cpu().numpy(), orc.weights_from_sigma(rb, sg, opaque)), "shared exp recipe => bit-identical"
+    v = rng.standard_normal((3000, 32, 7)).astype(np.float32)
+    wt = w.clone().requires_grad_(True)
+    vt = T(v, gpu).requires_grad_(True)
+    out = rm.composite(wt, vt)
+    ref = (w.unsqueeze(-1).double() * T(v, gpu).double()).sum(1)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    go = torch.randn_like(out)
+    out.backward(go)
+    np.testing.assert_allclose(vt.grad.cpu().numpy(), (w.unsqueeze(-1) * go.unsqueeze(1)).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), (T(v, gpu) * go.unsqueeze(1)).sum(-1).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert rm.composite(w, T(v[..., 0], gpu)).shape == (3000,)

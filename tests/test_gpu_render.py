@@ -1,0 +1,253 @@
+"""GPU: the fused renderer (sn_rm_render_rays) and the heads / training step built on it, against
+  (1) the CPU oracle on the same seeded inputs — sample indices bit-exact, fp32 outputs within the
+      tolerances written at each assert (north_star: 1e-4 on RGB / features);
+  (2) the golden fixtures captured from the reference's own Python;
+  (3) size-independent properties at the benchmark's full size (weights partition of unity,
+      chunk / tile-mapping invariance, determinism)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import camera_rays, golden, oracle_cfg, params_from_spec, product_model, spec_of, synthetic_params
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4     # BASELINE.json north_star: fp32 within 1e-4 on RGB / feature
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _render(model, ro, rd, want=("bins", "weights", "sigmas", "inds", "xyzs_last", "geo_feat_last", "f_image"), **kw):
+    from sanerf_hq_amd import raymarching as rm
+    plan = rm.RenderPlan(model, model.opt.num_steps, kw.pop("table_dtype", torch.float32))
+    out = rm.render_rays(plan, ro, rd, want=want, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("mlp", ["mfma", "valu"])
+def test_sref_vs_oracle_and_reference(gpu, orc, mlp):
+    """Reference schedule [128, 64, 32] with both proposal grids, 256 rays of the sref fixture."""
+    os.environ["SN_RENDER_MLP"] = mlp
+    try:
+        g = golden("render_sref")
+        params = params_from_spec(spec_of(g))
+        model = product_model(params, [128, 64, 32], False, gpu)
+        u_tables = {k: T(g[f"u{k}"], gpu) for k in (1, 2)}
+        got = _render(model, T(g["rays_o"], gpu), T(g["rays_d"], gpu), u_tables=u_tables)
+        cfg = oracle_cfg(orc, params, [128, 64, 32])
+        want = orc.render(cfg, g["rays_o"], g["rays_d"], debug=True, u_tables={k: g[f"u{k}"] for k in (1, 2)})
+    finally:
+        os.environ.pop("SN_RENDER_MLP", None)
+    # --- vs oracle: everything that decides the sample indices is bit-identical ---
+    for k in (0, 1):
+        assert np.array_equal(got[f"sigmas{k}"], want[f"sigmas{k}"]), f"proposal sigma stage {k}"
+        assert np.array_equal(got[f"weights{k}"], want[f"weights{k}"]), f"proposal weights stage {k}"
+    for k in (1, 2):
+        assert np.array_equal(got[f"inds{k}"], want[f"inds{k}"]), f"sample indices stage {k} must be bit-exact"
+        assert np.array_equal(got[f"bins{k}"], want[f"bins{k}"])
+    assert np.array_equal(got["xyzs_last"], want["xyzs_last"])
+    # final stage: MFMA sums the hidden layers in a permuted (fixed) order -> fp32 round-off only
+    np.testing.assert_allclose(got["sigmas2"], want["sigmas2"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["weights2"], want["weights2"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got["image"], want["image"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got["depth"], want["depth"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got["weights_sum"], want["weights_sum"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["f_image"], want["f_image"], rtol=1e-5, atol=1e-5)
+    # --- vs the reference's own outputs (fixture) ---
+    for k in (1, 2):
+        assert (got[f"inds{k}"] != g[f"inds{k}"]).sum() <= 2, "only torch.sum tie cases may differ"
+    np.testing.assert_allclose(got["image"], g["image"], rtol=0, atol=RGB_TOL)
+    np.testing.assert_allclose(got["depth"], g["depth"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(got["weights_sum"], g["weights_sum"], rtol=0, atol=1e-6)
+
+
+def test_flat128_vs_oracle_and_reference(gpu, orc):
+    """BASELINE configs[1] schedule: one stage of 128 full-field samples per ray."""
+    g = golden("render_flat128")
+    params = params_from_spec(spec_of(g))
+    model = product_model(params, [128], False, gpu)
+    got = _render(model, T(g["rays_o"], gpu), T(g["rays_d"], gpu))
+    want = orc.render(oracle_cfg(orc, params, [128]), g["rays_o"], g["rays_d"], debug=True)
+    assert np.array_equal(got["bins0"], want["bins0"]) and np.array_equal(got["xyzs_last"], want["xyzs_last"])
+    np.testing.assert_allclose(got["sigmas0"], want["sigmas0"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["image"], want["image"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got["image"], g["image"], rtol=0, atol=RGB_TOL)
+    np.testing.assert_allclose(got["depth"], g["depth"], rtol=1e-5, atol=1e-4)
+
+
+def test_mfma_and_valu_paths_agree(gpu, orc):
+    params = synthetic_params([128, 64, 32], seed=3)
+    model = product_model(params, [128, 64, 32], False, gpu)
+    _, _, ro, rd = camera_rays(orc, 48, 48)
+    outs = {}
+    for mode in ("mfma", "valu"):
+        os.environ["SN_RENDER_MLP"] = mode
+        try:
+            outs[mode] = _render(model, T(ro, gpu), T(rd, gpu), want=("inds", "weights"))
+        finally:
+            os.environ.pop("SN_RENDER_MLP", None)
+    assert np.array_equal(outs["mfma"]["inds2"], outs["valu"]["inds2"])
+    np.testing.assert_allclose(outs["mfma"]["image"], outs["valu"]["image"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(outs["mfma"]["weights2"], outs["valu"]["weights2"], rtol=0, atol=5e-6)
+
+
+def test_model_render_api_and_staging(gpu, orc):
+    """NeRFRenderer.render: result keys, chunk neutrality (renderer.py:185-219), tile mapping neutrality,
+    cam_near_far and tensor backgrounds."""
+    params = synthetic_params([128, 64, 32], seed=5)
+    model = product_model(params, [128, 64, 32], False, gpu)
+    H = W = 40
+    _, _, ro, rd = camera_rays(orc, H, W)
+    ro_t, rd_t = T(ro, gpu), T(rd, gpu)
+    with torch.no_grad():
+        full = model.render(ro_t, rd_t, staged=False, perturb=False)
+        assert set(full) == {"image", "depth", "weights_sum"}
+        assert full["image"].shape == (H * W, 3) and full["depth"].shape == (H * W,)
+        model.opt.max_ray_batch = 1000
+        staged = model.render(ro_t, rd_t, staged=True, perturb=False)
+        tiled = model.render(ro_t, rd_t, staged=False, perturb=False, tile_w=W)
+        for k in full:
+            assert torch.equal(full[k], staged[k]), f"chunked render differs in {k}"
+            assert torch.equal(full[k], tiled[k]), f"8x8-tile lane mapping differs in {k}"
+        # oracle agreement on the whole image
+        want = orc.render(oracle_cfg(orc, params, [128, 64, 32]), ro, rd)
+        np.testing.assert_allclose(full["image"].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+        # cam_near_far clamps the march (renderer.py:233-235)
+        cnf = torch.tensor([[0.5, 3.0]], device=gpu)
+        a = model.render(ro_t, rd_t, cam_near_far=cnf)
+        wa = orc.render(oracle_cfg(orc, params, [128, 64, 32]), ro, rd, cam_near_far=np.array([[0.5, 3.0]], np.float32))
+        np.testing.assert_allclose(a["image"].cpu().numpy(), wa["image"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(a["depth"].cpu().numpy(), wa["depth"], rtol=1e-5, atol=1e-5)
+        assert float(a["depth"].max()) <= 3.0 + 1e-4
+        # background: weights_sum == 1 with the opaque last sample, so bg never shows (renderer.py:312-315, 353)
+        b = model.render(ro_t, rd_t, bg_color=torch.rand(H * W, 3, device=gpu))
+        np.testing.assert_allclose(b["image"].cpu().numpy(), full["image"].cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(full["weights_sum"].cpu().numpy(), 1.0, atol=2e-6)
+
+
+def test_heads_vs_reference_fixture(gpu, orc):
+    """SAM-feature head + mask head on top of the fused render (BASELINE configs[2] path)."""
+    g = golden("render_heads")
+    params = params_from_spec(spec_of(g))
+    model = product_model(params, [128, 64, 32], True, gpu)
+    n_side = int(g["HW"][2])
+    with torch.no_grad():
+        out = model.render(T(g["rays_o"], gpu), T(g["rays_d"], gpu), staged=False, perturb=False,
+                           return_feats=1, return_mask=1, H=n_side, W=n_side)
+    assert out["samvit"].shape == (n_side, n_side, 256)
+    np.testing.assert_allclose(out["image"].cpu().numpy(), g["image"], rtol=0, atol=RGB_TOL)
+    np.testing.assert_allclose(out["samvit"].reshape(-1, 256).cpu().numpy(), g["samvit"], rtol=0, atol=RGB_TOL)
+    np.testing.assert_allclose(out["instance_mask_logits"].cpu().numpy(), g["instance_mask_logits"], rtol=0, atol=RGB_TOL)
+
+
+def test_mask_training_step_vs_reference_fixture(gpu, orc):
+    """BASELINE configs[4]: forward+backward of m_grid + mask_mlp under the mask NLL (trainer.py:401-428,473),
+    radiance field frozen; grads within 1e-3 of the reference's autograd."""
+    g = golden("train_c5")
+    params = params_from_spec(spec_of(g))
+    from helpers import make_opt
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    opt = make_opt(with_mask=True)
+    model = NeRFNetwork(opt)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    assert not unexpected
+    model = model.to(gpu).train()
+    for n_, p in model.named_parameters():
+        p.requires_grad_(n_.startswith("m_grid") or n_.startswith("mask_mlp"))        # main.py:249-256
+    out = model.render(T(g["rays_o"], gpu), T(g["rays_d"], gpu), staged=False, bg_color=1, perturb=False,
+                       update_proposal=False, return_rgb=0, return_feats=0, return_mask=1)
+    logits = out["instance_mask_logits"]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=0, atol=RGB_TOL)
+    eps = float(g["epsilon"])
+    pm = torch.softmax(logits, dim=-1).clamp(min=eps, max=1 - eps)
+    loss = (-torch.log(torch.gather(pm, -1, T(g["labels"], gpu)[..., None]))).mean()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    for i, lin in enumerate(model.mask_mlp[0].net):
+        ref = g[f"mask_mlp_grad{i}"]
+        np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    ge = model.m_grid.embeddings.grad
+    rows = T(g["m_grid_rows"], gpu)
+    ref_rows = g["m_grid_grad_rows"]
+    np.testing.assert_allclose(ge[rows].cpu().numpy(), ref_rows, rtol=1e-3, atol=1e-3 * np.abs(ref_rows).max())
+    assert int((ge.abs().sum(-1) > 0).sum()) == int(g["m_grid_touched"])
+    assert abs(ge.double().sum().item() - float(g["m_grid_grad_sum"])) < 1e-3 * float(g["m_grid_grad_abssum"])
+    assert abs(ge.double().abs().sum().item() - float(g["m_grid_grad_abssum"])) < 1e-3 * float(g["m_grid_grad_abssum"])
+    assert model.grid.embeddings.grad is None, "frozen radiance field must not receive gradients"
+
+
+def test_rgb_training_path_is_differentiable(gpu, orc):
+    """perturb=True / trainable field goes through the autograd stage loop and agrees with the fused
+    render when perturbation is off."""
+    params = synthetic_params([32, 16, 8], seed=9)
+    model = product_model(params, [32, 16, 8], False, gpu).train()
+    _, _, ro, rd = camera_rays(orc, 16, 16)
+    ro_t, rd_t = T(ro, gpu), T(rd, gpu)
+    model.opt.lambda_proposal, model.opt.lambda_distort = 1.0, 0.01
+    out = model.render(ro_t, rd_t, staged=False, perturb=False)
+    assert {"weights", "num_points", "proposal_loss", "distort_loss"} <= set(out)
+    loss = out["image"].mean() + out["proposal_loss"] + out["distort_loss"]
+    loss.backward()
+    for p in (model.grid.embeddings, model.grid_mlp.net[0].weight, model.view_mlp.net[2].weight,
+              model.prop_encoders[0].embeddings, model.prop_mlp[1].net[0].weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+    with torch.no_grad():
+        fused = model.render(ro_t, rd_t, staged=False, perturb=False)
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), fused["image"].cpu().numpy(), rtol=0, atol=RGB_TOL)
+    pert = model.render(ro_t, rd_t, staged=False, perturb=True)
+    assert torch.isfinite(pert["image"]).all()
+
+
+def test_fp16_tables_stay_close(gpu, orc):
+    """Half-precision table storage (BASELINE configs[1] says fp16): arithmetic stays fp32, so the result equals
+    the oracle run on the rounded tables; versus fp32 tables the image moves by table-rounding error only."""
+    params = synthetic_params([128], seed=13)
+    model = product_model(params, [128], False, gpu)
+    _, _, ro, rd = camera_rays(orc, 32, 32)
+    got16 = _render(model, T(ro, gpu), T(rd, gpu), want=(), table_dtype=torch.float16)
+    want16 = orc.render(oracle_cfg(orc, params, [128], table_f16=True), ro, rd)
+    np.testing.assert_allclose(got16["image"], want16["image"], rtol=0, atol=1e-5)
+    got32 = _render(model, T(ro, gpu), T(rd, gpu), want=())
+    assert np.abs(got16["image"] - got32["image"]).max() < 5e-3
+
+
+def test_full_size_properties(gpu, orc):
+    """800x800 (BASELINE configs[1] size): properties that do not need an oracle run."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    params = synthetic_params([128, 64, 32], seed=17)
+    model = product_model(params, [128, 64, 32], False, gpu)
+    H = W = 800
+    pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    ro, rd = rm.generate_rays(pose, synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    plan = rm.RenderPlan(model, [128, 64, 32])
+    a = rm.render_rays(plan, ro, rd, tile_w=W)
+    img = a["image"].clone(); dep = a["depth"].clone(); ws = a["weights_sum"].clone()
+    assert torch.isfinite(img).all() and torch.isfinite(dep).all()
+    np.testing.assert_allclose(ws.cpu().numpy(), 1.0, atol=3e-6)          # opaque last sample => partition of unity
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 + 1e-5     # sigmoid + (1 - 1) * bg
+    b = rm.render_rays(plan, ro, rd, tile_w=W)                            # deterministic
+    assert torch.equal(b["image"], img) and torch.equal(b["depth"], dep)
+    c = rm.render_rays(plan, ro, rd, tile_w=0, out={})                    # linear lane mapping: same pixels
+    assert torch.equal(c["image"], img)
+    # spot-check 512 random pixels against the oracle
+    idx = (synth.hash_u01(512, 5) * (H * W)).astype(np.int64)
+    want = orc.render(oracle_cfg(orc, params, [128, 64, 32]), ro[idx].cpu().numpy(), rd[idx].cpu().numpy())
+    np.testing.assert_allclose(img[idx].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dep[idx].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
+
+
+def test_unsupported_configurations_fail_loudly(gpu, orc):
+    from sanerf_hq_amd import raymarching as rm
+    params = synthetic_params([128, 64, 32], seed=19)
+    model = product_model(params, [128, 64, 32], False, gpu)
+    plan = rm.RenderPlan(model, [128, 64, 32])
+    plan.cfg.sh_degree = 3
+    with pytest.raises(RuntimeError, match="SH degree 4"):
+        rm.render_rays(plan, torch.rand(8, 3, device=gpu), torch.rand(8, 3, device=gpu))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        rm.render_rays(rm.RenderPlan(model, [128, 64, 32]), torch.rand(8, 3), torch.rand(8, 3))
