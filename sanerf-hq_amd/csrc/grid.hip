@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) void k_grid_tv(const float *__restrict__ input
         x01[d] = inputs[(size_t)b * D + d];
         if (x01[d] < 0 || x01[d] > 1) return;
     }
-    const uint32_t res = g.res[level], size = g.size[level], mode = g.mode[level];
+    // Neighbour coordinates can be one past the last vertex (the reference's guard at gridencoder.cu:593 is
+    // always true); its unconditional `% hashmap_size` (gridencoder.cu:78) wraps them, so force the generic modulo.
+    const uint32_t res = g.res[level], size = g.size[level], mode = (g.mode[level] & ~6u) | (2u << 1);
     const float *tab = table + (size_t)g.off[level] * C;
     float *gt = grad + (size_t)g.off[level] * C;
     uint32_t pg[D];
@@ -326,6 +328,7 @@ int sn_grid_encode_forward(const float *inputs, const void *embeddings, int tabl
                            float S, uint32_t H, float *dy_dx,
                            uint32_t gridtype, int align_corners, uint32_t interp,
                            int layout, sn_stream_t stream) {
+    if (B == 0) return SN_OK;   // empty batch: nothing to launch, pointers may be NULL
     SN_REQUIRE(inputs && embeddings && outputs, "grid_encode_forward: inputs/embeddings/outputs must be device pointers");
     SN_REQUIRE(table_dtype == SN_F32 || table_dtype == SN_F16, "grid_encode_forward: embeddings must be float32 or float16");
     SN_REQUIRE(layout == SN_LAYOUT_LBC || layout == SN_LAYOUT_BLC, "grid_encode_forward: bad layout %d", layout);
@@ -356,6 +359,7 @@ int sn_grid_encode_backward(const float *grad, const float *inputs, const void *
                             uint32_t gridtype, int align_corners, uint32_t interp,
                             int layout, sn_stream_t stream) {
     (void)embeddings; (void)table_dtype;
+    if (B == 0) return SN_OK;
     SN_REQUIRE(grad && inputs && grad_embeddings, "grid_encode_backward: grad/inputs/grad_embeddings must be device pointers");
     SN_REQUIRE(layout == SN_LAYOUT_LBC || layout == SN_LAYOUT_BLC, "grid_encode_backward: bad layout %d", layout);
     GridLevels g;

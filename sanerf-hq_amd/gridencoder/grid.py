@@ -14,7 +14,7 @@ Differences a caller can observe (all in the reference's favour-neutral directio
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Tuple
+from typing import Tuple
 
 import numpy as np
 import torch
@@ -26,21 +26,21 @@ from .. import _lib
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 _interp_to_id = {"linear": 0, "smoothstep": 1}
 
-_host_offsets_cache: Dict[Tuple[int, int, int], Tuple[int, ...]] = {}
-
-
 def _host_offsets(offsets: torch.Tensor) -> Tuple[int, ...]:
-    """Offsets as host ints; cached so a device-resident buffer costs one sync, once."""
-    key = (offsets.data_ptr(), offsets._version, offsets.numel())
-    hit = _host_offsets_cache.get(key)
-    if hit is None:
-        if offsets.dtype != torch.int32:
-            raise RuntimeError("offsets must be an int tensor")               # gridencoder.cu:17
-        hit = tuple(int(v) for v in offsets.detach().cpu().tolist())
-        if len(_host_offsets_cache) > 256:
-            _host_offsets_cache.clear()
-        _host_offsets_cache[key] = hit
-    return hit
+    """Offsets as host ints.  The copy is memoised ON the tensor object (with its version counter),
+    so a device-resident buffer costs one device->host sync, once; a memo keyed by address would be
+    unsafe because the allocator recycles addresses."""
+    memo = getattr(offsets, "_sn_host_offsets", None)
+    if memo is not None and memo[0] == offsets._version:
+        return memo[1]
+    if offsets.dtype != torch.int32:
+        raise RuntimeError("offsets must be an int tensor")               # gridencoder.cu:17
+    host = tuple(int(v) for v in offsets.detach().cpu().tolist())
+    try:
+        offsets._sn_host_offsets = (offsets._version, host)
+    except AttributeError:
+        pass
+    return host
 
 
 def _table_dtype(embeddings: torch.Tensor) -> int:
@@ -71,6 +71,8 @@ class _grid_encode(Function):
             table = embeddings.to(torch.half)
         table = table.contiguous()
         offs = _host_offsets(offsets)
+        if offs[-1] != embeddings.shape[0]:
+            raise RuntimeError(f"offsets end at row {offs[-1]} but embeddings has {embeddings.shape[0]} rows")
         out = torch.empty(B, L * Cc, device=inputs.device, dtype=torch.float32)
         if max_level < L:
             out.zero_()

@@ -130,7 +130,7 @@ def synthetic_params(num_steps, heads: bool = False, seed: int = 7, table_amp: f
         lin(f"grid_mlp.net.{i}.weight", o, k)
     for i, (o, k) in enumerate(((32, 31), (32, 32), (3, 32))):
         lin(f"view_mlp.net.{i}.weight", o, k)
-    for p in range(len(num_steps) - 1):
+    for p in range(2):   # NeRFNetwork always owns both proposal nets (network.py:131-143)
         tab(f"prop_encoders.{p}")
         lin(f"prop_mlp.{p}.net.0.weight", 16, 10)
         lin(f"prop_mlp.{p}.net.1.weight", 1, 16)

@@ -124,7 +124,8 @@ def test_sh_matches_oracle(gpu, orc, degree):
     dt = T(d, gpu).requires_grad_(True)
     got = sh_encode(dt, degree, True)
     # the kernel sums monomials (tools/gen_sh.py), the oracle evaluates the reference's factored forms
-    np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=0, atol=4e-6)
+    # (cancellation grows with the polynomial degree: coefficients reach ~75 at degree 8)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=0, atol=4e-6 if degree <= 6 else 2e-5)
     g = rng.standard_normal(want.shape).astype(np.float32)
     got.backward(T(g, gpu))
     gi = orc.sh_encode_backward(g, d, degree, want_dd)
