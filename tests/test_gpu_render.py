@@ -182,7 +182,9 @@ def test_mask_training_step_vs_reference_fixture(gpu, orc):
     ge = model.m_grid.embeddings.grad
     rows = T(g["m_grid_rows"], gpu)
     close(ge[rows].cpu().numpy(), g["m_grid_grad_rows"], "m_grid sampled rows")
-    assert int((ge.abs().sum(-1) > 0).sum()) == int(g["m_grid_touched"])
+    # rows whose contributions cancel to exactly 0.0 depend on the atomics' summation order: allow 0.01 %
+    touched = int((ge.abs().sum(-1) > 0).sum())
+    assert abs(touched - int(g["m_grid_touched"])) <= 1e-4 * int(g["m_grid_touched"]), (touched, int(g["m_grid_touched"]))
     assert abs(ge.double().sum().item() - float(g["m_grid_grad_sum"])) < 1e-3 * float(g["m_grid_grad_abssum"])
     assert abs(ge.double().abs().sum().item() - float(g["m_grid_grad_abssum"])) < 1e-3 * float(g["m_grid_grad_abssum"])
     assert model.grid.embeddings.grad is None, "frozen radiance field must not receive gradients"

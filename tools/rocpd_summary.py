@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (rocpd sqlite) outputs into the small text tables committed under profiles/.
+
+  python tools/rocpd_summary.py stats <results.db>      per-kernel count / total / avg / min / max (kernel-trace --stats)
+  python tools/rocpd_summary.py pmc   <results.db>      per-kernel mean of every collected counter
+"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    for key in ("k_final_stage", "k_prop_stage", "k_pack_grid_mlp", "k_grid_forward", "k_grid_backward", "k_composite",
+                "k_generate_rays", "k_sample_pdf", "k_weights"):
+        if key in name:
+            tag = ""
+            if "Lb1E" in name: tag = "<mfma>"
+            if "Lb0E" in name: tag = "<valu>"
+            if "6__half" in name: tag += "<f16>"
+            return key + tag
+    return name[:70]
+
+
+def stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, (end - start) from kernels").fetchall()
+    agg = defaultdict(list)
+    for n, d in rows:
+        agg[short(n)].append(d)
+    tot = sum(sum(v) for v in agg.values())
+    print(f"{'kernel':42s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k:42s} {len(v):6d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:10.2f} {min(v) / 1e3:10.2f} {max(v) / 1e3:10.2f} {100 * sum(v) / tot:6.2f}")
+
+
+def pmc(db):
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
+    rows = con.execute("select * from counters_collection").fetchall()
+    ki, ci, vi = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value")
+    agg = defaultdict(lambda: defaultdict(list))
+    for r in rows:
+        agg[short(r[ki])][r[ci]].append(r[vi])
+    for k, cs in agg.items():
+        if not any(t in k for t in ("k_final", "k_prop", "k_pack")):
+            continue
+        for c, v in sorted(cs.items()):
+            print(f"{k:30s} {c:28s} dispatches={len(v):4d} mean={sum(v) / len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
