@@ -98,50 +98,77 @@ __device__ __forceinline__ void sample_x01(const RayCommon &rc, const RaySetup &
     for (int k = 0; k < 3; ++k) x01[k] = (p[k] + rc.bound) / den;
 }
 
-// Row indices of the 8 corners of one cell.  One wave-uniform branch per LEVEL (hashed vs dense)
-// instead of one per corner, so the eight gathers of a level issue back to back.
-// Fast-path assumption checked on the host (levels_fast): hashed levels have a power-of-two
-// size, dense levels index all three dimensions and need no modulo.
+// Row indices of the 8 corners of one cell, BRANCH-FREE.  A per-level branch (hashed vs dense) is a
+// basic-block boundary for every level and pins the march to 8 gathers in flight per lane; here both
+// index forms are evaluated from shared partial products (the multipliers and the mask are
+// wave-uniform selects) and one v_cndmask per corner picks the result, so the gathers of all levels
+// can be scheduled together.
+// Fast-path assumptions checked on the host (levels_fast): hashed levels have a power-of-two size,
+// dense levels index all three dimensions and need no modulo, align_corners = False, linear interp.
 __device__ __forceinline__ void corner_rows(const uint32_t (&cell)[3], uint32_t res, uint32_t size, uint32_t mode,
                                             uint32_t (&rows)[8]) {
+    const bool hashed = (mode & 1u) != 0u;
+    const uint32_t my = hashed ? 2654435761u : res;            // gridencoder.cu:49 primes / :66-70 strides
+    const uint32_t mz = hashed ? 805459861u : res * res;
+    const uint32_t mask = hashed ? size - 1u : 0xffffffffu;
     const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
     const uint32_t x1 = umin(x0 + 1u, res - 1u), y1 = umin(y0 + 1u, res - 1u), z1 = umin(z0 + 1u, res - 1u);
-    if (mode & 1u) {   // gridencoder.cu:45-59
-        const uint32_t m = size - 1u;
-        const uint32_t hy0 = y0 * 2654435761u, hy1 = y1 * 2654435761u;
-        const uint32_t hz0 = z0 * 805459861u, hz1 = z1 * 805459861u;
-        rows[0] = (x0 ^ hy0 ^ hz0) & m; rows[1] = (x1 ^ hy0 ^ hz0) & m;
-        rows[2] = (x0 ^ hy1 ^ hz0) & m; rows[3] = (x1 ^ hy1 ^ hz0) & m;
-        rows[4] = (x0 ^ hy0 ^ hz1) & m; rows[5] = (x1 ^ hy0 ^ hz1) & m;
-        rows[6] = (x0 ^ hy1 ^ hz1) & m; rows[7] = (x1 ^ hy1 ^ hz1) & m;
-    } else {           // gridencoder.cu:66-70 with all three dimensions in the walk
-        const uint32_t r2 = res * res;
-        const uint32_t dy0 = y0 * res, dy1 = y1 * res, dz0 = z0 * r2, dz1 = z1 * r2;
-        rows[0] = x0 + dy0 + dz0; rows[1] = x1 + dy0 + dz0;
-        rows[2] = x0 + dy1 + dz0; rows[3] = x1 + dy1 + dz0;
-        rows[4] = x0 + dy0 + dz1; rows[5] = x1 + dy0 + dz1;
-        rows[6] = x0 + dy1 + dz1; rows[7] = x1 + dy1 + dz1;
+    const uint32_t Y0 = y0 * my, Y1 = y1 * my, Z0 = z0 * mz, Z1 = z1 * mz;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t x = (i & 1u) ? x1 : x0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
+        const uint32_t hx = x ^ Y ^ Z, dn = x + Y + Z;
+        rows[i] = (hashed ? hx : dn) & mask;
     }
 }
 
+// gridencoder.cu:145-149 for align_corners = False, linear interpolation (what the fused kernels support)
+__device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t res, float (&pos)[3], uint32_t (&cell)[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = __builtin_fmaf(x01[d], (float)res, -0.5f);
+        p = fminf(fmaxf(p, 0.0f), (float)(res - 1u));
+        const float f = floorf(p);
+        cell[d] = (uint32_t)f;
+        pos[d] = p - f;
+    }
+}
+
+// ---- two-phase level groups -----------------------------------------------------------------
+// hipcc schedules "8 loads, wait, 16 fmas" level by level if the source is written level by level,
+// which leaves 8 gathers in flight per lane and exposes one full memory latency per level.  The
+// march therefore handles GROUP levels at a time in two explicit phases separated by scheduling
+// barriers: (1) locate + row indices + ISSUE all GROUP*8 gathers (32-bit byte offsets from a
+// wave-uniform base -> saddr-form global loads, one address VGPR each), (2) blend.
 template <typename T, int C>
-__device__ __forceinline__ void level_interp(const T *__restrict__ tab, const uint32_t (&rows)[8], const float (&pos)[3], float (&acc)[C]) {
-    // issue the 8 gathers first (32-bit byte offsets from a wave-uniform base: saddr-form loads)
-    float v[8][C];
+struct Corner { float v[C]; };
+
+template <typename T, int C>
+__device__ __forceinline__ void issue_level(const T *__restrict__ table, const GridLevels &g, int l, const float (&x01)[3],
+                                            float (&pos)[3], Corner<T, C> (&cv)[8]) {
+    const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
+    const T *tab = table + (size_t)g.off[l] * C;
+    uint32_t cell[3], rows[8];
+    locate_linear(x01, res, pos, cell);
+    corner_rows(cell, res, size, mode, rows);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const T *row = reinterpret_cast<const T *>(reinterpret_cast<const char *>(tab) + rows[i] * (uint32_t)(C * sizeof(T)));
         if constexpr (C == 2 && sizeof(T) == 4) {
             const float2 t = *reinterpret_cast<const float2 *>(row);
-            v[i][0] = t.x; v[i][1] = t.y;
+            cv[i].v[0] = t.x; cv[i].v[1] = t.y;
         } else if constexpr (C == 2 && sizeof(T) == 2) {
             const __half2 t = *reinterpret_cast<const __half2 *>(row);
-            v[i][0] = __low2float(t); v[i][1] = __high2float(t);
+            cv[i].v[0] = __low2float(t); cv[i].v[1] = __high2float(t);
         } else {
 #pragma unroll
-            for (int c = 0; c < C; ++c) v[i][c] = table_ld<T>(row + c);
+            for (int c = 0; c < C; ++c) cv[i].v[c] = table_ld<T>(row + c);
         }
     }
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<T, C> (&cv)[8], float (&acc)[C]) {
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
 #pragma unroll
@@ -150,31 +177,45 @@ __device__ __forceinline__ void level_interp(const T *__restrict__ tab, const ui
 #pragma unroll
         for (uint32_t d = 0; d < 3; ++d) w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, v[idx][c], acc[c]);
+        for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, cv[idx].v[c], acc[c]);
     }
 }
 
-// all levels of one grid at one position; D = 3.  gridencoder.cu:94-201 per level.
-template <typename T, int L, int C>
-__device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
-                                              float (&feat)[L * C]) {
+// Encodes all L levels; `emit(l, acc)` receives each level's C features (zeros when out of range).
+template <typename T, int L, int C, int GROUP, typename Emit>
+__device__ __forceinline__ void encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit) {
+    static_assert(L % GROUP == 0 || GROUP >= L, "GROUP must divide L");
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < 3; ++d) oob |= (x01[d] < 0.0f || x01[d] > 1.0f);
+    constexpr int G = GROUP >= L ? L : GROUP;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
-        const T *tab = table + (size_t)g.off[l] * C;
-        float pos[3], deriv[3];
-        uint32_t cell[3];
-        grid_locate<3>(x01, res, g.align_corners != 0, g.interp, pos, deriv, cell);
-        float acc[C];
-        uint32_t rows[8];
-        corner_rows(cell, res, size, mode, rows);
-        level_interp<T, C>(tab, rows, pos, acc);
+    for (int l0 = 0; l0 < L; l0 += G) {
+        float pos[G][3];
+        Corner<T, C> cv[G][8];
 #pragma unroll
-        for (int c = 0; c < C; ++c) feat[l * C + c] = oob ? 0.0f : acc[c];
+        for (int k = 0; k < G; ++k) issue_level<T, C>(table, g, l0 + k, x01, pos[k], cv[k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            float acc[C];
+            blend_level<T, C>(pos[k], cv[k], acc);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = oob ? 0.0f : acc[c];
+            emit(l0 + k, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
+template <typename T, int L, int C, int GROUP = L>
+__device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
+                                              float (&feat)[L * C]) {
+    encode_grouped<T, L, C, GROUP>(table, g, x01, [&](int l, const float (&acc)[C]) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) feat[l * C + c] = acc[c];
+    });
 }
 
 // y = act(W x), W [OUT][IN] row-major at a wave-uniform address (SGPR / scalar-cache loads);
@@ -493,6 +534,149 @@ __device__ __forceinline__ void grid_mlp_mfma(const float *__restrict__ lds_pack
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// fp16 hi/lo split path of the same MLP (MLP_F16X3, the default).
+// fp32 MFMA issues at the vector-ALU rate (64 cycles per 32x32x2), which made the matrix pipe the
+// co-bound of the final stage.  Writing every operand as x = hi + lo with hi = f16(x),
+// lo = f16(x - hi) (22 significant bits) and accumulating the three products hi*hi + hi*lo + lo*hi
+// in fp32 on v_mfma_f32_32x32x16_f16 costs 3 x 32 cycles per 32x32x16 block instead of 8 x 64:
+// 5.3x fewer matrix-pipe cycles at ~2^-22 relative error per product (f16 x f16 is exact in fp32;
+// the dropped lo*lo term is 2^-22).  Range: |activation| must stay below 65504.
+//   A operand (weights):     lane l holds W[m = l&31][k = 8*(l>>5) + 0..7] of the k-step
+//   B operand (activations): lane l holds X[k = 8*(l>>5) + 0..7][j = l&31]
+//   C/D layout as for every 32x32 MFMA: reg r of lane l = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+// so 8 consecutive accumulator registers of a lane are a valid B operand of the next layer
+// (low half-wave rows {0-3, 8-11} / high half-wave rows {4-7, 12-15} of that 16-row block); only
+// the weights' k order is permuted, once, by k_pack_grid_mlp_f16.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+constexpr int PACK16_VECS = 4 + 8 + 4;                 // layer1 [mt 2][s 2], layer2 [mt 2][q 4], layer3 [q 4]
+constexpr int PACK16_U4 = PACK16_VECS * 2 * 64;        // x (hi, lo) x 64 lanes, 16 B each = 32 KiB
+constexpr int SLAB_STRIDE = 20;                        // dwords per sample row (16 levels + 4 pad: conflict-free b128 reads)
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+    const half2_t h = {(_Float16)a, (_Float16)b};
+    const half2_t l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+__global__ void k_pack_grid_mlp_f16(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
+                                    uint4 *__restrict__ pack) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;        // one thread per (vec, lane)
+    if (t >= (uint32_t)PACK16_VECS * 64u) return;
+    const uint32_t lane = t & 63u, vec = t >> 6;
+    const uint32_t m = lane & 31u, hi = lane >> 5;
+    float v[8];
+    if (vec < 4u) {                       // layer 1: k = 16 s + 8 hi + i  (feature 2*level + c)
+        const uint32_t mt = vec >> 1, sst = vec & 1u;
+        for (uint32_t i = 0; i < 8; ++i) v[i] = w1[(mt * 32u + m) * 32u + 16u * sst + 8u * hi + i];
+    } else {
+        const bool l3 = vec >= 12u;
+        const uint32_t q = l3 ? vec - 12u : (vec - 4u) & 3u, mt = l3 ? 0u : (vec - 4u) >> 2;
+        const uint32_t src_mt = q >> 1, half = q & 1u;
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t r = 8u * half + i;
+            const uint32_t h = src_mt * 32u + (r & 3u) + 8u * (r >> 2) + 4u * hi;
+            v[i] = l3 ? (m < 16u ? w3[m * 64u + h] : 0.0f) : w2[(mt * 32u + m) * 64u + h];
+        }
+    }
+    uint4 ph, pl;
+    split2(v[0], v[1], ph.x, pl.x); split2(v[2], v[3], ph.y, pl.y);
+    split2(v[4], v[5], ph.z, pl.z); split2(v[6], v[7], ph.w, pl.w);
+    pack[(vec * 2u + 0u) * 64u + lane] = ph;
+    pack[(vec * 2u + 1u) * 64u + lane] = pl;
+}
+
+__device__ __forceinline__ floatx16 mfma3(const uint4 &ah, const uint4 &al, const uint4 &bh, const uint4 &bl, floatx16 acc) {
+    const half8_t Ah = __builtin_bit_cast(half8_t, ah), Al = __builtin_bit_cast(half8_t, al);
+    const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+    return acc;
+}
+
+// relu + split of 8 consecutive accumulator registers -> (hi, lo) B operand of the next layer
+__device__ __forceinline__ void acc_to_b(const floatx16 &v, int half, uint4 &bh, uint4 &bl) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float t = v[8 * half + i]; x[i] = t > 0.0f ? t : 0.0f; }
+    split2(x[0], x[1], bh.x, bl.x); split2(x[2], x[3], bh.y, bl.y);
+    split2(x[4], x[5], bh.z, bl.z); split2(x[6], x[7], bh.w, bl.w);
+}
+
+// slab_hi / slab_lo: this wave's [64 samples][SLAB_STRIDE dwords] images written by encode_levels_split
+__device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, const uint32_t *__restrict__ slab_hi,
+                                                const uint32_t *__restrict__ slab_lo, float (&out)[16]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = lane & 31u, hi = lane >> 5;
+    float res[2][8];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        const uint32_t row = (tile * 32u + lo) * SLAB_STRIDE + 4u * hi;
+        floatx16 h1[2], h2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const uint4 bh = *reinterpret_cast<const uint4 *>(slab_hi + row + 8 * st);
+                const uint4 bl = *reinterpret_cast<const uint4 *>(slab_lo + row + 8 * st);
+                const int vec = mt * 2 + st;
+                acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+            }
+            h1[mt] = acc;
+            __builtin_amdgcn_sched_barrier(0);   // keep the next block's operand reads from being hoisted (VGPR pressure)
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 bh, bl;
+                acc_to_b(h1[q >> 1], q & 1, bh, bl);
+                const int vec = 4 + mt * 4 + q;
+                acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+            }
+            h2[mt] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 bh, bl;
+            acc_to_b(h2[q >> 1], q & 1, bh, bl);
+            const int vec = 12 + q;
+            acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) res[tile][r] = acc[r];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(res[0][r]), __float_as_uint(res[1][r]), false, false);
+        const int base = (r & 3) + 8 * (r >> 2);
+        out[base] = __uint_as_float(rr[0]);
+        out[base + 4] = __uint_as_float(rr[1]);
+    }
+}
+
+// hash-grid features of one position, split into f16 hi / lo and written to this lane's slab rows
+// (dword l = the level's two features as a half2).
+template <typename T, int L, int GROUP>
+__device__ __forceinline__ void encode_levels_split(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
+                                                    uint32_t *__restrict__ row_hi, uint32_t *__restrict__ row_lo) {
+    encode_grouped<T, L, 2, GROUP>(table, g, x01, [&](int l, const float (&acc)[2]) {
+        uint32_t ph, pl;
+        split2(acc[0], acc[1], ph, pl);
+        row_hi[l] = ph;
+        row_lo[l] = pl;
+    });
+}
+
 // Scalar-pipe fallback of the same MLP (SN_RENDER_MLP=valu): activations live in per-thread LDS
 // columns act[k][tid]; every neuron is one k-ascending fmaf chain (the oracle's order).
 template <int IN, int OUT, int ACT>
@@ -510,33 +694,21 @@ __device__ __forceinline__ void dense_lds(const float *__restrict__ W, const flo
     }
 }
 
-// hash-grid features of one position written to an LDS column fe[k * stride]; levels are
-// issued in groups of GROUP so at most GROUP*8 gathers are in flight per lane.
+// hash-grid features of one position written to an LDS column fe[k * stride]
 template <typename T, int L, int C, int GROUP>
 __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                   float *__restrict__ fe, uint32_t stride) {
-    bool oob = false;
+    encode_grouped<T, L, C, GROUP>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) oob |= (x01[d] < 0.0f || x01[d] > 1.0f);
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
-        const T *tab = table + (size_t)g.off[l] * C;
-        float pos[3], deriv[3];
-        uint32_t cell[3];
-        grid_locate<3>(x01, res, g.align_corners != 0, g.interp, pos, deriv, cell);
-        float acc[C];
-        uint32_t rows[8];
-        corner_rows(cell, res, size, mode, rows);
-        level_interp<T, C>(tab, rows, pos, acc);
-#pragma unroll
-        for (int c = 0; c < C; ++c) fe[(l * C + c) * stride] = oob ? 0.0f : acc[c];
-        if ((l % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int c = 0; c < C; ++c) fe[(l * C + c) * stride] = acc[c];
+    });
 }
 
-template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, bool MFMA>
-__global__ __launch_bounds__(256, MFMA ? 2 : 1) void k_final_stage(FinalArgs a) {
+enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
+
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE>
+__global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(FinalArgs a) {
+    constexpr bool MFMA = MODE != MLP_VALU;
     constexpr int IN = L * C;
     constexpr int GEO = NOUT - 1;
     constexpr int NSH = 16;                       // sh degree 4 (network.py:97)
@@ -551,7 +723,19 @@ __global__ __launch_bounds__(256, MFMA ? 2 : 1) void k_final_stage(FinalArgs a) 
     float *actB = nullptr;
     constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value, VW2 = 3 * PadIn<VH>::value;
     float *lds_vw;        // view_mlp weights (padded rows), all three layers back to back
-    if constexpr (MFMA) {
+    uint32_t *slab_hi = nullptr, *slab_lo = nullptr;      // MLP_F16X3: this wave's split feature images
+    if constexpr (MODE == MLP_F16X3) {
+        static_assert(PACK16_U4 * 4 == PACK_FLOATS, "both packings fill the same 32 KiB");
+        for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += 256u)
+            reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
+        constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;   // dwords: hi image + lo image
+        float *wave_base = lds + PACK_FLOATS + (threadIdx.x >> 6) * WAVE_SLAB;
+        slab_hi = reinterpret_cast<uint32_t *>(wave_base);
+        slab_lo = slab_hi + 64 * SLAB_STRIDE;
+        fe = wave_base + (threadIdx.x & 63u);             // after the march the slab is reused as fp32 columns
+        fstride = 64u;
+        lds_vw = lds + PACK_FLOATS + 4 * WAVE_SLAB;
+    } else if constexpr (MODE == MLP_F32) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)PACK_FLOATS / 4u; i += 256u)
             reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(a.mlp_pack)[i];
         fe = lds + PACK_FLOATS + (threadIdx.x >> 6) * (IN * 64) + (threadIdx.x & 63u);
@@ -607,14 +791,21 @@ __global__ __launch_bounds__(256, MFMA ? 2 : 1) void k_final_stage(FinalArgs a) 
         const float tmid = (rb_next + rb_prev) / 2.0f;
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
-        encode_levels_lds<TT, L, C, 2>(table, a.g, x01, fe, fstride);
         float h[NOUT];
-        if constexpr (MFMA) {
+        if constexpr (MODE == MLP_F16X3) {
+            const uint32_t lane = threadIdx.x & 63u;
+            encode_levels_split<TT, L, 4>(table, a.g, x01, slab_hi + lane * SLAB_STRIDE, slab_lo + lane * SLAB_STRIDE);
+            __builtin_amdgcn_wave_barrier();
+            grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+            __builtin_amdgcn_wave_barrier();
+        } else if constexpr (MODE == MLP_F32) {
+            encode_levels_lds<TT, L, C, 2>(table, a.g, x01, fe, fstride);
             // the slab is private to this wave and LDS serves a wave's requests in order
             __builtin_amdgcn_wave_barrier();
             grid_mlp_mfma(lds + opaque_zero(), fe - (threadIdx.x & 63u), h);
             __builtin_amdgcn_wave_barrier();
         } else {
+            encode_levels_lds<TT, L, C, 2>(table, a.g, x01, fe, fstride);
             dense_lds<IN, H1, 1>(a.w[0], fe, actB, fstride);
             dense_lds<H1, H2, 1>(a.w[1], actB, fe, fstride);
             dense_lds<H2, NOUT, 0>(a.w[2], fe, actB, fstride);
@@ -647,7 +838,8 @@ __global__ __launch_bounds__(256, MFMA ? 2 : 1) void k_final_stage(FinalArgs a) 
     }
 
     // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
-    static_assert(VH <= IN && NCOL <= IN, "view MLP activations reuse the feature column");
+    static_assert(VH <= IN && NCOL <= IN && IN * 64 <= 2 * 64 * SLAB_STRIDE, "view MLP activations reuse the feature column / slab");
+    __builtin_amdgcn_wave_barrier();
     float rgb[3];
     const float ws = (float)wsum;
     {   // sum_t w_t * SH_c(d) = SH_c(d) * sum_t w_t: the direction is constant along the ray
@@ -719,7 +911,7 @@ static bool levels_fast(const GridLevels &g) {
         if (mode & 1u) { if (mk != 1u) return false; }
         else if (mk != 0u || nd != 3u) return false;
     }
-    return g.align_corners == 0 || true;
+    return g.align_corners == 0 && g.interp == 0;
 }
 
 static bool mlp_is(const sn_mlp_desc *m, uint32_t nl, const uint32_t *dims) {
@@ -824,8 +1016,14 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         set_error("render_rays: the C1 plumbing field is a CPU-only configuration (BASELINE.json configs[0]); not instantiated for the GPU");
         return SN_ERR_UNSUPPORTED;
     }
+    // SN_RENDER_MLP = f16x3 (default: fp16 hi/lo split on the matrix cores, fp32 accumulate),
+    //                 mfma32 / mfma (exact fp32 v_mfma_f32_32x32x2_f32), valu (vector-ALU fallback)
     const char *mode = getenv("SN_RENDER_MLP");
-    const bool use_mfma = !(mode && strcmp(mode, "valu") == 0);
+    int mlp_mode = MLP_F16X3;
+    if (mode && strcmp(mode, "valu") == 0) mlp_mode = MLP_VALU;
+    else if (mode && (strcmp(mode, "mfma32") == 0 || strcmp(mode, "mfma") == 0)) mlp_mode = MLP_F32;
+    else if (mode && mode[0] && strcmp(mode, "f16x3") != 0) { set_error("render_rays: unknown SN_RENDER_MLP=%s", mode); return SN_ERR_INVALID; }
+    const bool use_mfma = mlp_mode != MLP_VALU;
 
     SN_REQUIRE(io->workspace != nullptr, "render_rays: workspace is NULL");
     float *pack = reinterpret_cast<float *>(io->workspace);
@@ -833,7 +1031,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     const size_t scratch_floats_avail = io->workspace_bytes / sizeof(float) > (size_t)PACK_FLOATS ? io->workspace_bytes / sizeof(float) - PACK_FLOATS : 0;
     if (use_mfma) {
         ProfScope ps(st, PK_PACK);
-        hipLaunchKernelGGL(k_pack_grid_mlp, dim3(PACK_FLOATS / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0], cfg->grid_mlp.weight[1], cfg->grid_mlp.weight[2], pack);
+        if (mlp_mode == MLP_F16X3)
+            hipLaunchKernelGGL(k_pack_grid_mlp_f16, dim3(PACK16_VECS * 64 / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0],
+                               cfg->grid_mlp.weight[1], cfg->grid_mlp.weight[2], reinterpret_cast<uint4 *>(pack));
+        else
+            hipLaunchKernelGGL(k_pack_grid_mlp, dim3(PACK_FLOATS / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0], cfg->grid_mlp.weight[1], cfg->grid_mlp.weight[2], pack);
         SN_LAUNCH_CHECK("k_pack_grid_mlp");
     }
 
@@ -898,21 +1100,24 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
         const bool f16 = cfg->grid.table_dtype == SN_F16;
         ProfScope ps_final(st, PK_FINAL);
-        if (use_mfma) {
-            const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 32 * 64 + 32 * 32 + 32 * 32 + 3 * 32) * sizeof(float);   // 72.4 KiB
-            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            if (f16) hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, true>), dim3(nblk), dim3(256), lds_bytes, st, fa);
-            else hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, true>), dim3(nblk), dim3(256), lds_bytes, st, fa);
-        } else {
-            const size_t lds_bytes = (size_t)(2 * 64 * 256 + 32 * 32 + 32 * 32 + 3 * 32) * sizeof(float);   // 136 KiB: needs the opt-in attribute
-            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            if (f16) hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, false>), dim3(nblk), dim3(256), lds_bytes, st, fa);
-            else hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, false>), dim3(nblk), dim3(256), lds_bytes, st, fa);
-        }
+#define SN_LAUNCH_FINAL(MODE_, LDS_FLOATS)                                                                                   \
+        do {                                                                                                                 \
+            const size_t lds_bytes = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
+            if (f16) {                                                                                                       \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
+                hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+            } else {                                                                                                         \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
+                hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+            }                                                                                                                \
+        } while (0)
+        constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
+        if (mlp_mode == MLP_F16X3) SN_LAUNCH_FINAL(MLP_F16X3, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE + VIEW_W);   // 75.1 KiB
+        else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, PACK_FLOATS + 4 * 32 * 64 + VIEW_W);               // 72.4 KiB
+        else SN_LAUNCH_FINAL(MLP_VALU, 2 * 64 * 256 + VIEW_W);                                                     // 136 KiB
+#undef SN_LAUNCH_FINAL
         SN_LAUNCH_CHECK("k_final_stage");
     }
     return SN_OK;

@@ -29,7 +29,7 @@ def _render(model, ro, rd, want=("bins", "weights", "sigmas", "inds", "xyzs_last
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("mlp", ["mfma", "valu"])
+@pytest.mark.parametrize("mlp", ["f16x3", "mfma32", "valu"])
 def test_sref_vs_oracle_and_reference(gpu, orc, mlp):
     """Reference schedule [128, 64, 32] with both proposal grids, 256 rays of the sref fixture."""
     os.environ["SN_RENDER_MLP"] = mlp
@@ -51,7 +51,8 @@ def test_sref_vs_oracle_and_reference(gpu, orc, mlp):
         assert np.array_equal(got[f"inds{k}"], want[f"inds{k}"]), f"sample indices stage {k} must be bit-exact"
         assert np.array_equal(got[f"bins{k}"], want[f"bins{k}"])
     assert np.array_equal(got["xyzs_last"], want["xyzs_last"])
-    # final stage: MFMA sums the hidden layers in a permuted (fixed) order -> fp32 round-off only
+    # final stage: the matrix-core paths sum the hidden layers in a permuted (fixed) order; the default f16x3
+    # path additionally drops the lo*lo product terms (2^-22 relative) -> fp32 round-off class either way
     np.testing.assert_allclose(got["sigmas2"], want["sigmas2"], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(got["weights2"], want["weights2"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(got["image"], want["image"], rtol=0, atol=1e-5)
@@ -80,20 +81,30 @@ def test_flat128_vs_oracle_and_reference(gpu, orc):
     np.testing.assert_allclose(got["depth"], g["depth"], rtol=1e-5, atol=1e-4)
 
 
-def test_mfma_and_valu_paths_agree(gpu, orc):
+def test_mlp_paths_agree(gpu, orc):
+    """The three implementations of the 32-64-64-16 MLP (fp16 hi/lo split MFMA = default, exact fp32 MFMA,
+    vector ALU) give the same picture; the proposal stages (which decide the indices) are shared."""
     params = synthetic_params([128, 64, 32], seed=3)
     model = product_model(params, [128, 64, 32], False, gpu)
     _, _, ro, rd = camera_rays(orc, 48, 48)
     outs = {}
-    for mode in ("mfma", "valu"):
+    for mode in ("f16x3", "mfma32", "valu"):
         os.environ["SN_RENDER_MLP"] = mode
         try:
-            outs[mode] = _render(model, T(ro, gpu), T(rd, gpu), want=("inds", "weights"))
+            outs[mode] = _render(model, T(ro, gpu), T(rd, gpu), want=("inds", "weights", "sigmas"))
         finally:
             os.environ.pop("SN_RENDER_MLP", None)
-    assert np.array_equal(outs["mfma"]["inds2"], outs["valu"]["inds2"])
-    np.testing.assert_allclose(outs["mfma"]["image"], outs["valu"]["image"], rtol=0, atol=5e-6)
-    np.testing.assert_allclose(outs["mfma"]["weights2"], outs["valu"]["weights2"], rtol=0, atol=5e-6)
+    for mode in ("mfma32", "valu"):
+        assert np.array_equal(outs["f16x3"]["inds2"], outs[mode]["inds2"])
+        np.testing.assert_allclose(outs["f16x3"]["sigmas2"], outs[mode]["sigmas2"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(outs["f16x3"]["image"], outs[mode]["image"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(outs["f16x3"]["weights2"], outs[mode]["weights2"], rtol=0, atol=5e-6)
+    os.environ["SN_RENDER_MLP"] = "bogus"
+    try:
+        with pytest.raises(RuntimeError, match="unknown SN_RENDER_MLP"):
+            _render(model, T(ro, gpu), T(rd, gpu), want=())
+    finally:
+        os.environ.pop("SN_RENDER_MLP", None)
 
 
 def test_model_render_api_and_staging(gpu, orc):
