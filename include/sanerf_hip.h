@@ -200,6 +200,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
  * synchronises, returns summed device milliseconds and launch counts per class, and resets. */
 void sn_rm_profile_enable(int on);
 int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_classes);
+/* Diagnostics: occupancy-API workgroups/CU of the fused kernels (prop, final f16x3, final f32-MFMA) and their dynamic LDS bytes. */
+int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "sn_rm_render_rays": (_int, [C.POINTER(RenderCfg), C.POINTER(RenderIO), _vp]),
     "sn_rm_profile_enable": (None, [_int]),
     "sn_rm_profile_read": (_int, [_vp, _vp, _int]),
+    "sn_rm_debug_occupancy": (_int, [_vp, _vp, _int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

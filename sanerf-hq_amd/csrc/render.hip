@@ -734,22 +734,24 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         slab_lo = slab_hi + 64 * SLAB_STRIDE;
         fe = wave_base + (threadIdx.x & 63u);             // after the march the slab is reused as fp32 columns
         fstride = 64u;
-        lds_vw = lds + PACK_FLOATS + 4 * WAVE_SLAB;
+        lds_vw = lds;                                     // overlays the packed weights once the march is over
     } else if constexpr (MODE == MLP_F32) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)PACK_FLOATS / 4u; i += 256u)
             reinterpret_cast<float4 *>(lds)[i] = reinterpret_cast<const float4 *>(a.mlp_pack)[i];
         fe = lds + PACK_FLOATS + (threadIdx.x >> 6) * (IN * 64) + (threadIdx.x & 63u);
         fstride = 64u;
-        lds_vw = lds + PACK_FLOATS + 4 * IN * 64;
+        lds_vw = lds;
     } else {
         fe = lds + threadIdx.x;
         actB = lds + 64 * 256 + threadIdx.x;
         fstride = 256u;
         lds_vw = lds + 2 * 64 * 256;
     }
-    stage_weights<NCOL, VH>(lds_vw, a.vw[0]);
-    stage_weights<VH, VH>(lds_vw + VW0, a.vw[1]);
-    stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
+    if constexpr (!MFMA) {
+        stage_weights<NCOL, VH>(lds_vw, a.vw[0]);
+        stage_weights<VH, VH>(lds_vw + VW0, a.vw[1]);
+        stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
+    }
     __syncthreads();
 
     uint32_t n;
@@ -839,6 +841,15 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
 
     // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
     static_assert(VH <= IN && NCOL <= IN && IN * 64 <= 2 * 64 * SLAB_STRIDE, "view MLP activations reuse the feature column / slab");
+    if constexpr (MFMA) {
+        // every wave marches the same T steps: once all are done the 32 KiB of packed MLP weights are dead and
+        // the view-MLP weights take their place (keeps the workgroup under 80 KiB of LDS = 2 workgroups per CU)
+        __syncthreads();
+        stage_weights<NCOL, VH>(lds_vw, a.vw[0]);
+        stage_weights<VH, VH>(lds_vw + VW0, a.vw[1]);
+        stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
+        __syncthreads();
+    }
     __builtin_amdgcn_wave_barrier();
     float rgb[3];
     const float ws = (float)wsum;
@@ -966,6 +977,24 @@ int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_c
         hipEventDestroy(sp.a); hipEventDestroy(sp.b);
     }
     g_prof.clear();
+    return SN_OK;
+}
+
+/* Diagnostics: occupancy-API answer (workgroups per CU) for the fused kernels at their launch LDS sizes.
+ * out[0] = k_prop_stage<float>, out[1] = k_final_stage f16x3 <float>, out[2] = f32-MFMA <float>; lds[i] = dynamic LDS bytes used. */
+int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
+    SN_REQUIRE(out && lds && n >= 3, "debug_occupancy: need 3 slots");
+    int v = 0;
+    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_prop_stage<float, 5, 2, 16>, 256, 0));
+    out[0] = v; lds[0] = 0;
+    size_t l1 = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3>, 256, l1));
+    out[1] = v; lds[1] = (int32_t)l1;
+    size_t l2 = (size_t)(PACK_FLOATS + 4 * 32 * 64) * sizeof(float);
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F32>, 256, l2));
+    out[2] = v; lds[2] = (int32_t)l2;
     return SN_OK;
 }
 
@@ -1114,8 +1143,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             }                                                                                                                \
         } while (0)
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
-        if (mlp_mode == MLP_F16X3) SN_LAUNCH_FINAL(MLP_F16X3, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE + VIEW_W);   // 75.1 KiB
-        else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, PACK_FLOATS + 4 * 32 * 64 + VIEW_W);               // 72.4 KiB
+        static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
+        if (mlp_mode == MLP_F16X3) SN_LAUNCH_FINAL(MLP_F16X3, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);            // 72 KiB
+        else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, PACK_FLOATS + 4 * 32 * 64);                        // 64 KiB
         else SN_LAUNCH_FINAL(MLP_VALU, 2 * 64 * 256 + VIEW_W);                                                     // 136 KiB
 #undef SN_LAUNCH_FINAL
         SN_LAUNCH_CHECK("k_final_stage");
