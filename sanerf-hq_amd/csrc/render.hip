@@ -25,6 +25,7 @@
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace sn {
@@ -98,27 +99,40 @@ __device__ __forceinline__ void sample_x01(const RayCommon &rc, const RaySetup &
     for (int k = 0; k < 3; ++k) x01[k] = (p[k] + rc.bound) / den;
 }
 
-// Row indices of the 8 corners of one cell, BRANCH-FREE.  A per-level branch (hashed vs dense) is a
-// basic-block boundary for every level and pins the march to 8 gathers in flight per lane; here both
-// index forms are evaluated from shared partial products (the multipliers and the mask are
-// wave-uniform selects) and one v_cndmask per corner picks the result, so the gathers of all levels
-// can be scheduled together.
+// Byte offsets (from the level's base) of the 8 corners of one cell.
+// KIND: 0 = dense level, 1 = hashed level (compile-time, from the kernel's dense-prefix length K),
+//      -1 = decided at run time by a wave-uniform select (generic instantiation).
+// No per-level branch either way: a branch is a basic-block boundary per level and pins the march
+// to 8 gathers in flight per lane.  The row stride in bytes is folded into the (wave-uniform)
+// multipliers: ((x ^ y*P1 ^ z*P2) & m) * s == ((x*s) ^ (y*P1*s) ^ (z*P2*s)) & (m*s) for s a power of two.
 // Fast-path assumptions checked on the host (levels_fast): hashed levels have a power-of-two size,
 // dense levels index all three dimensions and need no modulo, align_corners = False, linear interp.
-__device__ __forceinline__ void corner_rows(const uint32_t (&cell)[3], uint32_t res, uint32_t size, uint32_t mode,
-                                            uint32_t (&rows)[8]) {
-    const bool hashed = (mode & 1u) != 0u;
-    const uint32_t my = hashed ? 2654435761u : res;            // gridencoder.cu:49 primes / :66-70 strides
-    const uint32_t mz = hashed ? 805459861u : res * res;
-    const uint32_t mask = hashed ? size - 1u : 0xffffffffu;
+template <int KIND, uint32_t STRIDE_BYTES>
+__device__ __forceinline__ void corner_offsets(const uint32_t (&cell)[3], uint32_t res, uint32_t size, uint32_t mode,
+                                               uint32_t (&offs)[8]) {
+    static_assert((STRIDE_BYTES & (STRIDE_BYTES - 1)) == 0, "row stride must be a power of two");
+    const bool hashed = KIND == 1 || (KIND == -1 && (mode & 1u) != 0u);
+    const uint32_t my = (hashed ? 2654435761u : res) * STRIDE_BYTES;          // gridencoder.cu:49 primes / :66-70 strides
+    const uint32_t mz = (hashed ? 805459861u : res * res) * STRIDE_BYTES;
+    const uint32_t mask = hashed ? (size - 1u) * STRIDE_BYTES : 0xffffffffu;
     const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
     const uint32_t x1 = umin(x0 + 1u, res - 1u), y1 = umin(y0 + 1u, res - 1u), z1 = umin(z0 + 1u, res - 1u);
+    const uint32_t X0 = x0 * STRIDE_BYTES, X1 = x1 * STRIDE_BYTES;
     const uint32_t Y0 = y0 * my, Y1 = y1 * my, Z0 = z0 * mz, Z1 = z1 * mz;
 #pragma unroll
     for (uint32_t i = 0; i < 8; ++i) {
-        const uint32_t x = (i & 1u) ? x1 : x0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
-        const uint32_t hx = x ^ Y ^ Z, dn = x + Y + Z;
-        rows[i] = (hashed ? hx : dn) & mask;
+        const uint32_t X = (i & 1u) ? X1 : X0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
+        if constexpr (KIND == 1) offs[i] = (X ^ Y ^ Z) & mask;
+        else if constexpr (KIND == 0) offs[i] = X + Y + Z;
+        else offs[i] = (hashed ? (X ^ Y ^ Z) : (X + Y + Z)) & mask;
+    }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
@@ -143,17 +157,17 @@ __device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t re
 template <typename T, int C>
 struct Corner { float v[C]; };
 
-template <typename T, int C>
+template <typename T, int C, int KIND>
 __device__ __forceinline__ void issue_level(const T *__restrict__ table, const GridLevels &g, int l, const float (&x01)[3],
                                             float (&pos)[3], Corner<T, C> (&cv)[8]) {
     const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
     const T *tab = table + (size_t)g.off[l] * C;
-    uint32_t cell[3], rows[8];
+    uint32_t cell[3], offs[8];
     locate_linear(x01, res, pos, cell);
-    corner_rows(cell, res, size, mode, rows);
+    corner_offsets<KIND, (uint32_t)(C * sizeof(T))>(cell, res, size, mode, offs);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const T *row = reinterpret_cast<const T *>(reinterpret_cast<const char *>(tab) + rows[i] * (uint32_t)(C * sizeof(T)));
+        const T *row = reinterpret_cast<const T *>(reinterpret_cast<const char *>(tab) + offs[i]);
         if constexpr (C == 2 && sizeof(T) == 4) {
             const float2 t = *reinterpret_cast<const float2 *>(row);
             cv[i].v[0] = t.x; cv[i].v[1] = t.y;
@@ -182,19 +196,23 @@ __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<
 }
 
 // Encodes all L levels; `emit(l, acc)` receives each level's C features (zeros when out of range).
-template <typename T, int L, int C, int GROUP, typename Emit>
+// K = number of leading dense levels (levels >= K are hashed); K < 0: level kind decided at run time.
+template <typename T, int L, int C, int GROUP, int K, typename Emit>
 __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit) {
     static_assert(L % GROUP == 0 || GROUP >= L, "GROUP must divide L");
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < 3; ++d) oob |= (x01[d] < 0.0f || x01[d] > 1.0f);
     constexpr int G = GROUP >= L ? L : GROUP;
-#pragma unroll
-    for (int l0 = 0; l0 < L; l0 += G) {
+    static_for<0, L / G>([&](auto grp) {
+        constexpr int l0 = decltype(grp)::value * G;
         float pos[G][3];
         Corner<T, C> cv[G][8];
-#pragma unroll
-        for (int k = 0; k < G; ++k) issue_level<T, C>(table, g, l0 + k, x01, pos[k], cv[k]);
+        static_for<0, G>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            constexpr int KIND = K < 0 ? -1 : ((l0 + k) < K ? 0 : 1);
+            issue_level<T, C, KIND>(table, g, l0 + k, x01, pos[k], cv[k]);
+        });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < G; ++k) {
@@ -205,14 +223,14 @@ __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, cons
             emit(l0 + k, acc);
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
 // all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
-template <typename T, int L, int C, int GROUP = L>
+template <typename T, int L, int C, int K, int GROUP = L>
 __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                               float (&feat)[L * C]) {
-    encode_grouped<T, L, C, GROUP>(table, g, x01, [&](int l, const float (&acc)[C]) {
+    encode_grouped<T, L, C, GROUP, K>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) feat[l * C + c] = acc[c];
     });
@@ -247,6 +265,41 @@ __device__ __forceinline__ uint32_t opaque_zero() {
 // (it cannot prove the buffers read-only next to the kernel's stores) and wrecks occupancy.
 template <int IN> struct PadIn { static constexpr int value = (IN + 3) & ~3; };
 
+// dst[k * OUTP + o] = W[o][k]  (k-major; rows padded to a multiple of 4 outputs)
+template <int IN, int OUT>
+__device__ __forceinline__ void stage_weights_t(float *__restrict__ dst, const float *__restrict__ src) {
+    constexpr int OUTP = PadIn<OUT>::value;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(IN * OUTP); i += blockDim.x) {
+        const uint32_t k = i / OUTP, o = i - k * OUTP;
+        dst[i] = o < (uint32_t)OUT ? src[o * IN + k] : 0.0f;
+    }
+}
+
+// y = act(W x), W k-major in LDS at a wave-uniform address (broadcast ds_read_b128 of 4 adjacent outputs);
+// every output is still ONE k-ascending fmaf chain starting from 0 (the oracle's order), the chains of
+// adjacent outputs just advance together, which lets the compiler use packed fp32 FMAs without shuffles.
+template <int IN, int OUT, int ACT>
+__device__ __forceinline__ void dense_ldsw_t(const float *__restrict__ Wl, const float (&x)[IN], float (&y)[OUT]) {
+    constexpr int OUTP = PadIn<OUT>::value;
+    float acc[OUTP];
+#pragma unroll
+    for (int o = 0; o < OUTP; ++o) acc[o] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) {
+#pragma unroll
+        for (int o4 = 0; o4 < OUTP / 4; ++o4) {
+            const float4 w = *reinterpret_cast<const float4 *>(Wl + k * OUTP + 4 * o4);
+            acc[4 * o4 + 0] = __builtin_fmaf(w.x, x[k], acc[4 * o4 + 0]);
+            acc[4 * o4 + 1] = __builtin_fmaf(w.y, x[k], acc[4 * o4 + 1]);
+            acc[4 * o4 + 2] = __builtin_fmaf(w.z, x[k], acc[4 * o4 + 2]);
+            acc[4 * o4 + 3] = __builtin_fmaf(w.w, x[k], acc[4 * o4 + 3]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) y[o] = (ACT == 1) ? (acc[o] > 0.0f ? acc[o] : 0.0f) : acc[o];
+}
+
+// Tiny-MLP weights in the [out][in_padded] layout (view MLP, evaluated once per ray)
 template <int IN, int OUT>
 __device__ __forceinline__ void stage_weights(float *__restrict__ dst, const float *__restrict__ src) {
     constexpr int INP = PadIn<IN>::value;
@@ -334,12 +387,12 @@ struct PropArgs {
     int32_t *dbg_inds;                    // [N,Tn+1] or NULL
 };
 
-template <typename TT, int L, int C, int HID>
+template <typename TT, int L, int C, int HID, int K>
 __global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
     constexpr int IN = L * C;
-    __shared__ __attribute__((aligned(16))) float lds_w0[HID * PadIn<IN>::value];
-    __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];
-    stage_weights<IN, HID>(lds_w0, a.w0);
+    __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];   // k-major [IN][HID]
+    __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];        // [1][HID]
+    stage_weights_t<IN, HID>(lds_w0, a.w0);
     stage_weights<HID, 1>(lds_w1, a.w1);
     __syncthreads();
     uint32_t n;
@@ -370,10 +423,10 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
         float feat[L * C];
-        encode_levels<TT, L, C>(table, a.g, x01, feat);
+        encode_levels<TT, L, C, K>(table, a.g, x01, feat);
         float h[HID], raw[1];
         const uint32_t oz = opaque_zero();
-        dense_ldsw<IN, HID, 1>(lds_w0 + oz, feat, h);
+        dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
         dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, raw);
         const float sigma = expf_det(raw[0]);                // trunc_exp forward (activation.py:9)
         const float delta = rb_next - rb_prev;
@@ -666,10 +719,10 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
 
 // hash-grid features of one position, split into f16 hi / lo and written to this lane's slab rows
 // (dword l = the level's two features as a half2).
-template <typename T, int L, int GROUP>
+template <typename T, int L, int GROUP, int K>
 __device__ __forceinline__ void encode_levels_split(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                     uint32_t *__restrict__ row_hi, uint32_t *__restrict__ row_lo) {
-    encode_grouped<T, L, 2, GROUP>(table, g, x01, [&](int l, const float (&acc)[2]) {
+    encode_grouped<T, L, 2, GROUP, K>(table, g, x01, [&](int l, const float (&acc)[2]) {
         uint32_t ph, pl;
         split2(acc[0], acc[1], ph, pl);
         row_hi[l] = ph;
@@ -695,10 +748,10 @@ __device__ __forceinline__ void dense_lds(const float *__restrict__ W, const flo
 }
 
 // hash-grid features of one position written to an LDS column fe[k * stride]
-template <typename T, int L, int C, int GROUP>
+template <typename T, int L, int C, int GROUP, int K>
 __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                   float *__restrict__ fe, uint32_t stride) {
-    encode_grouped<T, L, C, GROUP>(table, g, x01, [&](int l, const float (&acc)[C]) {
+    encode_grouped<T, L, C, GROUP, K>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) fe[(l * C + c) * stride] = acc[c];
     });
@@ -706,7 +759,7 @@ __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, c
 
 enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 
-template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE>
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K>
 __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(FinalArgs a) {
     constexpr bool MFMA = MODE != MLP_VALU;
     constexpr int IN = L * C;
@@ -796,18 +849,18 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         float h[NOUT];
         if constexpr (MODE == MLP_F16X3) {
             const uint32_t lane = threadIdx.x & 63u;
-            encode_levels_split<TT, L, 4>(table, a.g, x01, slab_hi + lane * SLAB_STRIDE, slab_lo + lane * SLAB_STRIDE);
+            encode_levels_split<TT, L, 4, K>(table, a.g, x01, slab_hi + lane * SLAB_STRIDE, slab_lo + lane * SLAB_STRIDE);
             __builtin_amdgcn_wave_barrier();
             grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (MODE == MLP_F32) {
-            encode_levels_lds<TT, L, C, 2>(table, a.g, x01, fe, fstride);
+            encode_levels_lds<TT, L, C, 2, K>(table, a.g, x01, fe, fstride);
             // the slab is private to this wave and LDS serves a wave's requests in order
             __builtin_amdgcn_wave_barrier();
             grid_mlp_mfma(lds + opaque_zero(), fe - (threadIdx.x & 63u), h);
             __builtin_amdgcn_wave_barrier();
         } else {
-            encode_levels_lds<TT, L, C, 2>(table, a.g, x01, fe, fstride);
+            encode_levels_lds<TT, L, C, 2, K>(table, a.g, x01, fe, fstride);
             dense_lds<IN, H1, 1>(a.w[0], fe, actB, fstride);
             dense_lds<H1, H2, 1>(a.w[1], actB, fe, fstride);
             dense_lds<H2, NOUT, 0>(a.w[2], fe, actB, fstride);
@@ -925,6 +978,15 @@ static bool levels_fast(const GridLevels &g) {
     return g.align_corners == 0 && g.interp == 0;
 }
 
+// number of leading dense levels if the grid is "dense prefix, hashed tail" (every grid the reference builds is:
+// resolution grows with the level), else -1 (generic run-time level kind)
+static int dense_prefix(const GridLevels &g) {
+    uint32_t k = 0;
+    while (k < g.L && (g.mode[k] & 1u) == 0u) ++k;
+    for (uint32_t l = k; l < g.L; ++l) if ((g.mode[l] & 1u) == 0u) return -1;
+    return (int)k;
+}
+
 static bool mlp_is(const sn_mlp_desc *m, uint32_t nl, const uint32_t *dims) {
     if (m->num_layers != nl || m->activation != 0 || m->skip_mask != 0) return false;
     for (uint32_t l = 0; l <= nl; ++l) if (m->dims[l] != dims[l]) return false;
@@ -985,15 +1047,15 @@ int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_c
 int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
     SN_REQUIRE(out && lds && n >= 3, "debug_occupancy: need 3 slots");
     int v = 0;
-    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_prop_stage<float, 5, 2, 16>, 256, 0));
+    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_prop_stage<float, 5, 2, 16, 3>, 256, 0));
     out[0] = v; lds[0] = 0;
     size_t l1 = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
-    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
-    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3>, 256, l1));
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5>, 256, l1));
     out[1] = v; lds[1] = (int32_t)l1;
     size_t l2 = (size_t)(PACK_FLOATS + 4 * 32 * 64) * sizeof(float);
-    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
-    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F32>, 256, l2));
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F32, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+    SN_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F32, -1>, 256, l2));
     out[2] = v; lds[2] = (int32_t)l2;
     return SN_OK;
 }
@@ -1107,10 +1169,17 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             pa.dbg_inds = io->inds[k + 1] ? io->inds[k + 1] + (size_t)first * (pa.Tn + 1) : nullptr;
             {
                 ProfScope ps(st, PK_PROP0 + (int)k);
-                if (cfg->prop_grid[k].table_dtype == SN_F32)
-                    hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16>), dim3(nblk), dim3(256), 0, st, pa);
-                else
-                    hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16>), dim3(nblk), dim3(256), 0, st, pa);
+                const int K = dense_prefix(gl_prop[k]);
+                const bool h16 = cfg->prop_grid[k].table_dtype != SN_F32;
+#define SN_LAUNCH_PROP(KK)                                                                                         \
+                do {                                                                                               \
+                    if (h16) hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa); \
+                    else hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa);     \
+                } while (0)
+                if (K == 3) SN_LAUNCH_PROP(3);          // prop0: res 16, 27, 46 dense (network.py:135)
+                else if (K == 2) SN_LAUNCH_PROP(2);     // prop1: res 16, 32 dense (network.py:140)
+                else SN_LAUNCH_PROP(-1);
+#undef SN_LAUNCH_PROP
             }
             SN_LAUNCH_CHECK("k_prop_stage");
         }
@@ -1129,24 +1198,27 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
         const bool f16 = cfg->grid.table_dtype == SN_F16;
         ProfScope ps_final(st, PK_FINAL);
-#define SN_LAUNCH_FINAL(MODE_, LDS_FLOATS)                                                                                   \
+#define SN_LAUNCH_FINAL(MODE_, KK, LDS_FLOATS)                                                                                  \
         do {                                                                                                                 \
             const size_t lds_bytes = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
             if (f16) {                                                                                                       \
-                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_>), \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_, KK>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
-                hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+                hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_, KK>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
             } else {                                                                                                         \
-                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_>), \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_, KK>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
-                hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+                hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_, KK>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
             }                                                                                                                \
         } while (0)
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
-        if (mlp_mode == MLP_F16X3) SN_LAUNCH_FINAL(MLP_F16X3, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);            // 72 KiB
-        else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, PACK_FLOATS + 4 * 32 * 64);                        // 64 KiB
-        else SN_LAUNCH_FINAL(MLP_VALU, 2 * 64 * 256 + VIEW_W);                                                     // 136 KiB
+        const int Kmain = dense_prefix(gl_main);
+        if (mlp_mode == MLP_F16X3) {
+            if (Kmain == 5) SN_LAUNCH_FINAL(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
+            else SN_LAUNCH_FINAL(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);
+        } else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, -1, PACK_FLOATS + 4 * 32 * 64);       // 64 KiB
+        else SN_LAUNCH_FINAL(MLP_VALU, -1, 2 * 64 * 256 + VIEW_W);                                      // 136 KiB
 #undef SN_LAUNCH_FINAL
         SN_LAUNCH_CHECK("k_final_stage");
     }
