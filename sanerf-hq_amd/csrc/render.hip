@@ -42,14 +42,25 @@ struct RayCommon {
     float min_near, bound;
     int contract, last_opaque;
     float bg;
+    int xcd_swizzle;
 };
 
+// Workgroup id -> tile id.  The dispatcher places workgroup b on XCD b % 8 (observed, not contractual: used
+// for speed only).  Remapping so that each XCD owns a contiguous range of tile ids keeps neighbouring image
+// tiles -- which share fine-level table lines -- behind the same private L2.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t tile_id(const RayCommon &rc) {
+    const uint32_t b = blockIdx.x;
+    if (!rc.xcd_swizzle) return b;
+    const uint32_t nwg = gridDim.x, xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
+}
+
 // lane -> ray.  Tile mode: block = 16x16 pixels, wave = 8x8.
-__device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t &n) {
+__device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t wg, uint32_t &n) {
     const uint32_t tid = threadIdx.x;
     if (rc.W) {
         const uint32_t tiles_x = (rc.W + 15u) >> 4;
-        const uint32_t by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+        const uint32_t by = wg / tiles_x, bx = wg - by * tiles_x;
         const uint32_t wave = tid >> 6, lane = tid & 63u;
         const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
         const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -57,7 +68,7 @@ __device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t &n) {
         n = ok ? py * rc.W + px : 0u;
         return ok;
     }
-    n = blockIdx.x * 256u + tid;
+    n = wg * 256u + tid;
     const bool ok = n < rc.N;
     if (!ok) n = 0;
     return ok;
@@ -157,13 +168,36 @@ __device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t re
 template <typename T, int C>
 struct Corner { float v[C]; };
 
-template <typename T, int C, int KIND>
+template <typename T, int C, int KIND, bool PAIR>
 __device__ __forceinline__ void issue_level(const T *__restrict__ table, const GridLevels &g, int l, const float (&x01)[3],
                                             float (&pos)[3], Corner<T, C> (&cv)[8]) {
     const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
     const T *tab = table + (size_t)g.off[l] * C;
     uint32_t cell[3], offs[8];
     locate_linear(x01, res, pos, cell);
+    if constexpr (PAIR && KIND == 0 && C == 2 && sizeof(T) == 4) {
+        // Dense level, fp32 rows: (x0, y, z) and (x0+1, y, z) are adjacent in memory, so ONE 16-byte load of two
+        // rows serves both x-corners: 4 gathers per level instead of 8.  At the upper border x1 == x0
+        // (gridencoder.cu:182 clamps) and the reference re-reads row x0; the select below reproduces that, the
+        // extra row that was fetched is ignored (it is inside the table: a hashed level always follows, see
+        // dense_prefix()).  Measured: pays in the proposal stages (VALU/TA-bound, 3 of 5 levels dense), costs in
+        // the final stage (the 8-byte-aligned dwordx4 is slower per request), and an 8-byte load at 4-byte
+        // alignment (fp16 rows) does not return the expected bytes on gfx950 -> fp32 proposal stages only.
+        constexpr uint32_t SB = (uint32_t)(2 * sizeof(T));
+        const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
+        const uint32_t y1 = umin(y0 + 1u, res - 1u), z1 = umin(z0 + 1u, res - 1u);
+        const bool same_x = x0 + 1u > res - 1u;
+        const uint32_t X0 = x0 * SB, Y0 = y0 * (res * SB), Y1 = y1 * (res * SB), Z0 = z0 * (res * res * SB), Z1 = z1 * (res * res * SB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t off = X0 + ((i & 1) ? Y1 : Y0) + ((i & 2) ? Z1 : Z0);
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+            const f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(tab) + off);
+            cv[2 * i].v[0] = t.x; cv[2 * i].v[1] = t.y;
+            cv[2 * i + 1].v[0] = same_x ? t.x : t.z; cv[2 * i + 1].v[1] = same_x ? t.y : t.w;
+        }
+        return;
+    }
     corner_offsets<KIND, (uint32_t)(C * sizeof(T))>(cell, res, size, mode, offs);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -197,7 +231,7 @@ __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<
 
 // Encodes all L levels; `emit(l, acc)` receives each level's C features (zeros when out of range).
 // K = number of leading dense levels (levels >= K are hashed); K < 0: level kind decided at run time.
-template <typename T, int L, int C, int GROUP, int K, typename Emit>
+template <typename T, int L, int C, int GROUP, int K, bool PAIR, typename Emit>
 __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit) {
     static_assert(L % GROUP == 0 || GROUP >= L, "GROUP must divide L");
     bool oob = false;
@@ -211,7 +245,7 @@ __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, cons
         static_for<0, G>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int KIND = K < 0 ? -1 : ((l0 + k) < K ? 0 : 1);
-            issue_level<T, C, KIND>(table, g, l0 + k, x01, pos[k], cv[k]);
+            issue_level<T, C, KIND, PAIR>(table, g, l0 + k, x01, pos[k], cv[k]);
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -227,10 +261,10 @@ __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, cons
 }
 
 // all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
-template <typename T, int L, int C, int K, int GROUP = L>
+template <typename T, int L, int C, int K, bool PAIRX, int GROUP = L>
 __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                               float (&feat)[L * C]) {
-    encode_grouped<T, L, C, GROUP, K>(table, g, x01, [&](int l, const float (&acc)[C]) {
+    encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) feat[l * C + c] = acc[c];
     });
@@ -396,8 +430,9 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
     stage_weights<HID, 1>(lds_w1, a.w1);
     __syncthreads();
     uint32_t n;
-    const bool ok = ray_of_lane(a.rc, n);
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;   // scratch column
+    const uint32_t wg = tile_id(a.rc);
+    const bool ok = ray_of_lane(a.rc, wg, n);
+    const uint32_t r = wg * 256u + threadIdx.x;           // scratch column
     const uint32_t Npad = a.rc.Npad;
     RaySetup rs;
     setup_ray(a.rc, n, rs);
@@ -423,7 +458,7 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
         float feat[L * C];
-        encode_levels<TT, L, C, K>(table, a.g, x01, feat);
+        encode_levels<TT, L, C, K, true>(table, a.g, x01, feat);
         float h[HID], raw[1];
         const uint32_t oz = opaque_zero();
         dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
@@ -722,7 +757,7 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
 template <typename T, int L, int GROUP, int K>
 __device__ __forceinline__ void encode_levels_split(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                     uint32_t *__restrict__ row_hi, uint32_t *__restrict__ row_lo) {
-    encode_grouped<T, L, 2, GROUP, K>(table, g, x01, [&](int l, const float (&acc)[2]) {
+    encode_grouped<T, L, 2, GROUP, K, false>(table, g, x01, [&](int l, const float (&acc)[2]) {
         uint32_t ph, pl;
         split2(acc[0], acc[1], ph, pl);
         row_hi[l] = ph;
@@ -748,10 +783,10 @@ __device__ __forceinline__ void dense_lds(const float *__restrict__ W, const flo
 }
 
 // hash-grid features of one position written to an LDS column fe[k * stride]
-template <typename T, int L, int C, int GROUP, int K>
+template <typename T, int L, int C, int GROUP, int K, bool PAIRX = false>
 __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                   float *__restrict__ fe, uint32_t stride) {
-    encode_grouped<T, L, C, GROUP, K>(table, g, x01, [&](int l, const float (&acc)[C]) {
+    encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) fe[(l * C + c) * stride] = acc[c];
     });
@@ -808,8 +843,9 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     __syncthreads();
 
     uint32_t n;
-    const bool ok = ray_of_lane(a.rc, n);
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t wg = tile_id(a.rc);
+    const bool ok = ray_of_lane(a.rc, wg, n);
+    const uint32_t r = wg * 256u + threadIdx.x;
     const uint32_t Npad = a.rc.Npad;
     RaySetup rs;
     setup_ray(a.rc, n, rs);
@@ -984,6 +1020,7 @@ static int dense_prefix(const GridLevels &g) {
     uint32_t k = 0;
     while (k < g.L && (g.mode[k] & 1u) == 0u) ++k;
     for (uint32_t l = k; l < g.L; ++l) if ((g.mode[l] & 1u) == 0u) return -1;
+    if (k == g.L) return -1;   // the paired x-loads of dense levels rely on a hashed level following the dense prefix
     return (int)k;
 }
 
@@ -1148,6 +1185,10 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         for (int i = 0; i < 6; ++i) rc.aabb[i] = cfg->aabb[i];
         rc.min_near = cfg->min_near; rc.bound = cfg->bound; rc.contract = cfg->contract;
         rc.last_opaque = cfg->last_sample_opaque; rc.bg = cfg->bg_color;
+        {   // SN_RENDER_XCD=0 disables the XCD-aware tile order (A/B switch)
+            const char *xs = getenv("SN_RENDER_XCD");
+            rc.xcd_swizzle = !(xs && xs[0] == '0');
+        }
 
         // scratch carve-up
         float *w_scr[SN_MAX_STAGES] = {nullptr}, *b_scr[SN_MAX_STAGES] = {nullptr};
