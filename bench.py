@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--tables", choices=["f32", "f16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--primary-only", action="store_true", help="skip the extra configurations reported under `also`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,12 +74,6 @@ def main():
     from sanerf_hq_amd import _lib, raymarching as rm, synth
     from sanerf_hq_amd.dist import gather_image, shard_rows
 
-    steps = [128] if args.schedule == "flat128" else [128, 64, 32]
-    params = synthetic_params(steps, seed=0)
-    model = product_model(params, steps, False, dev)
-    tdt = torch.float16 if args.tables == "f16" else torch.float32
-    plan = rm.RenderPlan(model, steps, tdt)
-
     W = args.hw
     H = args.hw * world                      # weak scaling: one hw x hw band per rank
     b, e = shard_rows(H, world, rank)
@@ -86,66 +81,102 @@ def main():
     intr = synth.pinhole_intrinsics(args.hw, W)   # same focal length at every N
     rays_o, rays_d = rm.generate_rays(pose, (intr[0], intr[1], W / 2.0, H / 2.0), H, W, device=dev, row_begin=b, row_end=e)
     n_local = rays_o.shape[0]
-    out = {}
-
-    def step():
-        rm.render_rays(plan, rays_o, rays_d, tile_w=W, out=out)
-        if world > 1:
-            band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
-            return gather_image(band, H, W)
-        return out["image"]
-
-    for _ in range(args.warmup):
-        step()
     lib = _lib.lib()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    lib.sn_rm_profile_enable(1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ms = (C.c_float * 8)()
-    cnt = (C.c_int32 * 8)()
-    _lib.check(lib.sn_rm_profile_read(ms, cnt, 8), "profile_read")
-    lib.sn_rm_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     total_rays = H * W
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_rays / (elapsed / args.steps)
+    models = {}
 
-    # ---- roofline of the dominant kernel (final stage = class 4) on this rank ----
-    s_bytes = 2 if args.tables == "f16" else 4
-    final_ms = ms[4] / max(cnt[4], 1)
-    final_steps = [steps[-1]]
+    def measure(schedule, tables, n_steps, n_warm):
+        """K timed whole-image renders (+ all-gather at N>1) of one configuration; returns the bench numbers."""
+        steps = [128] if schedule == "flat128" else [128, 64, 32]
+        if schedule not in models:
+            params = synthetic_params(steps, seed=0)
+            models[schedule] = (params, product_model(params, steps, False, dev))
+        params, model = models[schedule]
+        plan = rm.RenderPlan(model, steps, torch.float16 if tables == "f16" else torch.float32)
+        out = {}
+
+        def step():
+            rm.render_rays(plan, rays_o, rays_d, tile_w=W, out=out)
+            if world > 1:
+                band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
+                return gather_image(band, H, W)
+            return out["image"]
+
+        for _ in range(n_warm):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        lib.sn_rm_profile_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ms = (C.c_float * 8)()
+        cnt = (C.c_int32 * 8)()
+        _lib.check(lib.sn_rm_profile_read(ms, cnt, 8), "profile_read")
+        lib.sn_rm_profile_enable(0)
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        s_bytes = 2 if tables == "f16" else 4
+        per = lambda i: (ms[i] / cnt[i]) if cnt[i] else None
+        return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=total_rays / (elapsed / n_steps),
+                    ms_per_step=elapsed / n_steps * 1e3, s_bytes=s_bytes, final_ms=per(4), final_launches=int(cnt[4]),
+                    pack_ms=per(0), prop_ms=[per(1), per(2)])
+
+    m = measure(args.schedule, args.tables, args.steps, args.warmup)
+    steps, params, out = m["steps"], m["params"], m["out"]
+    value, ms_per_step, s_bytes, final_ms = m["value"], m["ms_per_step"], m["s_bytes"], m["final_ms"]
+
+    # ---- roofline of the dominant kernel (final stage) on this rank ----
     bytes_final = n_local * (steps[-1] * 16 * 8 * 2 * s_bytes + 44)
     flops_final = n_local * 2 * (steps[-1] * 7168 + 2112)
     achieved = bytes_final / (final_ms * 1e-3)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    if os.path.exists(tpath):   # HBM-side bytes per launch from the rocprofv3 --pmc passes of this same command
+        tj = json.load(open(tpath)).get(f"{args.schedule}_{args.tables}")
+        if tj and tj.get("rays") == n_local:
+            traffic = tj
     roofline = {
         "kernel": "k_final_stage", "bound": "hbm",
         "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-        "avg_kernel_ms": round(final_ms, 4), "launches": int(cnt[4]),
+        "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+        "avg_kernel_ms": round(final_ms, 4), "launches": m["final_launches"],
         "algorithmic_bytes_per_launch": int(bytes_final),
-        "mfma_f32": {"achieved_tflops": round(flops_final / (final_ms * 1e-3) / 1e12, 2), "peak_tflops": MFMA_F32_PEAK / 1e12,
-                     "frac": round(flops_final / (final_ms * 1e-3) / MFMA_F32_PEAK, 4)},
-        "other_kernels_ms": {"pack": round(ms[0] / max(cnt[0], 1), 4),
-                             "prop0": round(ms[1] / max(cnt[1], 1), 4) if cnt[1] else None,
-                             "prop1": round(ms[2] / max(cnt[2], 1), 4) if cnt[2] else None},
+        "note": "achieved = algorithmic gather bytes (SURVEY 8d: every corner fetch counted once, no cache credit) / HIP-event kernel time; "
+                "it can exceed the HBM peak because L1/L2 absorb the re-reads of neighbouring rays (see traffic)",
+        "mlp_on_matrix_cores": {"achieved_tflops": round(flops_final / (final_ms * 1e-3) / 1e12, 2),
+                                "note": "algorithmic fp32-equivalent MLP FLOPs; executed as 3 fp16 MFMA products per fp32 product"},
+        "other_kernels_ms": {"pack": round(m["pack_ms"], 4) if m["pack_ms"] else None,
+                             "prop0": round(m["prop_ms"][0], 4) if m["prop_ms"][0] else None,
+                             "prop1": round(m["prop_ms"][1], 4) if m["prop_ms"][1] else None},
         "whole_path": {"algorithmic_bytes_per_ray": algorithmic_bytes_per_ray(steps, s_bytes),
                        "achieved_GBps": round(value / world * algorithmic_bytes_per_ray(steps, s_bytes) / 1e9, 2),
                        "frac": round(value / world * algorithmic_bytes_per_ray(steps, s_bytes) / HBM_PEAK, 4),
                        "flops_per_ray": flops_per_ray(steps)},
     }
+
+    # ---- other configurations of the same path, measured in the same process (N = 1 only, short) ----
+    also = None
+    if world == 1 and not args.primary_only:
+        also = {}
+        for sch, tb in (("ref", "f32"), ("flat128", "f16"), ("ref", "f16")):
+            if (sch, tb) == (args.schedule, args.tables):
+                continue
+            r = measure(sch, tb, max(3, args.steps // 2), 2)
+            also[f"{sch}_{tb}"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
+                                   "num_steps": r["steps"], "tables": tb,
+                                   "kernel_ms": {"final": round(r["final_ms"], 4),
+                                                 "prop0": round(r["prop_ms"][0], 4) if r["prop_ms"][0] else None,
+                                                 "prop1": round(r["prop_ms"][1], 4) if r["prop_ms"][1] else None}}
+        out = m["out"]
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -171,12 +202,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 tables, positions, interpolation, compositing; the 32-64-64-16 MLP multiplies fp16 hi/lo splits of fp32 operands on the matrix cores with fp32 accumulation (2^-22 per product, RGB within 1e-5 of the fp32 oracle)",
             "config": {"workload": f"BASELINE configs[1]: {W}x{args.hw} rays per GPU ({W}x{H} image), hashgrid L=16 T=2^19 F=2, "
                                    f"32-64-64-16 + 31-32-32-3 MLPs, num_steps={steps} ({args.schedule}), tables {args.tables}, "
                                    "arithmetic fp32, random-init weights, orbit camera",
                        "rays_per_gpu": n_local, "image": [H, W], "schedule": args.schedule,
                        "parallelism": f"ray-tile row bands x{world}" + (" + RCCL all-gather of rgb|depth|wsum" if world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "also": also,
         }
         print(json.dumps(line))
     if world > 1:
