@@ -138,16 +138,18 @@ def main():
     bytes_final = n_local * (steps[-1] * 16 * 8 * 2 * s_bytes + 44)
     flops_final = n_local * 2 * (steps[-1] * 7168 + 2112)
     achieved = bytes_final / (final_ms * 1e-3)
-    traffic = None
+    # HBM-side bytes per launch of the same kernel: from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/latest_traffic.json, regenerated with tools/gpu_pmc_quick.sh); null when no profile matches.
+    traffic = traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-    if os.path.exists(tpath):   # HBM-side bytes per launch from the rocprofv3 --pmc passes of this same command
+    if os.path.exists(tpath):
         tj = json.load(open(tpath)).get(f"{args.schedule}_{args.tables}")
         if tj and tj.get("rays") == n_local:
-            traffic = tj
+            traffic, traffic_detail = tj["hbm_bytes_per_launch"], tj
     roofline = {
         "kernel": "k_final_stage", "bound": "hbm",
         "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_detail": traffic_detail,
         "avg_kernel_ms": round(final_ms, 4), "launches": m["final_launches"],
         "algorithmic_bytes_per_launch": int(bytes_final),
         "note": "achieved = algorithmic gather bytes (SURVEY 8d: every corner fetch counted once, no cache credit) / HIP-event kernel time; "

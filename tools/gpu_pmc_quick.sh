@@ -6,7 +6,7 @@ i=0
 while read -r c; do
   [ -z "$c" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $c --kernel-trace -d $out/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --schedule $sch --tables $tb --no-cpu-baseline > $out/p$i.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $out/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --schedule $sch --tables $tb --no-cpu-baseline --primary-only > $out/p$i.log 2>&1
   echo "== pass $i: $c" >> $out/summary.txt
   python $GRAFT_REPO_ROOT/tools/rocpd_summary.py pmc $out/p$i/pmc_results.db >> $out/summary.txt 2>&1
   rm -rf $out/p$i $out/p$i.log

@@ -10,13 +10,21 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    for key in ("k_final_stage", "k_prop_stage", "k_pack_grid_mlp", "k_grid_forward", "k_grid_backward", "k_composite",
-                "k_generate_rays", "k_sample_pdf", "k_weights"):
+    import re
+    for key in ("k_final_stage", "k_prop_stage", "k_pack_grid_mlp_f16", "k_pack_grid_mlp", "k_grid_forward", "k_grid_backward",
+                "k_composite", "k_generate_rays", "k_sample_pdf", "k_weights"):
         if key in name:
             tag = ""
-            if "Lb1E" in name: tag = "<mfma>"
-            if "Lb0E" in name: tag = "<valu>"
-            if "6__half" in name: tag += "<f16>"
+            if key == "k_final_stage":
+                m = re.search(r"Li32ELi(\d)ELi(n?\d+)E", name)
+                if m:
+                    tag = {"0": "<valu>", "1": "<mfma_f32>", "2": "<mfma_f16x3>"}[m.group(1)]
+            if key == "k_prop_stage":
+                m = re.search(r"Li16ELi(n?\d+)E", name)
+                if m:
+                    tag = {"3": "<prop0,K=3>", "2": "<prop1,K=2>"}.get(m.group(1), "<generic>")
+            if "6__half" in name:
+                tag += "<f16 tables>"
             return key + tag
     return name[:70]
 
