@@ -1106,6 +1106,7 @@ size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32
 
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
     SN_REQUIRE(cfg && io, "render_rays: cfg/io is NULL");
+    if (io->N == 0) return SN_OK;   // empty batch: nothing to launch, pointers may be NULL
     SN_REQUIRE(io->rays_o && io->rays_d && io->image && io->depth && io->weights_sum, "render_rays: rays/outputs must be device pointers");
     const uint32_t S = cfg->num_stages;
     SN_REQUIRE(S >= 1 && S <= SN_MAX_STAGES, "render_rays: num_stages=%u outside 1..%d", S, SN_MAX_STAGES);

@@ -261,6 +261,61 @@ def test_full_size_properties(gpu, orc):
     np.testing.assert_allclose(dep[idx].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
 
 
+def test_row_band_shards_assemble_the_full_image(gpu, orc):
+    """The multi-GPU path (dist.py) renders contiguous 16-row-aligned bands per rank and concatenates them:
+    on one GPU, rendering every rank's band separately must reproduce the single-launch image bit for bit."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.dist import all_shards, render_model_sharded
+    params = synthetic_params([128, 64, 32], seed=29)
+    model = product_model(params, [128, 64, 32], False, gpu)
+    H, W = 200, 120                      # H is not a multiple of 16 * world: ragged last band
+    pose, intr = synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W)
+    with torch.no_grad():
+        full = render_model_sharded(model, pose, intr, H, W)            # no process group: world = 1
+        assert full.shape == (H * W, 5)
+        for world in (2, 4, 8):
+            parts = []
+            for b, e in all_shards(H, world):
+                if e == b:
+                    continue
+                ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu, row_begin=b, row_end=e)
+                o = model.render(ro, rd, staged=False, perturb=False, tile_w=W)
+                parts.append(torch.cat([o["image"], o["depth"].unsqueeze(-1), o["weights_sum"].unsqueeze(-1)], -1))
+            assert torch.equal(torch.cat(parts, 0), full), f"world={world}"
+
+
+def test_edge_cases(gpu, orc):
+    """Empty ray batch, batches that are not a multiple of the 256-lane workgroup, rays that miss the scene box."""
+    from sanerf_hq_amd import raymarching as rm
+    params = synthetic_params([128, 64, 32], seed=31)
+    model = product_model(params, [128, 64, 32], False, gpu)
+    plan = rm.RenderPlan(model, [128, 64, 32])
+    out = rm.render_rays(plan, torch.empty(0, 3, device=gpu), torch.empty(0, 3, device=gpu), out={})
+    assert out["image"].shape == (0, 3)
+    _, _, ro, rd = camera_rays(orc, 24, 24)
+    cfg = oracle_cfg(orc, params, [128, 64, 32])
+    for n in (1, 63, 65, 257, 576):
+        got = rm.render_rays(plan, T(ro[:n], gpu), T(rd[:n], gpu), out={}, want=("inds",))
+        want = orc.render(cfg, ro[:n], rd[:n], debug=True)
+        assert np.array_equal(got["inds2"].cpu().numpy(), want["inds2"])
+        np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+    # a small scene box that many rays miss: near = far = 1e9 (renderer.py:133-135) -> the reference's arithmetic
+    # degenerates to weights_sum = 0 and image = sigmoid(view_mlp(0)) + bg; oracle and kernel must agree
+    model.aabb_infer.copy_(torch.tensor([-0.2, -0.2, -0.2, 0.2, 0.2, 0.2], device=gpu))
+    plan2 = rm.RenderPlan(model, [128, 64, 32])
+    for i, v in enumerate([-0.2] * 3 + [0.2] * 3):
+        cfg.aabb[i] = v
+    got = rm.render_rays(plan2, T(ro, gpu), T(rd, gpu), out={})
+    want = orc.render(cfg, ro, rd)
+    miss = want["weights_sum"] == 0
+    assert miss.sum() > 0 and (~miss).sum() > 0, "fixture must contain both hits and misses"
+    np.testing.assert_allclose(got["weights_sum"].cpu().numpy(), want["weights_sum"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+    gd, wd = got["depth"].cpu().numpy(), want["depth"]
+    assert np.array_equal(np.isnan(gd), np.isnan(wd))
+    np.testing.assert_allclose(gd[~np.isnan(wd)], wd[~np.isnan(wd)], rtol=1e-5, atol=1e-5)
+
+
 def test_unsupported_configurations_fail_loudly(gpu, orc):
     from sanerf_hq_amd import raymarching as rm
     params = synthetic_params([128, 64, 32], seed=19)

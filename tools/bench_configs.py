@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations (not the contract bench line; numbers go to DESIGN.md).
+  C3: 400x400 rays + 256-d SAM-feature head (feature_container path), reference schedule [128,64,32]
+  C5: mask-field training step, 4096 rays: fwd + bwd of m_grid + mask_mlp under the mask NLL, radiance field frozen
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+from helpers import make_opt, synthetic_params  # noqa: E402
+from sanerf_hq_amd import raymarching as rm, synth  # noqa: E402
+from sanerf_hq_amd.nerf import NeRFNetwork  # noqa: E402
+
+
+def timeit(fn, warm=3, iters=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def build(heads_sam, heads_mask, dev):
+    params = synthetic_params([128, 64, 32], heads=True, seed=1)
+    opt = make_opt(with_sam=heads_sam, with_mask=heads_mask)
+    model = NeRFNetwork(opt)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    model.load_state_dict(sd, strict=False)
+    return model.to(dev)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = {}
+    # ---- C3 ----
+    model = build(True, False, dev).eval()
+    H = W = 400
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
+
+    def c3():
+        with torch.no_grad():
+            return model.render(ro, rd, staged=False, perturb=False, return_feats=1, H=H, W=W, tile_w=W)
+    t = timeit(c3)
+    with torch.no_grad():
+        t_rgb = timeit(lambda: rm.render_rays(model._get_plan(), ro, rd, tile_w=W))
+    out["C3_sam_head_400x400"] = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
+    del model
+    torch.cuda.empty_cache()
+    # ---- C5 ----
+    model = build(False, True, dev).train()
+    for n_, p in model.named_parameters():
+        p.requires_grad_(n_.startswith("m_grid") or n_.startswith("mask_mlp"))
+    H = W = 512
+    N = 4096
+    roF, rdF = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
+    pix = torch.from_numpy((synth.hash_u01(N, 99) * (H * W)).astype(np.int64)).to(dev)
+    ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
+    labels = torch.from_numpy((synth.hash_u01(N, 100) < 0.5).astype(np.int64)).to(dev)
+    optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
+
+    def fwd_bwd():
+        optim.zero_grad(set_to_none=True)
+        o = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=False, return_mask=1)
+        pm = torch.softmax(o["instance_mask_logits"], dim=-1).clamp(min=1e-6, max=1 - 1e-6)
+        loss = (-torch.log(torch.gather(pm, -1, labels[..., None]))).mean()
+        loss.backward()
+        return loss
+
+    def step():
+        fwd_bwd()
+        optim.step()
+    t_fb = timeit(fwd_bwd)
+    t_step = timeit(step)
+    out["C5_mask_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_step * 1e3, 3),
+                                               "rays_per_s_fwd_bwd": round(N / t_fb, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
