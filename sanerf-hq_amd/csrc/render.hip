@@ -260,6 +260,41 @@ __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, cons
     });
 }
 
+// ---- software-pipelined form of encode_grouped ------------------------------------------------
+// issue_group<GRP> starts the GROUP*8 gathers of level group GRP; blend_group<GRP> consumes them.
+// The final stage uses the pair to keep the FIRST group of sample j+1 in flight across the
+// matrix-core phase of sample j (the compiler never hoists loads over the loop back-edge).
+template <typename T, int C, int G>
+struct GroupRegs {
+    float pos[G][3];
+    Corner<T, C> cv[G][8];
+    bool oob;
+};
+
+template <typename T, int C, int G, int K, int GRP>
+__device__ __forceinline__ void issue_group(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
+                                            GroupRegs<T, C, G> &r) {
+    r.oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+    static_for<0, G>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int l = GRP * G + k;
+        constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
+        issue_level<T, C, KIND, false>(table, g, l, x01, r.pos[k], r.cv[k]);
+    });
+}
+
+template <typename T, int C, int G, int GRP, typename Emit>
+__device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit emit) {
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        float acc[C];
+        blend_level<T, C>(r.pos[k], r.cv[k], acc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = r.oob ? 0.0f : acc[c];
+        emit(GRP * G + k, acc);
+    }
+}
+
 // all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
 template <typename T, int L, int C, int K, bool PAIRX, int GROUP = L>
 __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
@@ -876,16 +911,53 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     float bprev = bin_at(0);
     float rb_prev = real_bin(rs, bprev);
     if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
+    // software pipeline (MLP_F16X3): group 0 of sample j+1 is issued before the matrix-core phase of sample j
+    constexpr int PG = 4;                                   // levels per gather group
+    GroupRegs<TT, 2, PG> g0;
+    float bnext_n = bin_at(1);
+    float rb_next_n = real_bin(rs, bnext_n);
+    float tmid_n = (rb_next_n + rb_prev) / 2.0f;
+    float p_n[3], x01_n[3];
+    sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+    if constexpr (MODE == MLP_F16X3) {
+        issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (uint32_t j = 0; j < T; ++j) {
-        const float bnext = bin_at(j + 1);
-        const float rb_next = real_bin(rs, bnext);
-        const float tmid = (rb_next + rb_prev) / 2.0f;
-        float p[3], x01[3];
-        sample_x01(a.rc, rs, tmid, p, x01);
+        const float bnext = bnext_n;
+        const float rb_next = rb_next_n;
+        const float tmid = tmid_n;
+        float p[3] = {p_n[0], p_n[1], p_n[2]}, x01[3] = {x01_n[0], x01_n[1], x01_n[2]};
         float h[NOUT];
         if constexpr (MODE == MLP_F16X3) {
             const uint32_t lane = threadIdx.x & 63u;
-            encode_levels_split<TT, L, 4, K>(table, a.g, x01, slab_hi + lane * SLAB_STRIDE, slab_lo + lane * SLAB_STRIDE);
+            uint32_t *row_hi = slab_hi + lane * SLAB_STRIDE, *row_lo = slab_lo + lane * SLAB_STRIDE;
+            auto emit = [&](int l, const float (&acc)[2]) {
+                uint32_t ph, pl;
+                split2(acc[0], acc[1], ph, pl);
+                row_hi[l] = ph;
+                row_lo[l] = pl;
+            };
+            blend_group<TT, 2, PG, 0>(g0, emit);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<1, L / PG>([&](auto gg) {
+                constexpr int GRP = decltype(gg)::value;
+                GroupRegs<TT, 2, PG> gr;
+                issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr);
+                __builtin_amdgcn_sched_barrier(0);
+                blend_group<TT, 2, PG, GRP>(gr, emit);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            {   // geometry of the next sample (the last iteration re-issues its own sample: in bounds, unused)
+                const uint32_t jn = j + 2u <= T ? j + 2u : T;
+                bnext_n = bin_at(jn);
+                rb_next_n = real_bin(rs, bnext_n);
+                const float rbp = j + 2u <= T ? rb_next : rb_prev;
+                tmid_n = (rb_next_n + rbp) / 2.0f;
+                sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+                issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_wave_barrier();
             grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
             __builtin_amdgcn_wave_barrier();
@@ -926,6 +998,13 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 for (int c = 0; c < GEO; ++c) q[c] = h[1 + c]; }
         }
         rb_prev = rb_next;
+        if constexpr (MODE != MLP_F16X3) {   // un-pipelined modes: geometry of the next sample
+            const uint32_t jn = j + 2u <= T ? j + 2u : T;
+            bnext_n = bin_at(jn);
+            rb_next_n = real_bin(rs, bnext_n);
+            tmid_n = (rb_next_n + (j + 2u <= T ? rb_next : rb_prev)) / 2.0f;
+            sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+        }
     }
 
     // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
