@@ -127,15 +127,25 @@ __device__ __forceinline__ void corner_offsets(const uint32_t (&cell)[3], uint32
     const uint32_t mz = (hashed ? 805459861u : res * res) * STRIDE_BYTES;
     const uint32_t mask = hashed ? (size - 1u) * STRIDE_BYTES : 0xffffffffu;
     const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
-    const uint32_t x1 = umin(x0 + 1u, res - 1u), y1 = umin(y0 + 1u, res - 1u), z1 = umin(z0 + 1u, res - 1u);
-    const uint32_t X0 = x0 * STRIDE_BYTES, X1 = x1 * STRIDE_BYTES;
-    const uint32_t Y0 = y0 * my, Y1 = y1 * my, Z0 = z0 * mz, Z1 = z1 * mz;
+    const uint32_t top = res - 1u;
+    // the +1 neighbour is clamped to res-1 (gridencoder.cu:182): its term is the base term plus one multiplier,
+    // or the base term itself at the border -- an add and a select instead of a second quarter-rate v_mul_lo_u32
+    const uint32_t X0 = x0 * STRIDE_BYTES, Y0 = y0 * my, Z0 = z0 * mz;
+    const uint32_t X1 = x0 < top ? X0 + STRIDE_BYTES : X0;
+    const uint32_t Y1 = y0 < top ? Y0 + my : Y0;
+    const uint32_t Z1 = z0 < top ? Z0 + mz : Z0;
+    if constexpr (KIND == 1) {
+        // (X ^ Y ^ Z) & m == (X & m) ^ (Y & m) ^ (Z & m): masking the 6 partial terms replaces 8 per-corner ANDs
+        const uint32_t X0m = X0 & mask, X1m = X1 & mask, Y0m = Y0 & mask, Y1m = Y1 & mask, Z0m = Z0 & mask, Z1m = Z1 & mask;
 #pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) {
-        const uint32_t X = (i & 1u) ? X1 : X0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
-        if constexpr (KIND == 1) offs[i] = (X ^ Y ^ Z) & mask;
-        else if constexpr (KIND == 0) offs[i] = X + Y + Z;
-        else offs[i] = (hashed ? (X ^ Y ^ Z) : (X + Y + Z)) & mask;
+        for (uint32_t i = 0; i < 8; ++i) offs[i] = ((i & 1u) ? X1m : X0m) ^ ((i & 2u) ? Y1m : Y0m) ^ ((i & 4u) ? Z1m : Z0m);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t X = (i & 1u) ? X1 : X0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
+            if constexpr (KIND == 0) offs[i] = X + Y + Z;
+            else offs[i] = (hashed ? (X ^ Y ^ Z) : (X + Y + Z)) & mask;
+        }
     }
 }
 
@@ -153,9 +163,8 @@ __device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t re
     for (int d = 0; d < 3; ++d) {
         float p = __builtin_fmaf(x01[d], (float)res, -0.5f);
         p = fminf(fmaxf(p, 0.0f), (float)(res - 1u));
-        const float f = floorf(p);
-        cell[d] = (uint32_t)f;
-        pos[d] = p - f;
+        cell[d] = (uint32_t)p;                     // p >= 0: truncation == floor (one v_cvt_u32_f32)
+        pos[d] = __builtin_amdgcn_fractf(p);       // p - floor(p), exact for p >= 0 (one v_fract_f32)
     }
 }
 
