@@ -240,8 +240,11 @@ __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<
 
 // Encodes all L levels; `emit(l, acc)` receives each level's C features (zeros when out of range).
 // K = number of leading dense levels (levels >= K are hashed); K < 0: level kind decided at run time.
+// Returns true for lanes whose coordinate is outside [0,1] (gridencoder.cu:105-130 writes zeros for them): the
+// caller zeroes those lanes' features on a wave-uniform, practically never taken branch instead of paying a
+// select per level (positions are contracted into [0,1] on this path).
 template <typename T, int L, int C, int GROUP, int K, bool PAIR, typename Emit>
-__device__ __forceinline__ void encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit) {
+__device__ __forceinline__ bool encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit) {
     static_assert(L % GROUP == 0 || GROUP >= L, "GROUP must divide L");
     bool oob = false;
 #pragma unroll
@@ -261,12 +264,11 @@ __device__ __forceinline__ void encode_grouped(const T *__restrict__ table, cons
         for (int k = 0; k < G; ++k) {
             float acc[C];
             blend_level<T, C>(pos[k], cv[k], acc);
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = oob ? 0.0f : acc[c];
             emit(l0 + k, acc);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
+    return oob;
 }
 
 // ---- software-pipelined form of encode_grouped ------------------------------------------------
@@ -283,7 +285,7 @@ struct GroupRegs {
 template <typename T, int C, int G, int K, int GRP>
 __device__ __forceinline__ void issue_group(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                             GroupRegs<T, C, G> &r) {
-    r.oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+    r.oob = false;   // out-of-range lanes are fixed up by the caller on a wave-uniform rare path
     static_for<0, G>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         constexpr int l = GRP * G + k;
@@ -298,8 +300,6 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
     for (int k = 0; k < G; ++k) {
         float acc[C];
         blend_level<T, C>(r.pos[k], r.cv[k], acc);
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = r.oob ? 0.0f : acc[c];
         emit(GRP * G + k, acc);
     }
 }
@@ -308,10 +308,13 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
 template <typename T, int L, int C, int K, bool PAIRX, int GROUP = L>
 __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                               float (&feat)[L * C]) {
-    encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
+    const bool oob = encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) feat[l * C + c] = acc[c];
     });
+    // register variant (proposal stages): L*C unconditional selects; a branch here costs more in scheduling than it saves
+#pragma unroll
+    for (int i = 0; i < L * C; ++i) feat[i] = oob ? 0.0f : feat[i];
 }
 
 // y = act(W x), W [OUT][IN] row-major at a wave-uniform address (SGPR / scalar-cache loads);
@@ -689,7 +692,8 @@ constexpr int SLAB_STRIDE = 20;                        // dwords per sample row 
 
 __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t &lo) {
     const half2_t h = {(_Float16)a, (_Float16)b};
-    const half2_t l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    // x - hi is exact in fp32 (hi is x rounded to 11 bits), so the single-rounding fma equals the subtraction
+    const half2_t l = {(_Float16)__builtin_fmaf((float)h[0], -1.0f, a), (_Float16)__builtin_fmaf((float)h[1], -1.0f, b)};
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
 }
@@ -801,12 +805,15 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
 template <typename T, int L, int GROUP, int K>
 __device__ __forceinline__ void encode_levels_split(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                     uint32_t *__restrict__ row_hi, uint32_t *__restrict__ row_lo) {
-    encode_grouped<T, L, 2, GROUP, K, false>(table, g, x01, [&](int l, const float (&acc)[2]) {
+    const bool oob = encode_grouped<T, L, 2, GROUP, K, false>(table, g, x01, [&](int l, const float (&acc)[2]) {
         uint32_t ph, pl;
         split2(acc[0], acc[1], ph, pl);
         row_hi[l] = ph;
         row_lo[l] = pl;
     });
+    if (__builtin_expect(__any(oob), 0)) {
+        if (oob) for (int l = 0; l < L; ++l) { row_hi[l] = 0u; row_lo[l] = 0u; }
+    }
 }
 
 // Scalar-pipe fallback of the same MLP (SN_RENDER_MLP=valu): activations live in per-thread LDS
@@ -830,10 +837,13 @@ __device__ __forceinline__ void dense_lds(const float *__restrict__ W, const flo
 template <typename T, int L, int C, int GROUP, int K, bool PAIRX = false>
 __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
                                                   float *__restrict__ fe, uint32_t stride) {
-    encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
+    const bool oob = encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) fe[(l * C + c) * stride] = acc[c];
     });
+    if (__builtin_expect(__any(oob), 0)) {
+        if (oob) for (int i = 0; i < L * C; ++i) fe[i * stride] = 0.0f;
+    }
 }
 
 enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
@@ -957,6 +967,12 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 blend_group<TT, 2, PG, GRP>(gr, emit);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            {
+                const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+                if (__builtin_expect(__any(oob), 0)) {      // gridencoder.cu:105-130: zeros outside [0,1]
+                    if (oob) for (int l = 0; l < L; ++l) { row_hi[l] = 0u; row_lo[l] = 0u; }
+                }
+            }
             {   // geometry of the next sample (the last iteration re-issues its own sample: in bounds, unused)
                 const uint32_t jn = j + 2u <= T ? j + 2u : T;
                 bnext_n = bin_at(jn);
