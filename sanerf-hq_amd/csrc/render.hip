@@ -43,6 +43,7 @@ struct RayCommon {
     int contract, last_opaque;
     float bg;
     int xcd_swizzle;
+    float inv_den;     // 1 / (2*bound) when that is a power of two (exact scaling), else 0
 };
 
 // Workgroup id -> tile id.  The dispatcher places workgroup b on XCD b % 8 (observed, not contractual: used
@@ -106,8 +107,13 @@ __device__ __forceinline__ void sample_x01(const RayCommon &rc, const RaySetup &
     for (int k = 0; k < 3; ++k) { const float m = rs.d[k] * tmid; p[k] = rs.o[k] + m; }
     if (rc.contract) contract3(p[0], p[1], p[2]);
     const float den = 2.0f * rc.bound;
+    if (rc.inv_den != 0.0f) {   // 2*bound is a power of two (bound = 2 when contracted): x / den == x * (1/den) exactly
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x01[k] = (p[k] + rc.bound) / den;
+        for (int k = 0; k < 3; ++k) x01[k] = (p[k] + rc.bound) * rc.inv_den;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x01[k] = (p[k] + rc.bound) / den;
+    }
 }
 
 // Byte offsets (from the level's base) of the 8 corners of one cell.
@@ -1290,6 +1296,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         for (int i = 0; i < 6; ++i) rc.aabb[i] = cfg->aabb[i];
         rc.min_near = cfg->min_near; rc.bound = cfg->bound; rc.contract = cfg->contract;
         rc.last_opaque = cfg->last_sample_opaque; rc.bg = cfg->bg_color;
+        {
+            int e = 0;
+            const float m = frexpf(2.0f * cfg->bound, &e);
+            rc.inv_den = (m == 0.5f && e > -100 && e < 100) ? 1.0f / (2.0f * cfg->bound) : 0.0f;
+        }
         {   // SN_RENDER_XCD=0 disables the XCD-aware tile order (A/B switch)
             const char *xs = getenv("SN_RENDER_XCD");
             rc.xcd_swizzle = !(xs && xs[0] == '0');
