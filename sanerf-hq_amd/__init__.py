@@ -3,6 +3,7 @@
 Layout
   csrc/            hand-written HIP kernels + the C ABI (libsanerf_hip.so, include/sanerf_hip.h)
   _lib.py          ctypes binding (the only native boundary; no CPU fallback)
+  ops.py          grid / SH / frequency encoders (autograd Functions + modules) over the C ABI
   gridencoder/ shencoder/ freqencoder/ raymarching/ encoding.py activation.py
                    the reference's operator modules, same names and call signatures
   nerf/            NeRFRenderer / NeRFNetwork / get_rays with the reference's contracts

@@ -1,200 +1,2 @@
-"""Multiresolution hash / tiled grid encoder on MI355X.
-
-Operator surface of the reference's gridencoder/grid.py (`grid_encode`, `GridEncoder`
-with `.embeddings`, `.offsets`, `.output_dim`, `grad_total_variation`,
-`grad_weight_decay`; state_dict keys `embeddings`, `offsets`), implemented over the C ABI
-of libsanerf_hip.so instead of the reference's pybind/CUDA `_gridencoder` module.
-
-Differences a caller can observe (all in the reference's favour-neutral direction):
-  * the kernel writes [B, L*C] directly, so the extra permute copy of grid.py:63 is gone;
-  * the per-level table (resolution, size, dense/hash) is computed once on the host from
-    the offsets instead of per thread on the device (gridencoder.cu:132-133);
-  * kernels run on torch's current stream, not the legacy default stream.
-"""
-from __future__ import annotations
-
-import ctypes as C
-from typing import Tuple
-
-import numpy as np
-import torch
-import torch.nn as nn
-from torch.autograd import Function
-
-from .. import _lib
-
-_gridtype_to_id = {"hash": 0, "tiled": 1}
-_interp_to_id = {"linear": 0, "smoothstep": 1}
-
-def _host_offsets(offsets: torch.Tensor) -> Tuple[int, ...]:
-    """Offsets as host ints.  The copy is memoised ON the tensor object (with its version counter),
-    so a device-resident buffer costs one device->host sync, once; a memo keyed by address would be
-    unsafe because the allocator recycles addresses."""
-    memo = getattr(offsets, "_sn_host_offsets", None)
-    if memo is not None and memo[0] == offsets._version:
-        return memo[1]
-    if offsets.dtype != torch.int32:
-        raise RuntimeError("offsets must be an int tensor")               # gridencoder.cu:17
-    host = tuple(int(v) for v in offsets.detach().cpu().tolist())
-    try:
-        offsets._sn_host_offsets = (offsets._version, host)
-    except AttributeError:
-        pass
-    return host
-
-
-def _table_dtype(embeddings: torch.Tensor) -> int:
-    if embeddings.dtype == torch.float32:
-        return _lib.SN_F32
-    if embeddings.dtype == torch.float16:
-        return _lib.SN_F16
-    raise RuntimeError("embeddings must be a floating tensor (float32 or float16)")
-
-
-class _grid_encode(Function):
-    """forward/backward contract of gridencoder/grid.py:24-95."""
-
-    @staticmethod
-    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0, align_corners=False, interpolation=0, max_level=None):
-        inputs = inputs.contiguous()
-        if inputs.dtype != torch.float32:
-            inputs = inputs.float()
-        B, D = inputs.shape
-        L = offsets.shape[0] - 1
-        Cc = embeddings.shape[1]
-        S = float(np.float32(np.log2(per_level_scale)))
-        H = int(base_resolution)
-        max_level = L if max_level is None else min(max_level, L)
-        table = embeddings
-        if torch.is_autocast_enabled() and Cc % 2 == 0:        # grid.py:43-46
-            table = embeddings.to(torch.half)
-        table = table.contiguous()
-        offs = _host_offsets(offsets)
-        if offs[-1] != embeddings.shape[0]:
-            raise RuntimeError(f"offsets end at row {offs[-1]} but embeddings has {embeddings.shape[0]} rows")
-        out = torch.empty(B, L * Cc, device=inputs.device, dtype=torch.float32)
-        if max_level < L:
-            out.zero_()
-        dy_dx = None
-        if calc_grad_inputs:
-            dy_dx = torch.empty(B, L * D * Cc, device=inputs.device, dtype=torch.float32)
-            if max_level < L:
-                dy_dx.zero_()
-        lib = _lib.lib()
-        _lib.check(lib.sn_grid_encode_forward(
-            _lib.dev(inputs, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table), _lib.host_i32(offs),
-            _lib.dev(out, "outputs"), B, D, Cc, L, max_level, S, H, _lib.dev(dy_dx, "dy_dx"),
-            gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC, _lib.stream()), "grid_encode_forward")
-        ctx.save_for_backward(inputs, table, dy_dx)
-        ctx.meta = (offs, B, D, Cc, L, S, H, gridtype, interpolation, max_level, bool(align_corners), embeddings.dtype)
-        return out if table.dtype == torch.float32 else out.to(table.dtype)
-
-    @staticmethod
-    def backward(ctx, grad):
-        inputs, table, dy_dx = ctx.saved_tensors
-        offs, B, D, Cc, L, S, H, gridtype, interpolation, max_level, align_corners, emb_dtype = ctx.meta
-        grad = grad.contiguous().float()
-        grad_embeddings = torch.zeros(table.shape, device=table.device, dtype=torch.float32)   # grid.py:83
-        grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
-        lib = _lib.lib()
-        _lib.check(lib.sn_grid_encode_backward(
-            _lib.dev(grad, "grad"), _lib.dev(inputs, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table),
-            _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"), B, D, Cc, L, max_level, S, H,
-            _lib.dev(dy_dx, "dy_dx"), _lib.dev(grad_inputs, "grad_inputs"),
-            gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC, _lib.stream()), "grid_encode_backward")
-        return grad_inputs, grad_embeddings.to(emb_dtype), None, None, None, None, None, None, None, None
-
-
-grid_encode = _grid_encode.apply
-
-
-class GridEncoder(nn.Module):
-    """Same constructor, attributes and state_dict keys as gridencoder/grid.py:102-204."""
-
-    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
-                 log2_hashmap_size=19, desired_resolution=None, gridtype="hash", align_corners=False,
-                 interpolation="linear"):
-        super().__init__()
-        if desired_resolution is not None:   # grid.py:107-108
-            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-        self.input_dim = input_dim
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
-        self.output_dim = num_levels * level_dim
-        self.gridtype = gridtype
-        self.gridtype_id = _gridtype_to_id[gridtype]
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
-        self.align_corners = align_corners
-
-        # rows per level: min(2^log2T, res^D) rounded up to a multiple of 8 (grid.py:121-136)
-        self.max_params = 2 ** log2_hashmap_size
-        sizes = []
-        for level in range(num_levels):
-            res = int(np.ceil(base_resolution * per_level_scale ** level))
-            rows = min(self.max_params, res ** input_dim)
-            sizes.append(int(np.ceil(rows / 8) * 8))
-        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-        self.register_buffer("offsets", torch.from_numpy(starts))
-        self.n_params = int(starts[-1]) * level_dim
-        self.embeddings = nn.Parameter(torch.empty(int(starts[-1]), level_dim))
-        self.reset_parameters()
-
-    def reset_parameters(self):
-        self.embeddings.data.uniform_(-1e-4, 1e-4)   # grid.py:144-146
-
-    def __repr__(self):
-        top = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> {top} per_level_scale={self.per_level_scale:.4f} "
-                f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners} "
-                f"interpolation={self.interpolation}")
-
-    def forward(self, inputs, bound=1, max_level=None):
-        inputs = (inputs + bound) / (2 * bound)   # [-bound, bound] -> [0, 1] (grid.py:156)
-        lead = list(inputs.shape[:-1])
-        flat = inputs.view(-1, self.input_dim)
-        out = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                          flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
-        return out.view(lead + [self.output_dim])
-
-    @torch.no_grad()
-    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
-        """In-place TV-regulariser gradient on .embeddings.grad (grid.py:170-191)."""
-        if self.embeddings.grad is None:
-            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
-        if inputs is None:
-            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
-        else:
-            inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
-            B = inputs.shape[0]
-        inputs = inputs.contiguous().float()
-        S = float(np.float32(np.log2(self.per_level_scale)))
-        emb = self.embeddings.detach().float().contiguous()
-        grad = self.embeddings.grad
-        g32 = grad if grad.dtype == torch.float32 and grad.is_contiguous() else grad.float().contiguous()
-        _lib.check(_lib.lib().sn_grad_total_variation(
-            _lib.dev(inputs, "inputs"), _lib.dev(emb, "embeddings"), _lib.dev(g32, "grad"),
-            _lib.host_i32(_host_offsets(self.offsets)), float(weight), B, self.input_dim, self.level_dim,
-            self.num_levels, S, int(self.base_resolution), self.gridtype_id, int(self.align_corners), _lib.stream()),
-            "grad_total_variation")
-        if g32 is not grad:
-            grad.copy_(g32)
-
-    @torch.no_grad()
-    def grad_weight_decay(self, weight=0.1):
-        """Level-wise mean weight decay added to .embeddings.grad (grid.py:193-204)."""
-        if self.embeddings.grad is None:
-            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
-        emb = self.embeddings.detach().float().contiguous()
-        grad = self.embeddings.grad
-        g32 = grad if grad.dtype == torch.float32 and grad.is_contiguous() else grad.float().contiguous()
-        _lib.check(_lib.lib().sn_grad_weight_decay(
-            _lib.dev(emb, "embeddings"), _lib.dev(g32, "grad"), _lib.host_i32(_host_offsets(self.offsets)),
-            float(weight), emb.shape[0], emb.shape[1], self.num_levels, _lib.stream()), "grad_weight_decay")
-        if g32 is not grad:
-            grad.copy_(g32)
+"""Module path of the reference (gridencoder/grid.py); the implementation lives in sanerf_hq_amd.ops."""
+from ..ops import GridEncoder, _grid_encode, _host_offsets, grid_encode  # noqa: F401
