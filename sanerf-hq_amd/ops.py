@@ -55,6 +55,30 @@ def _table_dtype(embeddings: torch.Tensor) -> int:
     raise RuntimeError("embeddings must be a floating tensor (float32 or float16)")
 
 
+# Gradient scatter strategy of the grid encoder: "auto" uses the sort-based kernel (no atomics per corner,
+# grid_sorted.hip) once the scatter is large enough to amortise the sort, "atomic" / "sorted" force one path.
+GRID_BACKWARD_MODE = "auto"
+_SORTED_MIN_CONTRIBUTIONS = 1 << 19
+_sorted_ws = {}
+
+
+def _use_sorted_backward(B: int, D: int, max_level: int, dy_dx) -> bool:
+    if GRID_BACKWARD_MODE == "atomic" or dy_dx is not None or D not in (2, 3) or B >= (1 << 24):
+        return False
+    n = B * max_level * (1 << D)
+    if n == 0 or n >= (1 << 31):
+        return False
+    return GRID_BACKWARD_MODE == "sorted" or n >= _SORTED_MIN_CONTRIBUTIONS
+
+
+def _sorted_workspace(nbytes: int, device) -> torch.Tensor:
+    ws = _sorted_ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _sorted_ws[device] = ws
+    return ws
+
+
 class _grid_encode(Function):
     """forward/backward contract of gridencoder/grid.py:24-95."""
 
@@ -102,6 +126,14 @@ class _grid_encode(Function):
         grad_embeddings = torch.zeros(table.shape, device=table.device, dtype=torch.float32)   # grid.py:83
         grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
         lib = _lib.lib()
+        if _use_sorted_backward(B, D, max_level, dy_dx):
+            need = int(lib.sn_grid_backward_sorted_workspace_bytes(B, D, max_level))
+            ws = _sorted_workspace(need, table.device)
+            _lib.check(lib.sn_grid_encode_backward_sorted(
+                _lib.dev(grad, "grad"), _lib.dev(inputs, "inputs"), _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"),
+                B, D, Cc, L, max_level, S, H, gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC,
+                ws.data_ptr(), ws.numel(), _lib.stream()), "grid_encode_backward_sorted")
+            return None, grad_embeddings.to(emb_dtype), None, None, None, None, None, None, None, None
         _lib.check(lib.sn_grid_encode_backward(
             _lib.dev(grad, "grad"), _lib.dev(inputs, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table),
             _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"), B, D, Cc, L, max_level, S, H,
