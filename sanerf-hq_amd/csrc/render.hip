@@ -136,7 +136,10 @@ __device__ __forceinline__ void corner_offsets(const uint32_t (&cell)[3], uint32
     const uint32_t top = res - 1u;
     // the +1 neighbour is clamped to res-1 (gridencoder.cu:182): its term is the base term plus one multiplier,
     // or the base term itself at the border -- an add and a select instead of a second quarter-rate v_mul_lo_u32
-    const uint32_t X0 = x0 * STRIDE_BYTES, Y0 = y0 * my, Z0 = z0 * mz;
+    uint32_t Y0, Z0;
+    if constexpr (KIND == 0) { Y0 = __umul24(y0, my); Z0 = __umul24(z0, mz); }   // full rate; operands bounded by levels_fast()
+    else { Y0 = y0 * my; Z0 = z0 * mz; }
+    const uint32_t X0 = x0 * STRIDE_BYTES;
     const uint32_t X1 = x0 < top ? X0 + STRIDE_BYTES : X0;
     const uint32_t Y1 = y0 < top ? Y0 + my : Y0;
     const uint32_t Z1 = z0 < top ? Z0 + mz : Z0;
@@ -200,9 +203,12 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
         // alignment (fp16 rows) does not return the expected bytes on gfx950 -> fp32 proposal stages only.
         constexpr uint32_t SB = (uint32_t)(2 * sizeof(T));
         const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
-        const uint32_t y1 = umin(y0 + 1u, res - 1u), z1 = umin(z0 + 1u, res - 1u);
         const bool same_x = x0 + 1u > res - 1u;
-        const uint32_t X0 = x0 * SB, Y0 = y0 * (res * SB), Y1 = y1 * (res * SB), Z0 = z0 * (res * res * SB), Z1 = z1 * (res * res * SB);
+        // full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate; levels_fast() bounds the operands); the +1
+        // neighbour (clamped to res-1, gridencoder.cu:182) is the base term plus one stride, capped
+        const uint32_t sy = res * SB, sz = res * res * SB, top = res - 1u;
+        const uint32_t X0 = x0 * SB, Y0 = __umul24(y0, sy), Z0 = __umul24(z0, sz);
+        const uint32_t Y1 = umin(Y0 + sy, top * sy), Z1 = umin(Z0 + sz, top * sz);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t off = X0 + ((i & 1) ? Y1 : Y0) + ((i & 2) ? Z1 : Z0);
@@ -1120,6 +1126,7 @@ static bool levels_fast(const GridLevels &g) {
         const uint32_t mode = g.mode[l], mk = (mode >> 1) & 3u, nd = (mode >> 4) & 15u;
         if (mode & 1u) { if (mk != 1u) return false; }
         else if (mk != 0u || nd != 3u) return false;
+        else if ((uint64_t)g.res[l] * g.res[l] * 16u >= (1u << 24)) return false;   // dense strides go through 24-bit multiplies
     }
     return g.align_corners == 0 && g.interp == 0;
 }

@@ -60,11 +60,11 @@ uint32_t level_resolution(uint32_t level, float S, uint32_t H);
 
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float expf_det(float x) {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -103.97208404541015625f) return 0.0f;
-    const float k = __builtin_rintf(x * 1.44269502162933349609375f);
-    float r = __builtin_fmaf(k, -0.693145751953125f, x);
+    // branch-free: the polynomial runs on the clamped argument and the three special cases are selected at the end
+    // (early returns compile to exec-mask branches that serialise the three exps of a march step)
+    const float xc = fminf(fmaxf(x, -104.0f), 89.0f);
+    const float k = __builtin_rintf(xc * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(k, -0.693145751953125f, xc);
     r = __builtin_fmaf(k, -1.42860676533018704503775e-06f, r);
     float p = 1.98756915e-4f;
     p = __builtin_fmaf(p, r, 1.39819995e-3f);
@@ -80,7 +80,10 @@ __device__ __forceinline__ float expf_det(float x) {
     const int k2 = ki - k1;
     const float s1 = __int_as_float((k1 + 127) << 23);
     const float s2 = __int_as_float((k2 + 127) << 23);
-    return (p * s1) * s2;
+    float y = (p * s1) * s2;
+    y = x < -103.97208404541015625f ? 0.0f : y;
+    y = x > 88.72283935546875f ? __builtin_inff() : y;
+    return x != x ? x : y;
 }
 
 template <typename T> __device__ __forceinline__ float table_ld(const T *p);
