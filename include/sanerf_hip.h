@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 1
+#define SN_ABI_VERSION 2
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -173,6 +173,10 @@ typedef struct sn_render_cfg {
     int32_t      contract;
     int32_t      last_sample_opaque;        /* opt.background == 'last_sample' */
     float        bg_color;
+    /* optional feature stage (renderer.py:301-302 + 361): f_feat[n,:] = sum_j w[n,j] * feat_grid(xyz[n,j]) over the
+     * last stage's samples -- the SAM head's f_sam with feat_grid = s_grid (network.py:103) */
+    sn_grid_desc feat_grid;
+    int32_t      with_feat;
 } sn_render_cfg;
 
 typedef struct sn_render_io {
@@ -195,6 +199,7 @@ typedef struct sn_render_io {
     float       *xyzs_last;                 /* [N,T_last,3] contracted positions of the last stage */
     float       *geo_feat_last;             /* [N,T_last,geo] per-sample geometry features (feeds the mask head) */
     float       *f_image;                   /* [N, geo+sh] composited colour features (feeds the SAM head) */
+    float       *f_feat;                    /* [N, L*C of cfg->feat_grid]; required when cfg->with_feat */
     /* workspace */
     void        *workspace;                 /* device, >= sn_rm_render_workspace_bytes() */
     size_t       workspace_bytes;
@@ -203,6 +208,26 @@ typedef struct sn_render_io {
 /* bytes of device workspace sn_rm_render_rays needs for N rays (tile_w as in sn_render_io) */
 size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w);
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream);
+
+/* Feature-head accumulation, nerf/renderer.py:301-302 + 361: out[n, :] = sum_j weights[n,j] * grid(xyzs[n,j])
+ * = composite(weights, s_grid(xyzs, bound)) without materialising the [N*T, L*C] per-sample features.
+ * xyzs [N,T,3] (contracted sample positions), weights [N,T], out [N, L*C]; tile_w > 0: rays are a row-major image
+ * of that width (lanes map to 8x8 pixel tiles).  Forward only (inference); training goes through
+ * sn_grid_encode_* + sn_rm_composite*. */
+int sn_rm_grid_composite(const float *xyzs, const float *weights, uint32_t N, uint32_t T, float bound,
+                         const sn_grid_desc *grid, uint32_t tile_w, float *out, sn_stream_t stream);
+
+/* Wide perceptron of the feature heads on the matrix cores: nerf/network.py:31-66 (SkipConnMLP) followed by an
+ * optional nn.LayerNorm (network.py:115) -- samvit_mlp per ray (renderer.py:359-374), mask_mlp per sample
+ * (renderer.py:376-385).  x [N, dims[0]] -> out [N, dims[num_layers]].  Hidden widths must be 256, the output
+ * width <= 256; bias optional per layer; activation 0 relu / 1 leaky_relu(0.01); skip_mask bit l: layer l sees
+ * cat([h, x]).  fp32 in / out; products run as fp16 hi+lo splits with fp32 accumulation (activations must stay
+ * inside the fp16 range, |v| < 65504).  workspace: >= sn_mlp_wide_workspace_bytes(), 16-byte aligned (holds the
+ * re-ordered weights, rebuilt on every call: the call is stateless).  ln_weight/ln_bias NULL = no LayerNorm. */
+size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp);
+int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
+                        const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
+                        sn_stream_t stream);
 
 /* Measurement hook (bench.py): bracket every kernel sn_rm_render_rays launches with hipEvents on the
  * caller's stream.  Classes: 0 weight pack, 1..3 proposal stage k, 4 final stage.  profile_read

@@ -39,7 +39,8 @@ class RenderCfg(C.Structure):
                 ("prop_grid", GridDesc * MAX_STAGES), ("prop_mlp", MlpDesc * MAX_STAGES),
                 ("grid", GridDesc), ("grid_mlp", MlpDesc), ("view_mlp", MlpDesc),
                 ("sh_degree", C.c_uint32), ("aabb", C.c_float * 6), ("min_near", C.c_float), ("bound", C.c_float),
-                ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float)]
+                ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float),
+                ("feat_grid", GridDesc), ("with_feat", C.c_int32)]
 
 
 class RenderIO(C.Structure):
@@ -49,11 +50,12 @@ class RenderIO(C.Structure):
                 ("image", C.c_void_p), ("depth", C.c_void_p), ("weights_sum", C.c_void_p),
                 ("bins", C.c_void_p * MAX_STAGES), ("weights", C.c_void_p * MAX_STAGES),
                 ("sigmas", C.c_void_p * MAX_STAGES), ("inds", C.c_void_p * MAX_STAGES),
-                ("xyzs_last", C.c_void_p), ("geo_feat_last", C.c_void_p), ("f_image", C.c_void_p),
+                ("xyzs_last", C.c_void_p), ("geo_feat_last", C.c_void_p), ("f_image", C.c_void_p), ("f_feat", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
+ABI_VERSION = 2   # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),
@@ -76,6 +78,9 @@ _SIGNATURES = {
     "sn_rm_weights_from_sigma": (_int, [_vp, _vp, _u32, _u32, _int, _vp, _vp]),
     "sn_rm_composite": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     "sn_rm_composite_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    "sn_rm_grid_composite": (_int, [_vp, _vp, _u32, _u32, _f32, C.POINTER(GridDesc), _u32, _vp, _vp]),
+    "sn_mlp_wide_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
+    "sn_mlp_wide_forward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _f32, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_render_workspace_bytes": (C.c_size_t, [C.POINTER(RenderCfg), _u32, _u32]),
     "sn_rm_render_rays": (_int, [C.POINTER(RenderCfg), C.POINTER(RenderIO), _vp]),
     "sn_rm_profile_enable": (None, [_int]),
@@ -110,6 +115,8 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        if l.sn_abi_version() != ABI_VERSION:   # the ctypes structs above mirror include/sanerf_hip.h of exactly this version
+            raise ImportError(f"{LIB_PATH} has ABI version {l.sn_abi_version()}, this package expects {ABI_VERSION}: rebuild it")
         _lib = l
     return _lib
 

@@ -106,11 +106,21 @@ __global__ __launch_bounds__(256) void k_grid_forward(const float *__restrict__ 
             else { w *= pos[d]; p[d] = umin(cell[d] + 1, res - 1); }
         }
         const T *row = tab + (size_t)grid_row<D>(p, res, size, mode) * C;
+        float v[C];
+        load_row<T, (int)C>(row, v);
 #pragma unroll
-        for (uint32_t c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, table_ld<T>(row + c), acc[c]);
+        for (uint32_t c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, v[c], acc[c]);
     }
+    if constexpr (C % 4 == 0) {   // 16-byte stores (outputs base is 16-byte aligned, checked on the host)
 #pragma unroll
-    for (uint32_t c = 0; c < C; ++c) out[c] = acc[c];
+        for (uint32_t q = 0; q < C / 4; ++q)
+            reinterpret_cast<float4 *>(out)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<float2 *>(out) = make_float2(acc[0], acc[1]);
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) out[c] = acc[c];
+    }
 
     if (dd) {  // gridencoder.cu:205-248
 #pragma unroll
@@ -332,6 +342,8 @@ int sn_grid_encode_forward(const float *inputs, const void *embeddings, int tabl
     SN_REQUIRE(inputs && embeddings && outputs, "grid_encode_forward: inputs/embeddings/outputs must be device pointers");
     SN_REQUIRE(table_dtype == SN_F32 || table_dtype == SN_F16, "grid_encode_forward: embeddings must be float32 or float16");
     SN_REQUIRE(layout == SN_LAYOUT_LBC || layout == SN_LAYOUT_BLC, "grid_encode_forward: bad layout %d", layout);
+    SN_REQUIRE(table_aligned(embeddings) && table_aligned(outputs),
+               "grid_encode_forward: embeddings and outputs must be 16-byte aligned (rows are read/written with vector accesses)");
     GridLevels g;
     int rc = build_grid_levels(&g, offsets_host, D, C, L, S, H, gridtype, align_corners, interp);
     if (rc) return rc;

@@ -1,0 +1,499 @@
+// mlp.hip — wide (256-neuron) skip-connection perceptrons of the feature heads on the matrix cores (gfx950).
+//
+//   sn_mlp_wide_forward    SkipConnMLP [+ LayerNorm]   (nerf/network.py:31-66, 101-128; renderer.py:359-385)
+//
+// samvit_mlp (163 -> 256 x4 -> 256, skip at layer 2, LayerNorm) runs once per ray and mask_mlp
+// (143 -> 256 -> 256 -> n_inst) once per SAMPLE; in the reference each layer is a GEMM launch plus an
+// activation launch with [rows, 256] round trips through memory.  Here one kernel carries a tile of
+// 128 rows through all layers:
+//
+//   * transposed formulation H^T = W * X^T on v_mfma_f32_32x32x16_f16: A = weights (32 output
+//     neurons x 16 inputs), B = activations (16 inputs x 32 rows), fp32 accumulate.  A wave owns 32
+//     rows and ALL 256 outputs of a layer (8 accumulator tiles = 128 registers);
+//   * fp32 accuracy from fp16 operands: x = hi + lo (two halves), three products hi*hi + hi*lo + lo*hi
+//     (the lo*lo term is below fp32 rounding) -- the same recipe as the radiance MLP in render.hip;
+//   * the accumulator layout of a 32x32 tile (reg r of lane l = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31])
+//     is a valid B-operand layout, so a layer's outputs feed the next layer from registers: only the
+//     weights' k order is permuted, once, by k_pack_mlp_wide;
+//   * weights stream through LDS in 16 KiB chunks (1 k-step x 8 output tiles x (hi, lo) x 64 lanes x 16 B) by
+//     LDS-DMA, a ring of 4 running 3 chunks ahead, shared by the 4 waves of the workgroup: 1 read per 128 rows.
+//
+// Packed weight stream: for each layer, its k-steps ("chunks"); h-input k-steps first (the previous
+// layer's 256 outputs, 16 k-steps), then x-input k-steps (layer 0 and skip layers; input width padded
+// to a multiple of 16).  Chunk = [mt 8][hi|lo][lane 64] uint4.
+#include "sn_common.h"
+
+namespace sn {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+constexpr int WIDE = 256;                 // hidden width this build instantiates
+constexpr int WIDE_MT = WIDE / 32;        // output tiles of a hidden layer
+constexpr int WIDE_HKS = WIDE / 16;       // k-steps that consume a hidden layer
+constexpr int WIDE_ROWS = 128;            // rows per workgroup (4 waves x 32)
+constexpr int WIDE_CHUNK_U4 = WIDE_MT * 2 * 64;       // uint4 per chunk (one k-step, all 8 output tiles) = 16 KiB
+constexpr int WIDE_NBUF = 4;                           // LDS ring: chunk g in buffer g % 4, DMA runs 3 chunks ahead
+
+struct WideLayer {
+    uint32_t uses_h, x_ks;                // h-input (previous layer) present; number of x-input k-steps
+    uint32_t mt;                          // output tiles (ceil(out / 32))
+    uint32_t out;                         // true output width
+    uint32_t w_off;                       // first uint4 of the layer in the packed stream
+    uint32_t has_bias;
+};
+
+struct WideArgs {
+    const float *x;                       // [N, din]
+    float *out;                           // [N, dout]
+    const uint4 *pack;
+    const float *bias[SN_MAX_LAYERS];
+    const float *ln_w, *ln_b;             // LayerNorm over the last layer's outputs, or NULL
+    float ln_eps;
+    uint32_t N, din, nl, leaky, total_chunks, xs, out_lds;
+    WideLayer layer[SN_MAX_LAYERS];
+};
+
+struct PackArgs {
+    const float *w[SN_MAX_LAYERS];        // nn.Linear.weight [out, in]
+    uint32_t in_dim[SN_MAX_LAYERS];       // row length of w[l]
+    uint32_t din, nl;
+    WideLayer layer[SN_MAX_LAYERS];
+    uint4 *pack;
+};
+
+__device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo) {
+    const half2_t h = {(_Float16)a, (_Float16)b};
+    // x - hi is exact in fp32 (hi is x rounded to 11 bits), so the single-rounding fma equals the subtraction
+    const half2_t l = {(_Float16)__builtin_fmaf((float)h[0], -1.0f, a), (_Float16)__builtin_fmaf((float)h[1], -1.0f, b)};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// one thread per (layer, k-step, output tile, lane): 8 weights -> (hi, lo) uint4
+__global__ void k_pack_mlp_wide(PackArgs a) {
+    const uint32_t layer = blockIdx.y;
+    const WideLayer L = a.layer[layer];
+    const uint32_t nks = (L.uses_h ? WIDE_HKS : 0u) + L.x_ks;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nks * (uint32_t)WIDE_MT * 64u) return;
+    const uint32_t lane = t & 63u, mt = (t >> 6) % (uint32_t)WIDE_MT, ks = (t >> 6) / (uint32_t)WIDE_MT;
+    const uint32_t m = mt * 32u + (lane & 31u), hi = lane >> 5;
+    const float *W = a.w[layer];
+    const uint32_t row = a.in_dim[layer];
+    float v[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) {
+        uint32_t col;
+        bool valid = m < L.out;
+        if (L.uses_h && ks < (uint32_t)WIDE_HKS) {     // previous layer's neuron held by register 8*(ks&1)+i of half-wave hi
+            const uint32_t r = 8u * (ks & 1u) + i;
+            col = 32u * (ks >> 1) + (r & 3u) + 8u * (r >> 2) + 4u * hi;
+        } else {
+            const uint32_t kx = ks - (L.uses_h ? (uint32_t)WIDE_HKS : 0u);
+            const uint32_t c = 16u * kx + 8u * hi + i;
+            valid = valid && c < a.din;
+            col = (L.uses_h ? (uint32_t)WIDE : 0u) + c;   // skip layers see cat([h, x]) (network.py:61-63)
+        }
+        v[i] = valid ? W[(size_t)m * row + col] : 0.0f;
+    }
+    uint4 ph, pl;
+    split2h(v[0], v[1], ph.x, pl.x); split2h(v[2], v[3], ph.y, pl.y);
+    split2h(v[4], v[5], ph.z, pl.z); split2h(v[6], v[7], ph.w, pl.w);
+    const size_t base = (size_t)L.w_off + (size_t)ks * WIDE_MT * 128u + (size_t)mt * 128u;   // [chunk = ks >> 1][ks & 1][mt][hi|lo][lane]
+    a.pack[base + lane] = ph;
+    a.pack[base + 64u + lane] = pl;
+}
+
+__device__ __forceinline__ floatx16 mfma3h(const uint4 &ah, const uint4 &al, const uint4 &bh, const uint4 &bl, floatx16 acc) {
+    const half8_t Ah = __builtin_bit_cast(half8_t, ah), Al = __builtin_bit_cast(half8_t, al);
+    const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+    return acc;
+}
+
+// LDS-DMA of 16 bytes per lane (1 KiB per wave) issued through inline assembly: the compiler then does not see an
+// LDS write in flight and does not put `s_waitcnt vmcnt(0)` in front of every following ds_read (it cannot prove
+// the buffers distinct), which would make the copy synchronous.  The consumer waits explicitly (dma_wait) before
+// the workgroup barrier that publishes the buffer.  Extra outstanding loads only make the compiler's own
+// vmcnt(N) waits conservative (the counter retires in order), never early.
+__device__ __forceinline__ void dma16(const void *gptr, uint32_t lds_byte_offset_uniform) {
+    const uint32_t base = __builtin_amdgcn_readfirstlane(lds_byte_offset_uniform);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+
+// LDS: [ weight ring 4 x 16 KiB | biases nl x 256 floats | the tile's inputs ]
+// XMODE 2: the tile's inputs (128 consecutive rows = one contiguous block of memory) are copied verbatim into LDS by
+//          LDS-DMA, row stride = input width (odd widths -- 163, 143 -- are bank-conflict free);
+// XMODE 1: copied with ordinary loads into rows padded to xs floats (16-byte aligned, conflict-free b128 reads);
+// XMODE 0: too wide for LDS: read from memory per k-step (clamped, branch-free).
+template <int XMODE>
+__global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];        // WIDE_NBUF x WIDE_CHUNK_U4, then floats
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t half = lane >> 5;
+    const uint32_t n = blockIdx.x * WIDE_ROWS + wave * 32u + (lane & 31u);
+    const bool ok = n < a.N;
+    const float *xrow = a.x + (size_t)(ok ? n : 0u) * a.din;
+    float *lds_bias = reinterpret_cast<float *>(lds_w + WIDE_NBUF * WIDE_CHUNK_U4);      // [nl][WIDE], zero where absent
+    float *lds_x = lds_bias + SN_MAX_LAYERS * WIDE;                               // [128][xs]
+    const uint32_t xs = a.xs;
+    for (uint32_t i = tid; i < a.nl * (uint32_t)WIDE; i += 256u) {
+        const uint32_t l = i / (uint32_t)WIDE, m = i % (uint32_t)WIDE;
+        const float *b = a.bias[l];
+        lds_bias[i] = (b != nullptr && m < a.layer[l].out) ? b[m] : 0.0f;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    if constexpr (XMODE == 2) {
+        // 16-byte pieces, 1 KiB per wave instruction, round-robin over the 4 waves.  Addresses are clamped to the last
+        // whole 16 bytes of the array: rows past N receive (finite or not) garbage that only reaches their own,
+        // never stored, outputs.  Asynchronous: the first chunk's wait + barrier below also covers these.
+        const uint32_t tile_bytes = (uint32_t)WIDE_ROWS * a.din * 4u;
+        const uint64_t arr_bytes = (uint64_t)a.N * a.din * 4u;
+        const uint64_t tile0 = (uint64_t)blockIdx.x * tile_bytes;
+        const uint32_t lds_x_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_x);
+        for (uint32_t piece = wave; piece * 1024u < tile_bytes; piece += 4u) {
+            uint64_t off = tile0 + (uint64_t)piece * 1024u + lane * 16u;
+            off = off + 16u <= arr_bytes ? off : arr_bytes - 16u;
+            dma16(reinterpret_cast<const char *>(a.x) + off, lds_x_off + piece * 1024u);
+        }
+    }
+    if constexpr (XMODE == 1) {
+        // the tile's inputs -> LDS, zero padded to xs columns: wave w copies rows 32w..32w+31, 64 consecutive columns
+        // per load (coalesced), 8 rows in flight
+        const uint32_t row0 = blockIdx.x * WIDE_ROWS + wave * 32u;
+        for (uint32_t c = lane; c < xs; c += 64u) {
+#pragma unroll
+            for (uint32_t rb = 0; rb < 32u; rb += 8u) {
+                float t[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const uint32_t r = row0 + rb + k;
+                    const uint32_t rr = r < a.N ? r : a.N - 1u, cc = c < a.din ? c : a.din - 1u;   // in range: no branch around the load
+                    const float v = a.x[(size_t)rr * a.din + cc];
+                    t[k] = (r < a.N && c < a.din) ? v : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) lds_x[(wave * 32u + rb + k) * xs + c] = t[k];
+            }
+        }
+        if (tid < 32u) lds_x[(uint32_t)WIDE_ROWS * xs + tid] = 0.0f;         // slack read by the last row's last k-step
+    }
+
+    floatx16 acc[WIDE_MT];
+    uint4 hbh[WIDE_HKS], hbl[WIDE_HKS];                                  // previous layer's outputs as B operands
+#pragma unroll
+    for (int k = 0; k < WIDE_HKS; ++k) { hbh[k] = make_uint4(0, 0, 0, 0); hbl[k] = make_uint4(0, 0, 0, 0); }
+
+    // ---- weight stream: chunk g = k-step g of the concatenated layers (output tiles beyond a narrow last layer are
+    //      zero padded by the packer), in LDS buffer g % WIDE_NBUF.  LDS-DMA (global_load_lds_dwordx4: the wave's
+    //      64 lanes land 1 KiB contiguously at a wave-uniform LDS base, no staging registers) runs 3 chunks ahead:
+    //      a chunk computes in ~770 cycles, an L2 fetch takes 1-2 thousand ----
+    uint32_t g = 0;                        // chunks consumed so far
+    const uint32_t total_chunks = a.total_chunks;
+    const uint32_t lds_w_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_w) + wave * 1024u;
+    constexpr uint32_t CHUNK_BYTES = WIDE_CHUNK_U4 * sizeof(uint4);
+    constexpr int PIECES = WIDE_CHUNK_U4 / 256;                          // DMA instructions per wave per chunk
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)WIDE_NBUF - 1u; ++c) {
+        if (c < total_chunks) {
+            const uint4 *src = a.pack + (size_t)c * WIDE_CHUNK_U4 + tid;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(src + i * 256, lds_w_off + c * CHUNK_BYTES + (uint32_t)i * 4096u);
+        }
+    }
+    __syncthreads();                       // publishes lds_bias / lds_x
+
+    // one chunk = one k-step x 8 output tiles; the B operand is supplied by the caller
+    auto run_chunk = [&](const uint4 &bh, const uint4 &bl) {
+        // chunk g has landed when at most the pieces of the chunks issued after it are still in flight
+        const uint32_t later = total_chunks - 1u - g;
+        if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
+        else if (later == 1u) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
+        __syncthreads();                   // every wave's pieces of chunk g are in LDS; buffer (g+3)%4 (chunk g-1) is free
+        const bool more = g + 3u < total_chunks;
+        const uint4 *nsrc = a.pack + (size_t)(g + 3u) * WIDE_CHUNK_U4 + tid;
+        const uint32_t ndst = lds_w_off + ((g + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        // Output tiles are processed in pairs with their MFMAs interleaved (a tile's three products depend on each
+        // other through the accumulator: back to back they leave the matrix pipe idle between issues); the A tiles
+        // of the next pair are read one pair ahead, and the scheduling barrier keeps the compiler from hoisting all
+        // the chunk's LDS reads (64 registers) to its top
+        const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+        uint4 ah[2][2], al[2][2];
+        ah[0][0] = buf[0]; al[0][0] = buf[64]; ah[0][1] = buf[128]; al[0][1] = buf[192];
+#pragma unroll
+        for (int pr = 0; pr < WIDE_MT / 2; ++pr) {
+            const int cur = pr & 1, nxt = cur ^ 1;
+            if (pr + 1 < WIDE_MT / 2) {
+                ah[nxt][0] = buf[(2 * pr + 2) * 128]; al[nxt][0] = buf[(2 * pr + 2) * 128 + 64];
+                ah[nxt][1] = buf[(2 * pr + 3) * 128]; al[nxt][1] = buf[(2 * pr + 3) * 128 + 64];
+            }
+            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cur][0]), A0l = __builtin_bit_cast(half8_t, al[cur][0]);
+            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cur][1]), A1l = __builtin_bit_cast(half8_t, al[cur][1]);
+            floatx16 c0 = acc[2 * pr], c1 = acc[2 * pr + 1];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+            acc[2 * pr] = c0; acc[2 * pr + 1] = c1;
+            // the 4 DMA pieces of chunk g+3 go out one per pair (their issue overlaps the matrix pipe)
+            if (more) dma16(nsrc + pr * 256, ndst + (uint32_t)pr * 4096u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_assert(PIECES == WIDE_MT / 2, "one DMA piece per output-tile pair");
+        ++g;
+    };
+
+    auto x_operand = [&](uint32_t kx, uint4 &bh, uint4 &bl) {            // x[n][16 kx + 8 half + 0..7], zero padded
+        float v[8];
+        const uint32_t c0 = 16u * kx + 8u * half;
+        if constexpr (XMODE == 2) {
+            const float *row = lds_x + (wave * 32u + (lane & 31u)) * a.din + c0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) { const float t = row[i]; v[i] = c0 + i < a.din ? t : 0.0f; }   // past the row: next row / slack
+        } else if constexpr (XMODE == 1) {
+            const float4 p = *reinterpret_cast<const float4 *>(lds_x + (wave * 32u + (lane & 31u)) * xs + c0);
+            const float4 q = *reinterpret_cast<const float4 *>(lds_x + (wave * 32u + (lane & 31u)) * xs + c0 + 4u);
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) v[i] = c0 + i < a.din ? v[i] : 0.0f;   // columns past xs alias the next row
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t c = c0 + i;
+                const float t = xrow[c < a.din ? c : a.din - 1u];         // always in range: no divergent branch around the load
+                v[i] = (ok && c < a.din) ? t : 0.0f;
+            }
+        }
+        split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
+        split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
+    };
+
+    for (uint32_t l = 0; l < a.nl; ++l) {
+        const WideLayer L = a.layer[l];
+        // bias -> accumulator init (register r of this lane is neuron 32 mt + (r&3) + 8 (r>>2) + 4 half)
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = *reinterpret_cast<const float4 *>(lds_bias + l * (uint32_t)WIDE + 32u * mt + 8u * q + 4u * half);
+                acc[mt][4 * q] = b.x; acc[mt][4 * q + 1] = b.y; acc[mt][4 * q + 2] = b.z; acc[mt][4 * q + 3] = b.w;
+            }
+        }
+        if (L.uses_h) {
+#pragma unroll
+            for (int k = 0; k < WIDE_HKS; ++k) run_chunk(hbh[k], hbl[k]);
+        }
+        for (uint32_t k = 0; k < L.x_ks; ++k) {
+            uint4 bh, bl;
+            x_operand(k, bh, bl);
+            run_chunk(bh, bl);
+        }
+        if (l + 1u < a.nl) {
+            // activation (network.py:65-66) + split into the next layer's B operands
+#pragma unroll
+            for (int mt = 0; mt < WIDE_MT; ++mt) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float t = acc[mt][8 * hf + i];
+                        v[i] = t > 0.0f ? t : (a.leaky ? t * 0.01f : 0.0f);
+                    }
+                    uint4 &bh = hbh[2 * mt + hf], &bl = hbl[2 * mt + hf];
+                    split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
+                    split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: optional LayerNorm over the row, then 16-byte stores (4 consecutive neurons per register quad) ----
+    const WideLayer LL = a.layer[a.nl - 1u];
+    float mean = 0.0f, rstd = 1.0f;
+    if (a.ln_w) {
+        float s = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = 32u * mt + (r & 3) + 8u * (r >> 2) + 4u * half;
+                s += m < LL.out ? acc[mt][r] : 0.0f;
+            }
+        s += __shfl_xor(s, 32);
+        mean = s / (float)LL.out;
+        float q = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = 32u * mt + (r & 3) + 8u * (r >> 2) + 4u * half;
+                const float d = acc[mt][r] - mean;
+                q += m < LL.out ? d * d : 0.0f;
+            }
+        q += __shfl_xor(q, 32);
+        rstd = 1.0f / sqrtf(q / (float)LL.out + a.ln_eps);
+    }
+    if (a.out_lds) {
+        // full-width output through LDS (the weight ring and the input tile are dead): a wave parks its 32 rows x 256
+        // outputs, then writes whole rows -- 1 KiB per store instruction instead of 64 scattered 16-byte pieces
+        constexpr uint32_t RS = WIDE + 4;                                 // row stride in floats (16-byte aligned, conflict-free)
+        __syncthreads();
+        float *reg = reinterpret_cast<float *>(lds_w) + wave * (32u * RS + 64u);
+        float *stat = reg + 32u * RS;                                     // [32][2] mean, rstd
+        const uint32_t r = lane & 31u;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                *reinterpret_cast<float4 *>(reg + r * RS + 32u * mt + 8u * qd + 4u * half) =
+                    make_float4(acc[mt][4 * qd], acc[mt][4 * qd + 1], acc[mt][4 * qd + 2], acc[mt][4 * qd + 3]);
+        if (half == 0u) { stat[2u * r] = mean; stat[2u * r + 1u] = rstd; }
+        float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.ln_w) { w4 = reinterpret_cast<const float4 *>(a.ln_w)[lane]; b4 = reinterpret_cast<const float4 *>(a.ln_b)[lane]; }
+        const uint32_t row0 = blockIdx.x * WIDE_ROWS + wave * 32u;
+#pragma unroll 8
+        for (uint32_t i = 0; i < 32u; ++i) {
+            if (row0 + i >= a.N) break;
+            float4 v = *reinterpret_cast<const float4 *>(reg + i * RS + lane * 4u);
+            const float mu = stat[2u * i], rs = stat[2u * i + 1u];
+            v.x = (v.x - mu) * rs * w4.x + b4.x; v.y = (v.y - mu) * rs * w4.y + b4.y;
+            v.z = (v.z - mu) * rs * w4.z + b4.z; v.w = (v.w - mu) * rs * w4.w + b4.w;
+            reinterpret_cast<float4 *>(a.out + (size_t)(row0 + i) * WIDE)[lane] = v;
+        }
+        return;
+    }
+    if (!ok) return;
+    float *orow = a.out + (size_t)n * LL.out;
+#pragma unroll
+    for (int mt = 0; mt < WIDE_MT; ++mt) {
+        if ((uint32_t)mt >= LL.mt) break;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const uint32_t m0 = 32u * mt + 8u * qd + 4u * half;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = acc[mt][4 * qd + i];
+                if (a.ln_w) {              // wave-uniform; index clamped so that the loads need no per-lane branch
+                    const uint32_t mi = m0 + i < LL.out ? m0 + i : LL.out - 1u;
+                    t = (t - mean) * rstd * a.ln_w[mi] + a.ln_b[mi];
+                }
+                v[i] = t;
+            }
+            if ((LL.out & 3u) == 0u && m0 + 3u < LL.out) {
+                *reinterpret_cast<float4 *>(orow + m0) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (m0 + i < LL.out) orow[m0 + i] = v[i];
+            }
+        }
+    }
+}
+
+static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) {
+    SN_REQUIRE(m->num_layers >= 1 && m->num_layers <= SN_MAX_LAYERS, "mlp_wide: num_layers=%u outside 1..%d", m->num_layers, SN_MAX_LAYERS);
+    SN_REQUIRE(m->activation <= 1u, "mlp_wide: activation must be 0 (relu) or 1 (leaky_relu 0.01)");
+    const uint32_t din = m->dims[0], nl = m->num_layers;
+    SN_REQUIRE(din >= 1 && din <= 1024, "mlp_wide: input width %u outside 1..1024", din);
+    SN_REQUIRE((m->skip_mask & 1u) == 0u, "mlp_wide: a skip connection into layer 0 is not meaningful");
+    size_t off = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        SN_REQUIRE(m->weight[l], "mlp_wide: layer %u has no weight", l);
+        if (l + 1 < nl) SN_REQUIRE(m->dims[l + 1] == (uint32_t)WIDE, "mlp_wide: hidden width must be %d (layer %u has %u)", WIDE, l, m->dims[l + 1]);
+        else SN_REQUIRE(m->dims[l + 1] >= 1 && m->dims[l + 1] <= (uint32_t)WIDE, "mlp_wide: output width %u outside 1..%d", m->dims[l + 1], WIDE);
+        WideLayer &L = layers[l];
+        const bool skip = ((m->skip_mask >> l) & 1u) != 0u;
+        L.uses_h = l > 0 ? 1u : 0u;
+        L.x_ks = (l == 0 || skip) ? div_up(din, 16) : 0u;
+        L.out = m->dims[l + 1];
+        L.mt = div_up(L.out, 32);
+        L.has_bias = m->bias[l] ? 1u : 0u;
+        L.w_off = (uint32_t)off;
+        off += (size_t)((L.uses_h ? WIDE_HKS : 0) + L.x_ks) * WIDE_CHUNK_U4;
+    }
+    SN_REQUIRE(off < (1ull << 31), "mlp_wide: packed weights too large");
+    *total_u4 = off;
+    return SN_OK;
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+extern "C" size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp) {
+    WideLayer layers[SN_MAX_LAYERS];
+    size_t u4 = 0;
+    if (!mlp || wide_plan(mlp, layers, &u4) != SN_OK) return 0;
+    return u4 * sizeof(uint4);
+}
+
+extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
+                                   const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
+                                   sn_stream_t stream) {
+    SN_REQUIRE(mlp, "mlp_wide: mlp is NULL");
+    if (N == 0) return SN_OK;
+    SN_REQUIRE(x && out && workspace, "mlp_wide: x/out/workspace must be device pointers");
+    SN_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "mlp_wide: LayerNorm needs both weight and bias");
+    SN_REQUIRE(table_aligned(workspace) && table_aligned(out), "mlp_wide: workspace/out must be 16-byte aligned");
+    PackArgs pa;
+    size_t u4 = 0;
+    int rc = wide_plan(mlp, pa.layer, &u4);
+    if (rc) return rc;
+    SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mlp_wide: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
+    const uint32_t nl = mlp->num_layers, din = mlp->dims[0];
+    hipStream_t st = (hipStream_t)stream;
+    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace);
+    uint32_t max_threads = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        pa.w[l] = mlp->weight[l];
+        pa.in_dim[l] = (l == 0 ? din : (uint32_t)WIDE) + ((l > 0 && ((mlp->skip_mask >> l) & 1u)) ? din : 0u);
+        SN_REQUIRE(l == 0 || mlp->dims[l] == (uint32_t)WIDE, "mlp_wide: dims[%u] must be %d", l, WIDE);
+        const uint32_t nks = (pa.layer[l].uses_h ? WIDE_HKS : 0) + pa.layer[l].x_ks;
+        const uint32_t th = nks * (uint32_t)WIDE_MT * 64u;
+        if (th > max_threads) max_threads = th;
+    }
+    hipLaunchKernelGGL(k_pack_mlp_wide, dim3(div_up(max_threads, 256), nl), dim3(256), 0, st, pa);
+    SN_LAUNCH_CHECK("k_pack_mlp_wide");
+    WideArgs wa;
+    wa.x = x; wa.out = out; wa.pack = pa.pack; wa.ln_w = ln_weight; wa.ln_b = ln_bias; wa.ln_eps = ln_eps;
+    wa.N = N; wa.din = din; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
+    for (uint32_t l = 0; l < nl; ++l) { wa.bias[l] = mlp->bias[l]; wa.layer[l] = pa.layer[l]; }
+    // XMODE 1 row stride: a multiple of 4 floats (16-byte reads) with stride/4 odd (the 32 rows of a wave then start in
+    // distinct bank groups: conflict-free ds_read_b128)
+    uint32_t xs = (din + 3u) & ~3u;
+    if (((xs >> 2) & 1u) == 0u) xs += 4u;
+    const size_t lds_fixed = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float);
+    const size_t lds_x1 = ((size_t)WIDE_ROWS * xs + 32u) * sizeof(float);       // + slack: the last k-step of the last row reads past xs
+    const size_t lds_x2 = (size_t)WIDE_ROWS * din * sizeof(float) + 1024u;      // whole 1 KiB DMA pieces + slack
+    const size_t lds_cap = 160u * 1024u;
+    // DMA mode: rows must be an odd number of floats apart (bank conflicts) and the array a whole number of 16-byte
+    // pieces unless the grid has no partial last tile
+    const bool dma_ok = (din & 1u) && lds_fixed + lds_x2 <= lds_cap && (uint64_t)N * din >= 4u &&
+                        ((((uint64_t)N * din) & 3u) == 0u || (N % WIDE_ROWS) == 0u);
+    const int xmode = dma_ok ? 2 : (lds_fixed + lds_x1 <= lds_cap ? 1 : 0);
+    size_t lds = lds_fixed + (xmode == 2 ? lds_x2 : xmode == 1 ? lds_x1 : 0u);
+    const size_t out_need = 4u * (32u * (WIDE + 4u) + 64u) * sizeof(float);      // the transposed output tile of 4 waves
+    wa.out_lds = (mlp->dims[nl] == (uint32_t)WIDE && lds_cap >= out_need) ? 1u : 0u;
+    if (wa.out_lds && lds < out_need) lds = out_need;
+    wa.xs = xs;
+#define SN_MLP_LAUNCH(MODE)                                                                                           \
+    do {                                                                                                              \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_mlp_wide<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);                     \
+    } while (0)
+    if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
+#undef SN_MLP_LAUNCH
+    SN_LAUNCH_CHECK("k_mlp_wide");
+    return SN_OK;
+}

@@ -49,12 +49,12 @@ struct RayCommon {
 // Workgroup id -> tile id.  The dispatcher places workgroup b on XCD b % 8 (observed, not contractual: used
 // for speed only).  Remapping so that each XCD owns a contiguous range of tile ids keeps neighbouring image
 // tiles -- which share fine-level table lines -- behind the same private L2.  Bijective for any grid size.
-__device__ __forceinline__ uint32_t tile_id(const RayCommon &rc) {
-    const uint32_t b = blockIdx.x;
+__device__ __forceinline__ uint32_t tile_id_x(const RayCommon &rc, uint32_t b, uint32_t nwg) {
     if (!rc.xcd_swizzle) return b;
-    const uint32_t nwg = gridDim.x, xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
+    const uint32_t xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
 }
+__device__ __forceinline__ uint32_t tile_id(const RayCommon &rc) { return tile_id_x(rc, blockIdx.x, gridDim.x); }
 
 // lane -> ray.  Tile mode: block = 16x16 pixels, wave = 8x8.
 __device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t wg, uint32_t &n) {
@@ -116,64 +116,11 @@ __device__ __forceinline__ void sample_x01(const RayCommon &rc, const RaySetup &
     }
 }
 
-// Byte offsets (from the level's base) of the 8 corners of one cell.
-// KIND: 0 = dense level, 1 = hashed level (compile-time, from the kernel's dense-prefix length K),
-//      -1 = decided at run time by a wave-uniform select (generic instantiation).
-// No per-level branch either way: a branch is a basic-block boundary per level and pins the march
-// to 8 gathers in flight per lane.  The row stride in bytes is folded into the (wave-uniform)
-// multipliers: ((x ^ y*P1 ^ z*P2) & m) * s == ((x*s) ^ (y*P1*s) ^ (z*P2*s)) & (m*s) for s a power of two.
-// Fast-path assumptions checked on the host (levels_fast): hashed levels have a power-of-two size,
-// dense levels index all three dimensions and need no modulo, align_corners = False, linear interp.
-template <int KIND, uint32_t STRIDE_BYTES>
-__device__ __forceinline__ void corner_offsets(const uint32_t (&cell)[3], uint32_t res, uint32_t size, uint32_t mode,
-                                               uint32_t (&offs)[8]) {
-    static_assert((STRIDE_BYTES & (STRIDE_BYTES - 1)) == 0, "row stride must be a power of two");
-    const bool hashed = KIND == 1 || (KIND == -1 && (mode & 1u) != 0u);
-    const uint32_t my = (hashed ? 2654435761u : res) * STRIDE_BYTES;          // gridencoder.cu:49 primes / :66-70 strides
-    const uint32_t mz = (hashed ? 805459861u : res * res) * STRIDE_BYTES;
-    const uint32_t mask = hashed ? (size - 1u) * STRIDE_BYTES : 0xffffffffu;
-    const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
-    const uint32_t top = res - 1u;
-    // the +1 neighbour is clamped to res-1 (gridencoder.cu:182): its term is the base term plus one multiplier,
-    // or the base term itself at the border -- an add and a select instead of a second quarter-rate v_mul_lo_u32
-    uint32_t Y0, Z0;
-    if constexpr (KIND == 0) { Y0 = __umul24(y0, my); Z0 = __umul24(z0, mz); }   // full rate; operands bounded by levels_fast()
-    else { Y0 = y0 * my; Z0 = z0 * mz; }
-    const uint32_t X0 = x0 * STRIDE_BYTES;
-    const uint32_t X1 = x0 < top ? X0 + STRIDE_BYTES : X0;
-    const uint32_t Y1 = y0 < top ? Y0 + my : Y0;
-    const uint32_t Z1 = z0 < top ? Z0 + mz : Z0;
-    if constexpr (KIND == 1) {
-        // (X ^ Y ^ Z) & m == (X & m) ^ (Y & m) ^ (Z & m): masking the 6 partial terms replaces 8 per-corner ANDs
-        const uint32_t X0m = X0 & mask, X1m = X1 & mask, Y0m = Y0 & mask, Y1m = Y1 & mask, Z0m = Z0 & mask, Z1m = Z1 & mask;
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) offs[i] = ((i & 1u) ? X1m : X0m) ^ ((i & 2u) ? Y1m : Y0m) ^ ((i & 4u) ? Z1m : Z0m);
-    } else {
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) {
-            const uint32_t X = (i & 1u) ? X1 : X0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
-            if constexpr (KIND == 0) offs[i] = X + Y + Z;
-            else offs[i] = (hashed ? (X ^ Y ^ Z) : (X + Y + Z)) & mask;
-        }
-    }
-}
-
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
         f(std::integral_constant<int, I>{});
         static_for<I + 1, N>(f);
-    }
-}
-
-// gridencoder.cu:145-149 for align_corners = False, linear interpolation (what the fused kernels support)
-__device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t res, float (&pos)[3], uint32_t (&cell)[3]) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float p = __builtin_fmaf(x01[d], (float)res, -0.5f);
-        p = fminf(fmaxf(p, 0.0f), (float)(res - 1u));
-        cell[d] = (uint32_t)p;                     // p >= 0: truncation == floor (one v_cvt_u32_f32)
-        pos[d] = __builtin_amdgcn_fractf(p);       // p - floor(p), exact for p >= 0 (one v_fract_f32)
     }
 }
 
@@ -591,6 +538,7 @@ struct FinalArgs {
     uint32_t sh_degree;
     float *image, *depth, *wsum;
     float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
+    float *w_out;                // scratch [T][Npad] for the feature stage, or NULL
 };
 
 // A-operand packing for the 32->64->64->16 MLP on v_mfma_f32_32x32x2_f32.
@@ -1025,6 +973,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         dep = __builtin_fmaf(w, tmid, dep);
 #pragma unroll
         for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, h[1 + c], fimg[c]);
+        if (a.w_out) a.w_out[(size_t)j * Npad + r] = w;
         if (ok) {
             if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
             if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
@@ -1092,13 +1041,109 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
 }
 
 // ------------------------------------------------------------------------------------------
+// feature stage: f[n, :] = sum_j w[n,j] * feat_grid(xyz[n,j])   (renderer.py:301-302 + 361, the SAM head's f_sam)
+// ------------------------------------------------------------------------------------------
+// Runs after the final stage on the same lane -> ray mapping.  Sample positions are recomputed from the last
+// stage's bins (scratch, coalesced) with the very same code the final stage uses, weights come from the final
+// stage's scratch column; nothing per-sample is written.  A workgroup pass covers LG levels (blockIdx.y).
+struct FeatArgs {
+    RayCommon rc;
+    GridLevels g;
+    const void *table;
+    uint32_t T;
+    const float *bins_in;        // scratch [T+1][Npad] or NULL (single-stage)
+    const float *bins0_tab;
+    const float *w_in;           // scratch [T][Npad]
+    float *out;                  // [N, L*C]
+};
+
+template <typename TT, int C, int LG>
+__global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
+    uint32_t n;
+    const uint32_t wg = tile_id_x(a.rc, blockIdx.x, gridDim.x);
+    const bool ok = ray_of_lane(a.rc, wg, n);
+    const uint32_t r = wg * 256u + threadIdx.x;
+    const uint32_t Npad = a.rc.Npad;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    const uint32_t T = a.T;
+    const float b0step = 1.0f / (float)T;
+    auto bin_at = [&](uint32_t j) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
+        if (a.bins0_tab) return a.bins0_tab[j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+    const uint32_t l0 = blockIdx.y * LG;
+    const TT *table = reinterpret_cast<const TT *>(a.table);
+    float acc[LG][C];
+#pragma unroll
+    for (int i = 0; i < LG; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[i][c] = 0.0f;
+    float rb_prev = real_bin(rs, bin_at(0));
+    for (uint32_t j = 0; j < T; ++j) {
+        const float rb_next = real_bin(rs, bin_at(j + 1u));
+        const float tmid = (rb_next + rb_prev) / 2.0f;
+        rb_prev = rb_next;
+        float p[3], x01[3];
+        sample_x01(a.rc, rs, tmid, p, x01);
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (x01[d] < 0.0f || x01[d] > 1.0f) oob = true;     // gridencoder.cu:105-130
+        const float w = a.w_in[(size_t)j * Npad + r];
+        const float wz = oob ? 0.0f : w;
+        float pos[LG][3];
+        float cv[LG][8][C];
+#pragma unroll
+        for (int i = 0; i < LG; ++i) {
+            const uint32_t l = l0 + i;
+            uint32_t cell[3], offs[8];
+            locate_linear(x01, a.g.res[l], pos[i], cell);
+            corner_offsets<-1, (uint32_t)(C * sizeof(TT))>(cell, a.g.res[l], a.g.size[l], a.g.mode[l], offs);
+            const char *tab = reinterpret_cast<const char *>(table + (size_t)a.g.off[l] * C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) load_row<TT, C>(reinterpret_cast<const TT *>(tab + offs[k]), cv[i][k]);
+        }
+#pragma unroll
+        for (int i = 0; i < LG; ++i) {
+            float feat[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) feat[c] = 0.0f;
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8u; ++idx) {       // gridencoder.cu:171-192
+                float cw = 1.0f;
+#pragma unroll
+                for (uint32_t d = 0; d < 3u; ++d) cw *= (idx & (1u << d)) ? pos[i][d] : 1.0f - pos[i][d];
+#pragma unroll
+                for (int c = 0; c < C; ++c) feat[c] = __builtin_fmaf(cw, cv[i][idx][c], feat[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[i][c] = __builtin_fmaf(wz, feat[c], acc[i][c]);
+        }
+    }
+    if (!ok) return;
+    float *o = a.out + (size_t)n * a.g.L * C + (size_t)l0 * C;
+#pragma unroll
+    for (int i = 0; i < LG; ++i) {
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q)
+                reinterpret_cast<float4 *>(o + i * C)[q] = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[i * C + c] = acc[i][c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 // ---- optional per-kernel timing (bench.py's roofline leg) ---------------------------------
 // When enabled, every kernel launched by sn_rm_render_rays is bracketed by hipEvents recorded
 // on the caller's stream; sn_rm_profile_read() synchronises them and returns, per kernel class,
 // the launch count and the summed device time.  Off by default (no events, no overhead).
-enum { PK_PACK = 0, PK_PROP0, PK_PROP1, PK_PROP2, PK_FINAL, PK_CLASSES };
+enum { PK_PACK = 0, PK_PROP0, PK_PROP1, PK_PROP2, PK_FINAL, PK_FEAT, PK_CLASSES };
 struct ProfSpan { hipEvent_t a, b; int cls; };
 static bool g_prof_on = false;
 static std::vector<ProfSpan> g_prof;
@@ -1118,17 +1163,6 @@ struct ProfScope {
 static int to_levels(GridLevels *g, const sn_grid_desc *d) {
     SN_REQUIRE(d->D == 3, "render: grids must be 3-D (got D=%u)", d->D);
     return build_grid_levels(g, d->offsets, d->D, d->C, d->L, d->S, d->H, d->gridtype, (int)d->align_corners, d->interp);
-}
-
-// fused kernels assume: hashed levels have power-of-two size; dense levels walk all 3 dims, no modulo
-static bool levels_fast(const GridLevels &g) {
-    for (uint32_t l = 0; l < g.L; ++l) {
-        const uint32_t mode = g.mode[l], mk = (mode >> 1) & 3u, nd = (mode >> 4) & 15u;
-        if (mode & 1u) { if (mk != 1u) return false; }
-        else if (mk != 0u || nd != 3u) return false;
-        else if ((uint64_t)g.res[l] * g.res[l] * 16u >= (1u << 24)) return false;   // dense strides go through 24-bit multiplies
-    }
-    return g.align_corners == 0 && g.interp == 0;
 }
 
 // number of leading dense levels if the grid is "dense prefix, hashed tail" (every grid the reference builds is:
@@ -1165,6 +1199,7 @@ static size_t stage_scratch_floats(const sn_render_cfg *cfg, uint32_t Npad) {
     size_t f = 0;
     for (uint32_t k = 0; k + 1 < cfg->num_stages; ++k) f += (size_t)cfg->num_steps[k] * Npad;          // weights
     for (uint32_t k = 1; k < cfg->num_stages; ++k) f += (size_t)(cfg->num_steps[k] + 1) * Npad;       // bins
+    if (cfg->with_feat) f += (size_t)cfg->num_steps[cfg->num_stages - 1] * Npad;                      // last-stage weights
     return f;
 }
 
@@ -1262,6 +1297,23 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         set_error("render_rays: the C1 plumbing field is a CPU-only configuration (BASELINE.json configs[0]); not instantiated for the GPU");
         return SN_ERR_UNSUPPORTED;
     }
+    GridLevels gl_feat;
+    int feat_lg = 2;   // levels per workgroup pass of the feature stage (more passes = more workgroups, fewer registers)
+    if (cfg->with_feat) {
+        SN_REQUIRE(io->f_feat, "render_rays: with_feat is set but io->f_feat is NULL");
+        SN_REQUIRE(cfg->feat_grid.embeddings && table_aligned(cfg->feat_grid.embeddings) && table_aligned(io->f_feat),
+                   "render_rays: feature grid table / f_feat must be 16-byte aligned device pointers");
+        int rc = to_levels(&gl_feat, &cfg->feat_grid);
+        if (rc) return rc;
+        if (!levels_fast(gl_feat) || !(gl_feat.C == 2 || gl_feat.C == 4 || gl_feat.C == 8)) {
+            set_error("render_rays: feature grid must be a hash grid with level_dim 2/4/8, align_corners=False, linear "
+                      "interpolation (network.py:103); use sn_rm_grid_composite for other grids");
+            return SN_ERR_UNSUPPORTED;
+        }
+        if (const char *e = getenv("SN_FEAT_LEVELS")) feat_lg = atoi(e);
+        if (feat_lg != 1 && feat_lg != 2 && feat_lg != 4) feat_lg = 2;
+        while (gl_feat.L % (uint32_t)feat_lg) feat_lg >>= 1;
+    }
     // SN_RENDER_MLP = f16x3 (default: fp16 hi/lo split on the matrix cores, fp32 accumulate),
     //                 mfma32 / mfma (exact fp32 v_mfma_f32_32x32x2_f32), valu (vector-ALU fallback)
     const char *mode = getenv("SN_RENDER_MLP");
@@ -1318,6 +1370,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         float *cur = scratch;
         for (uint32_t k = 0; k + 1 < S; ++k) { w_scr[k] = cur; cur += (size_t)cfg->num_steps[k] * Npad; }
         for (uint32_t k = 1; k < S; ++k) { b_scr[k] = cur; cur += (size_t)(cfg->num_steps[k] + 1) * Npad; }
+        if (cfg->with_feat) { w_scr[S - 1] = cur; cur += (size_t)cfg->num_steps[S - 1] * Npad; }
 
         for (uint32_t k = 0; k + 1 < S; ++k) {
             PropArgs pa;
@@ -1360,7 +1413,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_xyz = io->xyzs_last ? io->xyzs_last + (size_t)first * fa.T * 3 : nullptr;
         fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * 15 : nullptr;
         fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
+        fa.w_out = cfg->with_feat ? w_scr[S - 1] : nullptr;
         const bool f16 = cfg->grid.table_dtype == SN_F16;
+        {
         ProfScope ps_final(st, PK_FINAL);
 #define SN_LAUNCH_FINAL(MODE_, KK, LDS_FLOATS)                                                                                  \
         do {                                                                                                                 \
@@ -1385,6 +1440,27 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         else SN_LAUNCH_FINAL(MLP_VALU, -1, 2 * 64 * 256 + VIEW_W);                                      // 136 KiB
 #undef SN_LAUNCH_FINAL
         SN_LAUNCH_CHECK("k_final_stage");
+        }
+        if (cfg->with_feat) {
+            FeatArgs ft;
+            ft.rc = rc; ft.g = gl_feat; ft.table = cfg->feat_grid.embeddings; ft.T = cfg->num_steps[S - 1];
+            ft.bins_in = b_scr[S - 1]; ft.bins0_tab = S == 1 ? io->bins0_table : nullptr;
+            ft.w_in = w_scr[S - 1];
+            ft.out = io->f_feat + (size_t)first * gl_feat.L * gl_feat.C;
+            const bool h16 = cfg->feat_grid.table_dtype == SN_F16;
+            ProfScope ps_feat(st, PK_FEAT);
+#define SN_LAUNCH_FEAT(CC, LGG)                                                                                       \
+            do {                                                                                                      \
+                const dim3 fg(nblk, gl_feat.L / LGG);                                                                 \
+                if (h16) hipLaunchKernelGGL((k_feat_stage<__half, CC, LGG>), fg, dim3(256), 0, st, ft);                \
+                else hipLaunchKernelGGL((k_feat_stage<float, CC, LGG>), fg, dim3(256), 0, st, ft);                     \
+            } while (0)
+            if (gl_feat.C == 8) { if (feat_lg == 4) SN_LAUNCH_FEAT(8, 4); else if (feat_lg == 2) SN_LAUNCH_FEAT(8, 2); else SN_LAUNCH_FEAT(8, 1); }
+            else if (gl_feat.C == 4) { if (feat_lg == 4) SN_LAUNCH_FEAT(4, 4); else if (feat_lg == 2) SN_LAUNCH_FEAT(4, 2); else SN_LAUNCH_FEAT(4, 1); }
+            else { if (feat_lg == 4) SN_LAUNCH_FEAT(2, 4); else if (feat_lg == 2) SN_LAUNCH_FEAT(2, 2); else SN_LAUNCH_FEAT(2, 1); }
+#undef SN_LAUNCH_FEAT
+            SN_LAUNCH_CHECK("k_feat_stage");
+        }
     }
     return SN_OK;
 }

@@ -90,6 +90,44 @@ template <typename T> __device__ __forceinline__ float table_ld(const T *p);
 template <> __device__ __forceinline__ float table_ld<float>(const float *p) { return *p; }
 template <> __device__ __forceinline__ float table_ld<__half>(const __half *p) { return __half2float(*p); }
 
+// One table row (C features) with the widest loads its size allows.  Rows are C*sizeof(T) bytes and the table
+// base is at least 16-byte aligned (checked on the host, table_aligned()), so a row of 8/16/32+ bytes is naturally
+// aligned for dwordx2/dwordx4: 1-2 vector loads instead of C scalar ones per corner.
+template <typename T, int C>
+__device__ __forceinline__ void load_row(const T *__restrict__ row, float (&v)[C]) {
+    constexpr int BYTES = C * (int)sizeof(T);
+    if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+        for (int q = 0; q < BYTES / 16; ++q) {
+            const uint4 t = reinterpret_cast<const uint4 *>(row)[q];
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (sizeof(T) == 4) v[q * 4 + i] = __uint_as_float(w[i]);
+                else {
+                    const __half2 h = *reinterpret_cast<const __half2 *>(&w[i]);
+                    v[q * 8 + 2 * i] = __low2float(h); v[q * 8 + 2 * i + 1] = __high2float(h);
+                }
+            }
+        }
+    } else if constexpr (BYTES == 8) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(row);
+        if constexpr (sizeof(T) == 4) { v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); }
+        else {
+            const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
+            v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+        }
+    } else if constexpr (BYTES == 4 && sizeof(T) == 2) {
+        const __half2 a = *reinterpret_cast<const __half2 *>(row);
+        v[0] = __low2float(a); v[1] = __high2float(a);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = table_ld<T>(row + c);
+    }
+}
+
+static inline bool table_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // gridencoder.cu:45-79 — row of a grid vertex inside its level.
@@ -185,5 +223,71 @@ __device__ __forceinline__ float linspace_at(float start, float end, float step,
     const float m = step * (float)(steps - i - 1);
     return end - m;
 }
+
+// ---- fast-path level addressing shared by the fused kernels (render.hip, heads.hip) ---------------
+// Byte offsets (from the level's base) of the 8 corners of one cell.
+// KIND: 0 = dense level, 1 = hashed level (compile-time, from the kernel's dense-prefix length K),
+//      -1 = decided at run time by a wave-uniform select (generic instantiation).
+// No per-level branch either way: a branch is a basic-block boundary per level and pins the march
+// to 8 gathers in flight per lane.  The row stride in bytes is folded into the (wave-uniform)
+// multipliers: ((x ^ y*P1 ^ z*P2) & m) * s == ((x*s) ^ (y*P1*s) ^ (z*P2*s)) & (m*s) for s a power of two.
+// Fast-path assumptions checked on the host (levels_fast): hashed levels have a power-of-two size,
+// dense levels index all three dimensions and need no modulo, align_corners = False, linear interp.
+template <int KIND, uint32_t STRIDE_BYTES>
+__device__ __forceinline__ void corner_offsets(const uint32_t (&cell)[3], uint32_t res, uint32_t size, uint32_t mode,
+                                               uint32_t (&offs)[8]) {
+    static_assert((STRIDE_BYTES & (STRIDE_BYTES - 1)) == 0, "row stride must be a power of two");
+    const bool hashed = KIND == 1 || (KIND == -1 && (mode & 1u) != 0u);
+    const uint32_t my = (hashed ? 2654435761u : res) * STRIDE_BYTES;          // gridencoder.cu:49 primes / :66-70 strides
+    const uint32_t mz = (hashed ? 805459861u : res * res) * STRIDE_BYTES;
+    const uint32_t mask = hashed ? (size - 1u) * STRIDE_BYTES : 0xffffffffu;
+    const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
+    const uint32_t top = res - 1u;
+    // the +1 neighbour is clamped to res-1 (gridencoder.cu:182): its term is the base term plus one multiplier,
+    // or the base term itself at the border -- an add and a select instead of a second quarter-rate v_mul_lo_u32
+    uint32_t Y0, Z0;
+    if constexpr (KIND == 0) { Y0 = __umul24(y0, my); Z0 = __umul24(z0, mz); }   // full rate; operands bounded by levels_fast()
+    else { Y0 = y0 * my; Z0 = z0 * mz; }
+    const uint32_t X0 = x0 * STRIDE_BYTES;
+    const uint32_t X1 = x0 < top ? X0 + STRIDE_BYTES : X0;
+    const uint32_t Y1 = y0 < top ? Y0 + my : Y0;
+    const uint32_t Z1 = z0 < top ? Z0 + mz : Z0;
+    if constexpr (KIND == 1) {
+        // (X ^ Y ^ Z) & m == (X & m) ^ (Y & m) ^ (Z & m): masking the 6 partial terms replaces 8 per-corner ANDs
+        const uint32_t X0m = X0 & mask, X1m = X1 & mask, Y0m = Y0 & mask, Y1m = Y1 & mask, Z0m = Z0 & mask, Z1m = Z1 & mask;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) offs[i] = ((i & 1u) ? X1m : X0m) ^ ((i & 2u) ? Y1m : Y0m) ^ ((i & 4u) ? Z1m : Z0m);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t X = (i & 1u) ? X1 : X0, Y = (i & 2u) ? Y1 : Y0, Z = (i & 4u) ? Z1 : Z0;
+            if constexpr (KIND == 0) offs[i] = X + Y + Z;
+            else offs[i] = (hashed ? (X ^ Y ^ Z) : (X + Y + Z)) & mask;
+        }
+    }
+}
+
+// gridencoder.cu:145-149 for align_corners = False, linear interpolation (what the fused kernels support)
+__device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t res, float (&pos)[3], uint32_t (&cell)[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = __builtin_fmaf(x01[d], (float)res, -0.5f);
+        p = fminf(fmaxf(p, 0.0f), (float)(res - 1u));
+        cell[d] = (uint32_t)p;                     // p >= 0: truncation == floor (one v_cvt_u32_f32)
+        pos[d] = __builtin_amdgcn_fractf(p);       // p - floor(p), exact for p >= 0 (one v_fract_f32)
+    }
+}
+
+// fused kernels assume: hashed levels have power-of-two size; dense levels walk all 3 dims, no modulo
+static inline bool levels_fast(const GridLevels &g) {
+    for (uint32_t l = 0; l < g.L; ++l) {
+        const uint32_t mode = g.mode[l], mk = (mode >> 1) & 3u, nd = (mode >> 4) & 15u;
+        if (mode & 1u) { if (mk != 1u) return false; }
+        else if (mk != 0u || nd != 3u) return false;
+        else if ((uint64_t)g.res[l] * g.res[l] * 16u >= (1u << 24)) return false;   // dense strides go through 24-bit multiplies
+    }
+    return g.align_corners == 0 && g.interp == 0;
+}
+
 
 }  // namespace sn

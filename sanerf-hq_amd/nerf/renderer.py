@@ -128,16 +128,26 @@ class NeRFRenderer(nn.Module):
             return False
         return any(p.requires_grad for p in self._core_parameters())
 
-    def _get_plan(self):
+    def _get_plan(self, with_feat: bool = False):
         key = (self.grid.embeddings.data_ptr(), self.grid.embeddings.device, tuple(self.opt.num_steps),
-               self.render_table_dtype, self.training)
+               self.render_table_dtype, self.training, self.s_grid.embeddings.data_ptr() if with_feat else None)
         if self._plan is None or self._plan_key != key:
-            self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype)
+            self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype,
+                                       feat_encoder=self.s_grid if with_feat else None)
             ab = (self.aabb_train if self.training else self.aabb_infer).detach().cpu().tolist()
             for i in range(6):
                 self._plan.cfg.aabb[i] = ab[i]
             self._plan_key = key
         return self._plan
+
+    def _sam_fusable(self) -> bool:
+        """f_sam can be accumulated inside the fused render (no graph through s_grid wanted, standard hash grid)."""
+        if not self.opt.with_sam or not self.opt.sam_use_view_direction:
+            return False
+        if torch.is_grad_enabled() and self.s_grid.embeddings.requires_grad:
+            return False
+        g = self.s_grid
+        return g.gridtype_id == 0 and not g.align_corners and g.interp_id == 0 and g.level_dim in (2, 4, 8)
 
     def run(self, rays_o, rays_d, bg_color=None, perturb=False, cam_near_far=None, update_proposal=True,
             return_feats=0, return_mask=0, H=None, W=None, tile_w=0, **kwargs):
@@ -151,22 +161,41 @@ class NeRFRenderer(nn.Module):
         return self._run_fused(rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w)
 
     # ---------------------------------------------------------------------------------------
-    def _heads(self, results, weights, xyzs, geo_feat, f_image, image, depth, return_feats, return_mask, H, W):
+    @staticmethod
+    def _head_mlp(seq, x):
+        """nn.Sequential(SkipConnMLP[, LayerNorm]) of a feature head.  Without autograd (inference) the whole stack is
+        one matrix-core kernel (rm.mlp_forward); with autograd it is the torch module."""
+        mlp = seq[0]
+        ln = seq[1] if len(seq) > 1 else None
+        fusable = (not torch.is_grad_enabled() and x.is_cuda and mlp.dim_hidden == 256 and mlp.dim_out <= 256
+                   and len(mlp.net) <= 8 and (ln is None or isinstance(ln, torch.nn.LayerNorm)))
+        if not fusable:
+            return seq(x)
+        lead = x.shape[:-1]
+        return rm.mlp_forward(x.reshape(-1, x.shape[-1]), mlp, ln).reshape(*lead, -1)
+
+    def _heads(self, results, weights, xyzs, geo_feat, f_image, image, depth, return_feats, return_mask, H, W,
+               tile_w=0, f_sam=None):
         opt = self.opt
         if opt.with_sam:                                    # renderer.py:301-302, 359-374
-            features = self.s_grid(xyzs, bound=self.bound)
-            f_sam = rm.composite(weights, features)
+            if f_sam is not None:
+                pass                                        # accumulated inside the fused render (feature stage)
+            elif torch.is_grad_enabled() and any(t.requires_grad for t in (self.s_grid.embeddings, weights, xyzs)):
+                features = self.s_grid(xyzs, bound=self.bound)
+                f_sam = rm.composite(weights, features)
+            else:   # inference: one kernel, no [N*T, 128] intermediate
+                f_sam = rm.grid_composite(weights, xyzs, self.s_grid, self.bound, tile_w=tile_w)
             if opt.sam_use_view_direction:
                 f = torch.cat([f_sam, f_image, image, depth.unsqueeze(-1)], dim=-1)
             else:
                 f = torch.cat([f_sam, rm.composite(weights, geo_feat), image, depth.unsqueeze(-1)], dim=-1)
-            samvit = self.samvit_mlp(f)
+            samvit = self._head_mlp(self.samvit_mlp, f)
             if return_feats > 0:
                 results["samvit"] = samvit.view(H, W, -1)
         if return_mask > 0:                                 # renderer.py:304-305, 376-385
             masks = self.m_grid(xyzs, bound=self.bound)
             if opt.mask_mlp_type == "default":
-                point_masks = self.mask_mlp(torch.cat([masks, geo_feat.detach()], dim=-1))
+                point_masks = self._head_mlp(self.mask_mlp, torch.cat([masks, geo_feat.detach()], dim=-1))
             else:
                 raise RuntimeError("mask_mlp_type='lightweight_mask' is dimensionally inconsistent in the reference "
                                    "(renderer.py:381 feeds 63 features into a 35-input MLP, network.py:128)")
@@ -175,8 +204,16 @@ class NeRFRenderer(nn.Module):
     def _run_fused(self, rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w):
         opt = self.opt
         need_heads = opt.with_sam or return_mask > 0
-        want = ["weights_last", "xyzs_last", "geo_feat_last", "f_image"] if need_heads else []
-        plan = self._get_plan()
+        fused_sam = self._sam_fusable()
+        need_samples = return_mask > 0 or (opt.with_sam and not fused_sam)      # per-sample tensors for the torch heads
+        want = []
+        if opt.with_sam:
+            want.append("f_image")
+        if need_samples:
+            want += ["weights_last", "xyzs_last"]
+        if return_mask > 0 or (opt.with_sam and not opt.sam_use_view_direction):
+            want.append("geo_feat_last")                    # [N,T,15] per-sample features
+        plan = self._get_plan(with_feat=fused_sam)
         bg = float(bg_color) if not torch.is_tensor(bg_color) else 0.0
         with torch.no_grad():
             out = rm.render_rays(plan, rays_o, rays_d, cam_near_far=cam_near_far, bg_color=bg, tile_w=tile_w, want=want)
@@ -185,8 +222,8 @@ class NeRFRenderer(nn.Module):
                 image = image + (1 - out["weights_sum"]).unsqueeze(-1) * bg_color
         results = {"weights_sum": out["weights_sum"], "depth": out["depth"], "image": image}
         if need_heads:
-            self._heads(results, out["weights_last"], out["xyzs_last"], out["geo_feat_last"], out["f_image"],
-                        image, out["depth"], return_feats, return_mask, H, W)
+            self._heads(results, out.get("weights_last"), out.get("xyzs_last"), out.get("geo_feat_last"), out.get("f_image"),
+                        image, out["depth"], return_feats, return_mask, H, W, tile_w=tile_w or 0, f_sam=out.get("f_feat"))
         return results
 
     # ---------------------------------------------------------------------------------------

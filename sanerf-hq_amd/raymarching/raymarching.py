@@ -10,6 +10,8 @@ This module is that operator surface, implemented over libsanerf_hip.so:
     sample_pdf           nerf/renderer.py:84-119   (+ the integer searchsorted result)
     weights_from_sigma   nerf/renderer.py:308-325
     composite            nerf/renderer.py:333-338, 361, 384  (autograd w.r.t. both operands)
+    grid_composite       nerf/renderer.py:301-302 + 361: composite(weights, s_grid(xyzs)) fused (inference)
+    mlp_forward          nerf/network.py:31-66 (+ LayerNorm :115): the 256-wide head MLPs on the matrix cores (inference)
     render_rays          nerf/renderer.py:221-357 + nerf/network.py:146-186, fused
 """
 from __future__ import annotations
@@ -149,6 +151,53 @@ def _fill_grid(desc: _lib.GridDesc, enc, table: torch.Tensor) -> None:
     desc.gridtype, desc.align_corners, desc.interp = enc.gridtype_id, int(enc.align_corners), enc.interp_id
 
 
+def grid_composite(weights: torch.Tensor, xyzs: torch.Tensor, encoder, bound: float = 1.0, tile_w: int = 0,
+                   table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """composite(weights, encoder(xyzs, bound)) in one kernel (renderer.py:301-302 + 361): [N,T], [N,T,3] -> [N, L*C].
+    Inference only: no autograd graph is recorded (training uses encoder(...) + composite(...))."""
+    N, T = weights.shape
+    assert xyzs.shape == (N, T, 3), f"xyzs {tuple(xyzs.shape)} does not match weights {tuple(weights.shape)}"
+    L = _lib.lib()
+    emb = (encoder.embeddings if table is None else table).detach()
+    w = weights.detach().contiguous().float()
+    x = xyzs.detach().contiguous().float()
+    out = torch.empty(N, encoder.output_dim, device=w.device, dtype=torch.float32)
+    desc = _lib.GridDesc()
+    _fill_grid(desc, encoder, emb.contiguous())
+    _lib.check(L.sn_rm_grid_composite(_lib.dev(x, "xyzs"), _lib.dev(w, "weights"), N, T, float(bound), C.byref(desc),
+                                      int(tile_w), _lib.dev(out, "out"), _lib.stream()), "sn_rm_grid_composite")
+    return out
+
+
+def mlp_forward(x: torch.Tensor, mlp, layer_norm: Optional[torch.nn.LayerNorm] = None) -> torch.Tensor:
+    """SkipConnMLP / MLP forward [+ LayerNorm] in one matrix-core kernel (network.py:9-66, 115; the feature heads
+    of renderer.py:359-385).  x [N, dim_in] -> [N, dim_out].  Inference only (no autograd graph); hidden width 256."""
+    L = _lib.lib()
+    x = x.detach().contiguous().float()
+    layers = list(mlp.net)
+    desc = _lib.MlpDesc()
+    keep: list = []
+    _fill_mlp(desc, layers, x.shape[-1], keep)
+    leaky = getattr(mlp, "skip_layers", None) is not None        # SkipConnMLP uses LeakyReLU(0.01), MLP uses ReLU
+    desc.activation = 1 if leaky else 0
+    desc.skip_mask = sum(1 << int(i) for i in (getattr(mlp, "skip_layers", None) or []))
+    need = int(L.sn_mlp_wide_workspace_bytes(C.byref(desc)))
+    if need == 0:
+        raise RuntimeError("mlp_forward: " + L.sn_last_error().decode())
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = torch.empty(x.shape[0], desc.dims[desc.num_layers], device=x.device, dtype=torch.float32)
+    lw = lb = None
+    eps = 0.0
+    if layer_norm is not None:
+        lw = layer_norm.weight.detach().contiguous().float()
+        lb = layer_norm.bias.detach().contiguous().float()
+        eps = float(layer_norm.eps)
+    _lib.check(L.sn_mlp_wide_forward(C.byref(desc), _lib.dev(lw, "ln.weight"), _lib.dev(lb, "ln.bias"), eps,
+                                     _lib.dev(x, "x"), x.shape[0], _lib.dev(out, "out"), ws.data_ptr(), ws.numel(),
+                                     _lib.stream()), "sn_mlp_wide_forward")
+    return out
+
+
 def _fill_mlp(desc: _lib.MlpDesc, layers: Sequence[torch.nn.Linear], dim_in: int, keep: list) -> None:
     desc.num_layers = len(layers)
     desc.activation = 0
@@ -174,7 +223,7 @@ class RenderPlan:
     table_dtype=torch.float16 renders from half-precision copies of the hash tables (made here,
     the module keeps its fp32 parameters); arithmetic stays fp32 either way."""
 
-    def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32):
+    def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32, feat_encoder=None):
         self.keep: list = []
         cfg = _lib.RenderCfg()
         S = len(num_steps)
@@ -207,6 +256,11 @@ class RenderPlan:
         cfg.contract = int(bool(model.opt.contract))
         cfg.last_sample_opaque = int(model.opt.background == "last_sample")
         cfg.bg_color = 1.0
+        self.feat_dim = 0
+        if feat_encoder is not None:                    # s_grid (network.py:103): f_sam accumulated inside the render
+            _fill_grid(cfg.feat_grid, feat_encoder, table_of(feat_encoder))
+            cfg.with_feat = 1
+            self.feat_dim = feat_encoder.output_dim
         self.cfg = cfg
         self.num_steps = [int(t) for t in num_steps]
         self.geo = model.geom_feat_dim
@@ -225,7 +279,8 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
                 bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None):
     """Fused render of N rays.  Returns dict(image [N,3], depth [N], weights_sum [N]) plus the
     per-stage tensors named in `want`: 'bins', 'weights', 'sigmas', 'inds' (all stages),
-    'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'."""
+    'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'; a plan built with `feat_encoder` also
+    returns 'f_feat' [N, L*C] = composite(weights_last, feat_encoder(xyzs_last))."""
     rays_o, rays_d = _flat3(rays_o), _flat3(rays_d)
     N = rays_o.shape[0]
     device = rays_o.device
@@ -276,6 +331,8 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         io.geo_feat_last = buf("geo_feat_last", (N, Tl, plan.geo)).data_ptr()
     if "f_image" in want:
         io.f_image = buf("f_image", (N, plan.ncol)).data_ptr()
+    if plan.cfg.with_feat:
+        io.f_feat = buf("f_feat", (N, plan.feat_dim)).data_ptr()
     ws = plan.workspace(N, int(tile_w), device)
     io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.cfg.bg_color = float(bg_color)

@@ -266,3 +266,76 @@ def test_weights_and_composite(gpu, orc):
     np.testing.assert_allclose(vt.grad.cpu().numpy(), (w.unsqueeze(-1) * go.unsqueeze(1)).cpu().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(wt.grad.cpu().numpy(), (T(v, gpu) * go.unsqueeze(1)).sum(-1).cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert rm.composite(w, T(v[..., 0], gpu)).shape == (3000,)
+
+
+@pytest.mark.parametrize("cfg,bound,tile_w,f16", [
+    (GRID_CASES[1], 2.0, 0, False),      # SAM grid, the C3 head
+    (GRID_CASES[1], 2.0, 40, True),      # image tiling (23 rows: partial 16x16 tiles), fp16 table
+    (GRID_CASES[0], 1.5, 0, False),      # bound not a power of two -> IEEE division
+    (GRID_CASES[4], 1.0, 24, False),     # tiled grid, generic modulo
+    (GRID_CASES[5], 1.0, 0, False),      # align_corners + smoothstep
+])
+def test_grid_composite_matches_oracle(gpu, orc, cfg, bound, tile_w, f16):
+    """sn_rm_grid_composite == composite(weights, grid(xyzs, bound)) (renderer.py:301-302 + 361)."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    rng = np.random.default_rng(91)
+    N = tile_w * 23 if tile_w else 777
+    Tn = 9
+    offs, pls = orc.grid_layout(3, cfg["L"], cfg["C"], 2, 16, cfg["log2T"], cfg["desired"])
+    emb = rng.uniform(-1, 1, (int(offs[-1]), cfg["C"])).astype(np.float32)
+    if f16:
+        emb = emb.astype(np.float16)
+    xyz = rng.uniform(-1.08 * bound, 1.08 * bound, (N, Tn, 3)).astype(np.float32)     # a few samples out of range
+    w = rng.uniform(0, 1, (N, Tn)).astype(np.float32)
+    x01 = ((xyz.reshape(-1, 3) + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
+    feat, _ = orc.grid_encode_forward(x01, emb, offs, pls, 16, False, cfg["gridtype"], cfg["ac"], cfg["interp"])
+    want = (w[..., None].astype(np.float64) * feat.reshape(N, Tn, -1).astype(np.float64)).sum(1)
+    enc = GridEncoder(3, cfg["L"], cfg["C"], 2, 16, cfg["log2T"], cfg["desired"],
+                      gridtype="hash" if cfg["gridtype"] == 0 else "tiled", align_corners=cfg["ac"],
+                      interpolation="linear" if cfg["interp"] == 0 else "smoothstep").to(gpu)
+    got = rm.grid_composite(T(w, gpu), T(xyz, gpu), enc, bound, tile_w=tile_w, table=T(emb, gpu))
+    assert got.shape == (N, cfg["L"] * cfg["C"]) and got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+    assert rm.grid_composite(T(w[:0], gpu), T(xyz[:0], gpu), enc, bound, table=T(emb, gpu)).shape == (0, cfg["L"] * cfg["C"])
+
+
+@pytest.mark.parametrize("kind,N", [("samvit", 1000), ("samvit", 1), ("mask", 777), ("mask", 128 * 3)])
+def test_wide_mlp_matches_oracle_and_torch(gpu, orc, kind, N):
+    """sn_mlp_wide_forward (matrix cores, fp16 hi/lo split products) vs the oracle's fp32 fmaf chains and vs the
+    torch module on the GPU: SkipConnMLP + LayerNorm of the SAM head (network.py:101-116) and the mask head's
+    143-256-256-n_inst MLP (network.py:118-123).  fp32 contract: 1e-4 (north_star); measured ~1e-6."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(0)
+    if kind == "samvit":
+        mlp = SkipConnMLP(163, 256, 256, 5, skip_layers=[2], bias=True).to(gpu)
+        ln = torch.nn.LayerNorm(256).to(gpu)
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.2, 0.2)
+    else:
+        mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+        ln = None
+    with torch.no_grad():
+        for i, lin in enumerate(mlp.net):        # deterministic, well-scaled weights (activations stay O(1))
+            lin.weight.copy_(T(synth.linear_weight(lin.weight.shape[0], lin.weight.shape[1], 300 + i, 2.0), gpu))
+            if lin.bias is not None:
+                lin.bias.copy_(T(synth.hash_uniform((lin.bias.shape[0],), 400 + i, -0.1, 0.1), gpu))
+    x = T(np.random.default_rng(3).standard_normal((N, mlp.dim_in)).astype(np.float32), gpu)
+    got = rm.mlp_forward(x, mlp, ln)
+    with torch.no_grad():
+        ref_t = mlp(x)
+        if ln is not None:
+            ref_t = ln(ref_t)
+    ws = [l.weight.detach().cpu().numpy() for l in mlp.net]
+    bs = [l.bias.detach().cpu().numpy() if l.bias is not None else None for l in mlp.net]
+    om = orc.make_mlp(ws, bs if kind == "samvit" else None, "leaky", mlp.skip_layers)
+    ref_o = orc.mlp_forward(om, x.cpu().numpy())
+    if ln is not None:
+        mu = ref_o.astype(np.float64).mean(-1, keepdims=True)
+        var = ((ref_o - mu) ** 2).mean(-1, keepdims=True)
+        ref_o = ((ref_o - mu) / np.sqrt(var + ln.eps) * ln.weight.detach().cpu().numpy() + ln.bias.detach().cpu().numpy()).astype(np.float32)
+    assert got.shape == ref_t.shape
+    scale = float(np.abs(ref_o).max())
+    assert np.abs(got.cpu().numpy() - ref_o).max() <= 2e-5 * max(scale, 1.0), "vs oracle"
+    assert float((got - ref_t).abs().max()) <= 1e-4 * max(scale, 1.0), "vs torch / rocBLAS"

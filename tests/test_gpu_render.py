@@ -326,3 +326,22 @@ def test_unsupported_configurations_fail_loudly(gpu, orc):
         rm.render_rays(plan, torch.rand(8, 3, device=gpu), torch.rand(8, 3, device=gpu))
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         rm.render_rays(rm.RenderPlan(model, [128, 64, 32]), torch.rand(8, 3), torch.rand(8, 3))
+
+
+def test_feature_stage_equals_grid_composite(gpu, orc):
+    """The in-render feature stage (f_sam of renderer.py:301-302 + 361) == sn_rm_grid_composite on the last stage's
+    exported weights / positions, bit for bit (same position code, same accumulation order), for both schedules."""
+    from sanerf_hq_amd import raymarching as rm
+    for steps in ([128, 64, 32], [24]):
+        params = synthetic_params(steps, heads=True, seed=5)
+        model = product_model(params, steps, True, gpu)
+        H, W = 40, 56
+        _, _, ro, rd = camera_rays(orc, H, W)
+        plan = rm.RenderPlan(model, steps, feat_encoder=model.s_grid)
+        out = rm.render_rays(plan, torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu), tile_w=W,
+                             want=["weights_last", "xyzs_last"])
+        ref = rm.grid_composite(out["weights_last"], out["xyzs_last"], model.s_grid, model.bound, tile_w=W)
+        assert out["f_feat"].shape == (H * W, 128)
+        assert torch.equal(out["f_feat"], ref)
+        plain = rm.render_rays(rm.RenderPlan(model, steps), torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu), tile_w=W)
+        assert torch.equal(plain["image"], out["image"]) and "f_feat" not in plain
