@@ -48,6 +48,11 @@ def gather_image(local: torch.Tensor, H: int, W: int, group: Optional[dist.Proce
     max_rows = max(e - b for b, e in bands)
     b, e = bands[rank]
     assert local.shape[0] == (e - b) * W, f"rank {rank}: expected {(e - b) * W} rays, got {local.shape[0]}"
+    if all(e2 - b2 == max_rows for b2, e2 in bands):
+        # equal bands (H a multiple of 16*world, e.g. the 800 x 800*N bench image): gather straight into the image
+        out = local.new_empty(H * W, K)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     send = local.new_zeros(max_rows * W, K)
     send[: local.shape[0]] = local
     recv = [torch.empty_like(send) for _ in range(world)]
