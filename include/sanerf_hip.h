@@ -177,6 +177,10 @@ typedef struct sn_render_cfg {
      * last stage's samples -- the SAM head's f_sam with feat_grid = s_grid (network.py:103) */
     sn_grid_desc feat_grid;
     int32_t      with_feat;
+    /* opt-in, NOT reference behaviour (the reference always evaluates every sample): in the last stage a wave (8x8
+     * pixels) stops marching once the transmittance of all its rays is below this value; 0 = off (default).  Every
+     * output changes by at most ~eps * |feature|.  Ignored when per-sample outputs or the feature stage are on. */
+    float        early_stop_eps;
 } sn_render_cfg;
 
 typedef struct sn_render_io {

@@ -40,7 +40,7 @@ class RenderCfg(C.Structure):
                 ("grid", GridDesc), ("grid_mlp", MlpDesc), ("view_mlp", MlpDesc),
                 ("sh_degree", C.c_uint32), ("aabb", C.c_float * 6), ("min_near", C.c_float), ("bound", C.c_float),
                 ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float),
-                ("feat_grid", GridDesc), ("with_feat", C.c_int32)]
+                ("feat_grid", GridDesc), ("with_feat", C.c_int32), ("early_stop_eps", C.c_float)]
 
 
 class RenderIO(C.Structure):

@@ -539,6 +539,7 @@ struct FinalArgs {
     float *image, *depth, *wsum;
     float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
     float *w_out;                // scratch [T][Npad] for the feature stage, or NULL
+    float stop_cum;              // > 0: a wave leaves the march once every lane's optical depth exceeds this (-ln eps)
 };
 
 // A-operand packing for the 32->64->64->16 MLP on v_mfma_f32_32x32x2_f32.
@@ -808,7 +809,9 @@ __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, c
 
 enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 
-template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K>
+// AUX: the instantiation that also serves the feature stage (weights -> scratch) and the opt-in early termination;
+// the plain one carries neither (one spilled register less in the march of the headline configuration)
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false>
 __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(FinalArgs a) {
     constexpr bool MFMA = MODE != MLP_VALU;
     constexpr int IN = L * C;
@@ -973,7 +976,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         dep = __builtin_fmaf(w, tmid, dep);
 #pragma unroll
         for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, h[1 + c], fimg[c]);
-        if (a.w_out) a.w_out[(size_t)j * Npad + r] = w;
+        if constexpr (AUX) { if (a.w_out) a.w_out[(size_t)j * Npad + r] = w; }
         if (ok) {
             if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
             if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
@@ -983,6 +986,9 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
 #pragma unroll
                 for (int c = 0; c < GEO; ++c) q[c] = h[1 + c]; }
         }
+        // opt-in early termination (not reference behaviour): all 64 rays of the wave are opaque to
+        // within eps -> the remaining samples could add at most eps to any weight sum
+        if constexpr (AUX) { if (a.stop_cum > 0.0f && __all((float)cum > a.stop_cum)) break; }
         rb_prev = rb_next;
         if constexpr (MODE != MLP_F16X3) {   // un-pipelined modes: geometry of the next sample
             const uint32_t jn = j + 2u <= T ? j + 2u : T;
@@ -1414,31 +1420,42 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * 15 : nullptr;
         fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
         fa.w_out = cfg->with_feat ? w_scr[S - 1] : nullptr;
+        // early termination is honoured only when nothing per-sample leaves the kernel (those tensors would be left
+        // unwritten past the stop)
+        const bool per_sample_out = fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo || fa.w_out;
+        fa.stop_cum = (cfg->early_stop_eps > 0.0f && cfg->early_stop_eps < 1.0f && !per_sample_out) ? -logf(cfg->early_stop_eps) : 0.0f;
         const bool f16 = cfg->grid.table_dtype == SN_F16;
         {
         ProfScope ps_final(st, PK_FINAL);
-#define SN_LAUNCH_FINAL(MODE_, KK, LDS_FLOATS)                                                                                  \
+#define SN_LAUNCH_FINAL_T(TT_, MODE_, KK, AUX_, LDS_FLOATS)                                                                      \
         do {                                                                                                                 \
             const size_t lds_bytes = (size_t)(LDS_FLOATS) * sizeof(float);                                                   \
-            if (f16) {                                                                                                       \
-                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_, KK>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
-                hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MODE_, KK>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
-            } else {                                                                                                         \
-                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_, KK>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
-                hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MODE_, KK>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
-            }                                                                                                                \
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MODE_, KK, AUX_>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                      \
+            hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MODE_, KK, AUX_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
         } while (0)
+#define SN_LAUNCH_FINAL(MODE_, KK, LDS_FLOATS)                                                                                  \
+        do {                                                                                                                 \
+            if (f16) SN_LAUNCH_FINAL_T(__half, MODE_, KK, true, LDS_FLOATS); else SN_LAUNCH_FINAL_T(float, MODE_, KK, true, LDS_FLOATS); \
+        } while (0)
+#define SN_LAUNCH_FINAL_AUX(MODE_, KK, LDS_FLOATS)   /* default mode only: plain instantiation unless the extras are on */ \
+        do {                                                                                                                 \
+            if (aux) SN_LAUNCH_FINAL(MODE_, KK, LDS_FLOATS);                                                                   \
+            else if (f16) SN_LAUNCH_FINAL_T(__half, MODE_, KK, false, LDS_FLOATS);                                             \
+            else SN_LAUNCH_FINAL_T(float, MODE_, KK, false, LDS_FLOATS);                                                       \
+        } while (0)
+        const bool aux = fa.w_out != nullptr || fa.stop_cum > 0.0f;
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = dense_prefix(gl_main);
         if (mlp_mode == MLP_F16X3) {
-            if (Kmain == 5) SN_LAUNCH_FINAL(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
-            else SN_LAUNCH_FINAL(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);
+            if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
+            else SN_LAUNCH_FINAL_AUX(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);
         } else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, -1, PACK_FLOATS + 4 * 32 * 64);       // 64 KiB
         else SN_LAUNCH_FINAL(MLP_VALU, -1, 2 * 64 * 256 + VIEW_W);                                      // 136 KiB
+#undef SN_LAUNCH_FINAL_AUX
 #undef SN_LAUNCH_FINAL
+#undef SN_LAUNCH_FINAL_T
         SN_LAUNCH_CHECK("k_final_stage");
         }
         if (cfg->with_feat) {

@@ -133,7 +133,8 @@ class NeRFRenderer(nn.Module):
                self.render_table_dtype, self.training, self.s_grid.embeddings.data_ptr() if with_feat else None)
         if self._plan is None or self._plan_key != key:
             self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype,
-                                       feat_encoder=self.s_grid if with_feat else None)
+                                       feat_encoder=self.s_grid if with_feat else None,
+                                       early_stop_eps=float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0))
             ab = (self.aabb_train if self.training else self.aabb_infer).detach().cpu().tolist()
             for i in range(6):
                 self._plan.cfg.aabb[i] = ab[i]

@@ -223,7 +223,8 @@ class RenderPlan:
     table_dtype=torch.float16 renders from half-precision copies of the hash tables (made here,
     the module keeps its fp32 parameters); arithmetic stays fp32 either way."""
 
-    def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32, feat_encoder=None):
+    def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32, feat_encoder=None,
+                 early_stop_eps: float = 0.0):
         self.keep: list = []
         cfg = _lib.RenderCfg()
         S = len(num_steps)
@@ -261,6 +262,7 @@ class RenderPlan:
             _fill_grid(cfg.feat_grid, feat_encoder, table_of(feat_encoder))
             cfg.with_feat = 1
             self.feat_dim = feat_encoder.output_dim
+        cfg.early_stop_eps = float(early_stop_eps)      # opt-in transmittance early-out of the last stage (0 = reference behaviour)
         self.cfg = cfg
         self.num_steps = [int(t) for t in num_steps]
         self.geo = model.geom_feat_dim

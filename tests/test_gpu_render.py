@@ -345,3 +345,27 @@ def test_feature_stage_equals_grid_composite(gpu, orc):
         assert torch.equal(out["f_feat"], ref)
         plain = rm.render_rays(rm.RenderPlan(model, steps), torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu), tile_w=W)
         assert torch.equal(plain["image"], out["image"]) and "f_feat" not in plain
+
+
+def test_early_stop_is_opt_in_and_bounded(gpu, orc):
+    """SURVEY 8f-1: transmittance early-out of the last stage.  Off by default (bit-identical to the plain plan);
+    switched on, what is dropped is the tail of the ray whose total weight is below eps: weights_sum moves by < eps
+    and every composited feature by < eps * max|feature|."""
+    from sanerf_hq_amd import raymarching as rm
+    steps = [128]
+    params = synthetic_params(steps, seed=3, gain=40.0)          # sigma is ~0 or huge: about half of all samples lie behind an opaque one
+    model = product_model(params, steps, False, gpu)
+    H, W = 64, 64
+    _, _, ro, rd = camera_rays(orc, H, W)
+    ro, rd = torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu)
+    base = {k: v.clone() for k, v in rm.render_rays(rm.RenderPlan(model, steps), ro, rd, tile_w=W, want=["f_image", "geo_feat_last"]).items()}
+    off = rm.render_rays(rm.RenderPlan(model, steps, early_stop_eps=0.0), ro, rd, tile_w=W)
+    assert torch.equal(off["image"], base["image"]) and torch.equal(off["depth"], base["depth"])
+    eps = 1e-4
+    on = rm.render_rays(rm.RenderPlan(model, steps, early_stop_eps=eps), ro, rd, tile_w=W, want=["f_image"])
+    assert float((on["weights_sum"] - base["weights_sum"]).abs().max()) <= 1.01 * eps
+    fmax = float(base["geo_feat_last"].abs().max())
+    assert float((on["f_image"] - base["f_image"]).abs().max()) <= 1.01 * eps * max(fmax, 1.0)
+    # per-sample outputs requested -> the early-out is ignored (they must be complete)
+    full = rm.render_rays(rm.RenderPlan(model, steps, early_stop_eps=eps), ro, rd, tile_w=W, want=["weights"])
+    assert torch.equal(full["image"], base["image"])

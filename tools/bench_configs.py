@@ -56,6 +56,18 @@ def main():
     out["C3_sam_head_400x400"] = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
     del model
     torch.cuda.empty_cache()
+    # ---- opt-in early termination on an opaque field: 800x800, [128], MLP gain 40 (sigma ~0 or huge) ----
+    from helpers import product_model  # noqa: E402
+    steps = [128]
+    dense = product_model(synthetic_params(steps, seed=3, gain=40.0), steps, False, dev)
+    H = W = 800
+    ro8, rd8 = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
+    p_off, p_on = rm.RenderPlan(dense, steps), rm.RenderPlan(dense, steps, early_stop_eps=1e-4)
+    t_off = timeit(lambda: rm.render_rays(p_off, ro8, rd8, tile_w=W))
+    t_on = timeit(lambda: rm.render_rays(p_on, ro8, rd8, tile_w=W))
+    d = float((rm.render_rays(p_on, ro8, rd8, tile_w=W)["weights_sum"] - rm.render_rays(p_off, ro8, rd8, tile_w=W)["weights_sum"]).abs().max())
+    out["early_stop_opaque_field_800x800_flat128"] = {"ms_off": round(t_off * 1e3, 3), "ms_eps_1e-4": round(t_on * 1e3, 3), "max_abs_weights_sum_diff": d}
+    del dense
     # ---- C5 ----
     model = build(False, True, dev).train()
     for n_, p in model.named_parameters():
