@@ -369,3 +369,44 @@ def test_early_stop_is_opt_in_and_bounded(gpu, orc):
     # per-sample outputs requested -> the early-out is ignored (they must be complete)
     full = rm.render_rays(rm.RenderPlan(model, steps, early_stop_eps=eps), ro, rd, tile_w=W, want=["weights"])
     assert torch.equal(full["image"], base["image"])
+
+
+def test_rgb_training_step_vs_reference_fixture(gpu, orc):
+    """RGB-mode training step (trainer.py:360-392): MSE + lambda_proposal * proposal_loss
+    (renderer.py:30-57) with every parameter trainable; loss terms and gradients against the reference's autograd
+    (tests/golden/train_rgb.npz, tools/gen_golden.py:fx_train_rgb)."""
+    g = golden("train_rgb")
+    params = params_from_spec(spec_of(g))
+    from helpers import make_opt
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    opt = make_opt()
+    opt.lambda_proposal, opt.lambda_distort = 1.0, 0.0
+    model = NeRFNetwork(opt)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    assert not unexpected
+    model = model.to(gpu).train()
+    out = model.render(T(g["rays_o"], gpu), T(g["rays_d"], gpu), staged=False, bg_color=1, perturb=False, update_proposal=True)
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), g["image"], rtol=0, atol=RGB_TOL)
+    assert abs(out["proposal_loss"].item() - float(g["proposal_loss"])) < 1e-5
+    mse = torch.nn.MSELoss(reduction="none")(out["image"], T(g["gt"], gpu)).mean()
+    assert abs(mse.item() - float(g["mse"])) < 1e-5
+    (mse + opt.lambda_proposal * out["proposal_loss"]).backward()
+
+    def close(got, ref, what):     # north_star: grads within 1e-3 of the reference (relative L2 of each tensor)
+        got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert rel < 1e-3, f"{what}: relative L2 error {rel:.2e}"
+
+    seen = 0
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        if name.endswith("embeddings"):
+            rows = T(g[f"rows:{name}"], gpu)
+            close(p.grad[rows].cpu().numpy(), g[f"grad_rows:{name}"], name + " sampled rows")
+            touched = int((p.grad.abs().sum(-1) > 0).sum())
+            assert abs(touched - int(g[f"touched:{name}"])) <= 2e-4 * int(g[f"touched:{name}"]) + 1, (name, touched)
+            assert abs(p.grad.double().abs().sum().item() - float(g[f"abssum:{name}"])) < 1e-3 * float(g[f"abssum:{name}"])
+        else:
+            close(p.grad.cpu().numpy(), g[f"grad:{name}"], name)
+        seen += 1
+    assert seen == 13   # grid + 3 grid_mlp + 3 view_mlp + 2 proposal grids + 2x2 prop_mlp

@@ -95,6 +95,32 @@ def main():
     t_step = timeit(step)
     out["C5_mask_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_step * 1e3, 3),
                                                "rays_per_s_fwd_bwd": round(N / t_fb, 1)}
+    # ---- RGB-mode training step (trainer.py:360-392): 4096 rays, [128,64,32], everything trainable, MSE + proposal loss ----
+    del model
+    torch.cuda.empty_cache()
+    opt = make_opt(with_sam=False, with_mask=False)
+    opt.lambda_proposal, opt.lambda_distort = 1.0, 0.0
+    model = NeRFNetwork(opt)
+    params = synthetic_params([128, 64, 32], seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    model = model.to(dev).train()
+    gt = torch.from_numpy(synth.hash_uniform((N, 3), 42, 0.0, 1.0)).to(dev)
+    optim = torch.optim.Adam(model.get_params(1e-2), eps=1e-15)
+
+    def rgb_fwd_bwd():
+        optim.zero_grad(set_to_none=True)
+        o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=True)
+        loss = torch.nn.functional.mse_loss(o["image"], gt) + opt.lambda_proposal * o["proposal_loss"]
+        loss.backward()
+        return loss
+
+    def rgb_step():
+        rgb_fwd_bwd()
+        optim.step()
+    t_fb = timeit(rgb_fwd_bwd)
+    t_st = timeit(rgb_step)
+    out["RGB_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_st * 1e3, 3),
+                                          "rays_per_s_step": round(N / t_st, 1)}
     print(json.dumps(out))
 
 

@@ -575,6 +575,51 @@ def fx_train(rr, nn_, ru):
     np.savez_compressed(os.path.join(GOLD, "train_c5.npz"), **sav)
 
 
+def fx_train_rgb(rr, nn_, ru):
+    """RGB-mode training step (trainer.py:360-392): everything trainable, MSE(image, gt) + lambda_proposal *
+    proposal_loss (renderer.py:30-57); the distortion term needs the absent third-party torch_efficient_distloss
+    and is switched off.  perturb=False so that the step is deterministic.  256 rays."""
+    print("[train:rgb] radiance-field MSE + proposal-loss step, 256 rays")
+    opt = make_opt(num_steps=[128, 64, 32], with_sam=False, with_mask=False)
+    opt.lambda_proposal, opt.lambda_distort = 1.0, 0.0
+    torch.manual_seed(0)
+    model = nn_.NeRFNetwork(opt)
+    spec = param_spec_for(model, 777, 1.0, 4.0)
+    load_params(model, spec)
+    model.train()
+    H = W = 256
+    pose = synth.orbit_pose(1.2, 15.0, 100.0)
+    fx, fy, cx, cy = synth.pinhole_intrinsics(H, W)
+    N = 256
+    pix = (synth.hash_u01(N, 41) * (H * W)).astype(np.int64)
+    res = ru.get_rays(torch.from_numpy(pose)[None], np.array([fx, fy, cx, cy], dtype=np.float32), H, W, -1)
+    ro = res["rays_o"].reshape(-1, 3)[pix].contiguous(); rd = res["rays_d"].reshape(-1, 3)[pix].contiguous()
+    gt = torch.from_numpy(synth.hash_uniform((N, 3), 42, 0.0, 1.0))
+    out = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=True)
+    mse = torch.nn.MSELoss(reduction="none")(out["image"], gt).mean()
+    loss = mse + opt.lambda_proposal * out["proposal_loss"]
+    loss.backward()
+    sav = dict(rays_o=np_(ro), rays_d=np_(rd), gt=np_(gt), pixels=pix, pose=pose, image=np_(out["image"]),
+               proposal_loss=np.array(out["proposal_loss"].item()), mse=np.array(mse.item()), loss=np.array(loss.item()),
+               param_spec=np.array(json.dumps(spec)))
+    for name, p in model.named_parameters():
+        g = p.grad
+        assert g is not None, name
+        if name.endswith("embeddings"):      # tables: a deterministic sample of touched rows + whole-table checksums
+            touched = torch.nonzero(g.abs().sum(-1) > 0).squeeze(-1)
+            pick = np.unique((synth.hash_u01(2048, 11) * touched.numel()).astype(np.int64))
+            rows = touched[torch.from_numpy(pick)]
+            sav[f"rows:{name}"] = np_(rows).astype(np.int64)
+            sav[f"grad_rows:{name}"] = np_(g[rows])
+            sav[f"touched:{name}"] = np.array(touched.numel())
+            sav[f"abssum:{name}"] = np.array(g.double().abs().sum().item())
+            sav[f"sum:{name}"] = np.array(g.double().sum().item())
+        else:
+            sav[f"grad:{name}"] = np_(g)
+    print(f"   mse {mse.item():.6f} proposal {out['proposal_loss'].item():.6f}")
+    np.savez_compressed(os.path.join(GOLD, "train_rgb.npz"), **sav)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -598,6 +643,8 @@ def main():
         fx_c1(rr, nn_, enc)
     if on("train"):
         fx_train(rr, nn_, ru)
+    if on("train_rgb"):
+        fx_train_rgb(rr, nn_, ru)
 
 
 if __name__ == "__main__":
