@@ -74,9 +74,10 @@ int sn_grid_encode_backward(const float *grad, const float *inputs, const void *
                             int layout, sn_stream_t stream);
 /* Same result as sn_grid_encode_backward (embedding gradient only) without the reference's atomics-per-corner scatter:
  * (row, contribution) pairs are radix-sorted and every table row is then written by one thread (grid_sorted.hip).
- * D in {2,3}; B < 2^24; B*max_level*2^D < 2^31; workspace >= sn_grid_backward_sorted_workspace_bytes() device bytes;
- * grad_embeddings zero-initialised by the caller.  ~6x faster than the atomic path at the sizes of the mask-field step. */
-size_t sn_grid_backward_sorted_workspace_bytes(uint32_t B, uint32_t D, uint32_t max_level);
+ * D in {2,3}; B*max_level*2^D < 2^31; workspace >= sn_grid_backward_sorted_workspace_bytes() device bytes (keys,
+ * indices and the B*max_level*2^D*C pre-multiplied contributions), 16-byte aligned like grad; grad_embeddings
+ * zero-initialised by the caller.  Several times faster than the atomic path at the sizes of the training steps. */
+size_t sn_grid_backward_sorted_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level);
 int sn_grid_encode_backward_sorted(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
                                    float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,

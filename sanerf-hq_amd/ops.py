@@ -127,7 +127,7 @@ class _grid_encode(Function):
         grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
         lib = _lib.lib()
         if _use_sorted_backward(B, D, max_level, dy_dx):
-            need = int(lib.sn_grid_backward_sorted_workspace_bytes(B, D, max_level))
+            need = int(lib.sn_grid_backward_sorted_workspace_bytes(B, D, Cc, max_level))
             ws = _sorted_workspace(need, table.device)
             _lib.check(lib.sn_grid_encode_backward_sorted(
                 _lib.dev(grad, "grad"), _lib.dev(inputs, "inputs"), _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"),
