@@ -1,0 +1,50 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/gpu_profile_all.sh [round-dir]   -> gpurun_out/<round-dir>/*  (copy what is judged into profiles/<round-dir>/)
+# Regenerates every profile artefact of the round from the code as it is: rocprofv3 --kernel-trace --stats summaries of the
+# bench line(s) and of the other configurations, the --pmc passes of the dominant kernel (separate passes, kernel-trace only),
+# the HBM-side traffic json bench.py reads, the micro-benchmarks and the un-profiled bench lines.
+R=${1:-r01}; out=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+root=$GRAFT_REPO_ROOT
+stats() {   # name, command...
+  local name=$1; shift
+  rm -rf $out/_t; rocprofv3 --kernel-trace --stats -d $out/_t -o t -- "$@" > $out/${name}_under_rocprof.log 2>&1
+  python $root/tools/rocpd_summary.py stats $out/_t/t_results.db > $out/kernel_stats_${name}.txt 2>&1
+  rm -rf $out/_t
+}
+for sch in flat128 ref; do for tb in f32 f16; do
+  stats ${sch}_${tb} python $root/bench.py --steps 20 --warmup 5 --schedule $sch --tables $tb --no-cpu-baseline --primary-only
+  grep "^{" $out/${sch}_${tb}_under_rocprof.log | tail -1 > $out/bench_under_rocprof_${sch}_${tb}.json; rm -f $out/${sch}_${tb}_under_rocprof.log
+done; done
+stats c3_sam_head python $root/tools/c3_profile.py
+stats train_rgb python $root/tools/train_profile.py rgb
+stats train_mask python $root/tools/train_profile.py mask
+rm -f $out/*_under_rocprof.log
+# PMC passes (primary configuration of each schedule, fp32 tables)
+for sch in flat128 ref; do
+  rm -f $out/pmc_$sch.txt
+  while read -r c; do
+    [ -z "$c" ] && continue
+    rm -rf $out/_p; rocprofv3 --pmc $c --kernel-trace -d $out/_p -o pmc -- python $root/bench.py --steps 2 --warmup 1 --schedule $sch --no-cpu-baseline --primary-only > /dev/null 2>&1
+    echo "== pass: $c" >> $out/pmc_$sch.txt
+    python $root/tools/rocpd_summary.py pmc $out/_p/pmc_results.db | grep -v k_pack >> $out/pmc_$sch.txt 2>&1
+    rm -rf $out/_p
+  done <<LIST
+MfmaUtil VALUBusy
+GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES
+SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU
+TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum
+TCC_HIT_sum TCC_MISS_sum
+FETCH_SIZE
+WRITE_SIZE
+LIST
+done
+python $root/tools/traffic_from_pmc.py $out > $out/latest_traffic.json
+# micro-benchmarks
+[ -x $root/tools/ubench/gathers_ub ] && timeout 300 $root/tools/ubench/gathers_ub > $out/ubench_gathers.txt 2>&1
+python $root/tools/mlp_bench.py > $out/ubench_head_mlp.txt 2>&1
+# un-profiled numbers
+cd $root
+python tools/bench_configs.py 2>/dev/null | tail -1 > $out/bench_configs.json
+python bench.py > $out/bench_default.json 2> $out/bench_default.err
+ls -la $out

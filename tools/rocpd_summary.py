@@ -11,7 +11,8 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     import re
-    for key in ("k_final_stage", "k_prop_stage", "k_pack_grid_mlp_f16", "k_pack_grid_mlp", "k_grid_forward", "k_grid_backward",
+    for key in ("k_final_stage", "k_prop_stage", "k_feat_stage", "k_pack_grid_mlp_f16", "k_pack_grid_mlp", "k_pack_mlp_wide", "k_mlp_wide",
+                "k_grid_composite", "k_grid_forward", "k_grid_backward", "k_bwd_reduce", "k_bwd_keys",
                 "k_composite", "k_generate_rays", "k_sample_pdf", "k_weights"):
         if key in name:
             tag = ""
@@ -19,6 +20,8 @@ def short(name: str) -> str:
                 m = re.search(r"Li32ELi(\d)ELi(n?\d+)E", name)
                 if m:
                     tag = {"0": "<valu>", "1": "<mfma_f32>", "2": "<mfma_f16x3>"}[m.group(1)]
+                if "ELb1EEE" in name:
+                    tag += "<aux>"
             if key == "k_prop_stage":
                 m = re.search(r"Li16ELi(n?\d+)E", name)
                 if m:

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""profiles/<round>/pmc_<schedule>.txt -> the HBM-side bytes per launch of the dominant kernel (profiles/latest_traffic.json,
+read by bench.py for roofline.traffic).  Follows MI355X_MICROARCH.md's HBM section: separate --pmc passes; on gfx950
+FETCH_SIZE tallies 128-byte requests at 64 B, so read bytes = 128 B x TCC_EA0_RDREQ_128B + 64 B x (RDREQ - RDREQ_128B)
+(= 2 x FETCH_SIZE KiB when every request is 128 B); WRITE_SIZE KiB as reported."""
+import json
+import os
+import re
+import sys
+
+
+def parse(path):
+    vals = {}
+    for line in open(path):
+        m = re.match(r"(\S+)\s+(\S+)\s+dispatches=\s*(\d+) mean=(\S+)", line)
+        if m and m.group(1).startswith("k_final_stage"):
+            vals[m.group(2)] = float(m.group(4))
+    return vals
+
+
+def main():
+    d = sys.argv[1]
+    out = {}
+    for sch in ("flat128", "ref"):
+        p = os.path.join(d, f"pmc_{sch}.txt")
+        if not os.path.exists(p):
+            continue
+        v = parse(p)
+        if "TCC_EA0_RDREQ_sum" not in v:
+            continue
+        rd, rd128 = v["TCC_EA0_RDREQ_sum"], v.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        read_b = 128 * rd128 + 64 * (rd - rd128)
+        write_b = v.get("WRITE_SIZE", 0.0) * 1024
+        out[f"{sch}_f32"] = {
+            "rays": 640000, "kernel": "k_final_stage",
+            "hbm_read_bytes_per_launch": int(read_b), "hbm_write_bytes_per_launch": int(write_b),
+            "hbm_bytes_per_launch": int(read_b + write_b),
+            "raw": {"TCC_EA0_RDREQ_sum": rd, "TCC_EA0_RDREQ_128B_sum": rd128, "FETCH_SIZE_KiB": v.get("FETCH_SIZE"),
+                    "WRITE_SIZE_KiB": v.get("WRITE_SIZE"), "TCC_HIT_sum": v.get("TCC_HIT_sum"), "TCC_MISS_sum": v.get("TCC_MISS_sum")},
+            "method": f"separate rocprofv3 --pmc passes ({os.path.basename(d)}/pmc_{sch}.txt); read bytes = 128 B x TCC_EA0_RDREQ_128B + "
+                      "64 B x the rest (= 2 x FETCH_SIZE KiB: the gfx950 correction of MI355X_MICROARCH.md, FETCH_SIZE tallies 128-B requests "
+                      "at 64 B); WRITE_SIZE KiB as reported (<0.1% of the total)"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
