@@ -45,12 +45,27 @@ def generate_rays(pose, intrinsics, H: int, W: int, device="cuda", row_begin: in
     return rays_o, rays_d
 
 
+def _host_values(t) -> list:
+    """Host copy of a small device tensor, memoised on the tensor object (keyed by its in-place version counter): a
+    device->host read per call would put a synchronisation into every training step and forbids graph capture."""
+    if not torch.is_tensor(t):
+        return list(t)
+    cached = getattr(t, "_sn_host_values", None)
+    if cached is None or cached[0] != t._version:
+        cached = (t._version, t.detach().cpu().tolist())
+        try:
+            t._sn_host_values = cached
+        except AttributeError:
+            pass
+    return cached[1]
+
+
 def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.05):
     rays_o, rays_d = _flat3(rays_o), _flat3(rays_d)
     N = rays_o.shape[0]
     nears = torch.empty(N, 1, device=rays_o.device, dtype=torch.float32)
     fars = torch.empty(N, 1, device=rays_o.device, dtype=torch.float32)
-    ab = aabb.detach().cpu().tolist() if torch.is_tensor(aabb) else list(aabb)
+    ab = _host_values(aabb)
     _lib.check(_lib.lib().sn_rm_near_far_from_aabb(_lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.host_f32(ab),
                                                    float(min_near), N, _lib.dev(nears, "nears"), _lib.dev(fars, "fars"),
                                                    _lib.stream()), "near_far_from_aabb")
