@@ -339,3 +339,20 @@ def test_wide_mlp_matches_oracle_and_torch(gpu, orc, kind, N):
     scale = float(np.abs(ref_o).max())
     assert np.abs(got.cpu().numpy() - ref_o).max() <= 2e-5 * max(scale, 1.0), "vs oracle"
     assert float((got - ref_t).abs().max()) <= 1e-4 * max(scale, 1.0), "vs torch / rocBLAS"
+
+
+def test_wide_mlp_rejects_unsupported_shapes(gpu):
+    """sn_mlp_wide_forward states its limits through the error channel instead of computing something else."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf.network import MLP, SkipConnMLP
+    x = torch.randn(10, 32, device=gpu)
+    with pytest.raises(RuntimeError, match="hidden width must be 256"):
+        rm.mlp_forward(x, SkipConnMLP(32, 4, 64, 3).to(gpu))
+    with pytest.raises(RuntimeError, match="output width"):
+        rm.mlp_forward(x, SkipConnMLP(32, 300, 256, 2).to(gpu))
+    y = rm.mlp_forward(x, MLP(32, 5, 256, 2, bias=False).to(gpu))          # ReLU perceptron (network.py:9-29) also maps onto it
+    assert y.shape == (10, 5)
+    ref = MLP(32, 5, 256, 2, bias=False)
+    torch.manual_seed(1); m = MLP(32, 5, 256, 2, bias=False).to(gpu)
+    with torch.no_grad():
+        np.testing.assert_allclose(rm.mlp_forward(x, m).cpu().numpy(), m(x).cpu().numpy(), rtol=0, atol=2e-5)

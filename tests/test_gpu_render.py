@@ -345,6 +345,14 @@ def test_feature_stage_equals_grid_composite(gpu, orc):
         assert torch.equal(out["f_feat"], ref)
         plain = rm.render_rays(rm.RenderPlan(model, steps), torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu), tile_w=W)
         assert torch.equal(plain["image"], out["image"]) and "f_feat" not in plain
+        # half-precision table copies (RenderPlan(table_dtype=float16)): same statement with 16-byte rows
+        plan16 = rm.RenderPlan(model, steps, torch.float16, feat_encoder=model.s_grid)
+        out16 = rm.render_rays(plan16, torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu), tile_w=W,
+                               want=["weights_last", "xyzs_last"])
+        ref16 = rm.grid_composite(out16["weights_last"], out16["xyzs_last"], model.s_grid, model.bound, tile_w=W,
+                                  table=model.s_grid.embeddings.detach().half())
+        assert torch.equal(out16["f_feat"], ref16)
+        assert float((out16["f_feat"] - out["f_feat"]).abs().max()) < 2e-2 * float(out["f_feat"].abs().max())
 
 
 def test_early_stop_is_opt_in_and_bounded(gpu, orc):
