@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsanerf_hip.so")
+LIB_PATH = os.environ.get("SN_LIB") or os.path.join(_PKG, "libsanerf_hip.so")   # SN_LIB: A/B a differently built library
 CSRC = os.path.join(_PKG, "csrc")
 
 MAX_LEVELS, MAX_LAYERS, MAX_STAGES = 32, 8, 4

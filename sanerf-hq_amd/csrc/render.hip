@@ -133,7 +133,32 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <typename T, int C>
 struct Corner { float v[C]; };
 
-template <typename T, int C, int KIND, bool PAIR>
+// XSWAP (hashed fine levels of the final stage): the two x-corners of a cell sit in the same 128-byte line 15 times
+// out of 16 (index = x ^ y*P1 ^ z*P2: x and x+1 differ in the low bits only), but as two instructions each line is
+// looked up twice and a fine-level instruction already touches ~40 distinct lines (its cost).
+// The half-waves therefore trade addresses with one v_permlane32_swap per corner pair: the first load serves BOTH
+// x-corners of lanes 0-31, the second those of lanes 32-63 -- about half the distinct lines per instruction, same
+// instruction count -- and blend_level_x swaps the fetched values back.
+#ifndef SN_XSWAP_FROM
+#define SN_XSWAP_FROM 0      // every hashed level (same-box A/B: 8.41 -> 7.78 ms for [128]; from level 9: 7.96, from 11: 8.19)
+#endif
+#ifndef SN_XSWAP_DENSE
+#define SN_XSWAP_DENSE 0
+#endif
+#ifndef SN_XSWAP_HALF
+#define SN_XSWAP_HALF 0
+#endif
+template <typename T, int KIND, int l>
+constexpr bool xswap_level() {
+    return (KIND == 1 || (KIND == 0 && SN_XSWAP_DENSE)) && l >= SN_XSWAP_FROM && (sizeof(T) == 4 || SN_XSWAP_HALF);
+}
+__device__ __forceinline__ void half_wave_swap(uint32_t &a, uint32_t &b) {
+    // a' = [a.lanes0-31 | b.lanes0-31], b' = [a.lanes32-63 | b.lanes32-63]
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
+template <typename T, int C, int KIND, bool PAIR, bool XSWAP = false>
 __device__ __forceinline__ void issue_level(const T *__restrict__ table, const GridLevels &g, int l, const float (&x01)[3],
                                             float (&pos)[3], Corner<T, C> (&cv)[8]) {
     const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
@@ -167,6 +192,10 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
         return;
     }
     corner_offsets<KIND, (uint32_t)(C * sizeof(T))>(cell, res, size, mode, offs);
+    if constexpr (XSWAP) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) half_wave_swap(offs[2 * p], offs[2 * p + 1]);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const T *row = reinterpret_cast<const T *>(reinterpret_cast<const char *>(tab) + offs[i]);
@@ -174,8 +203,13 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
             const float2 t = *reinterpret_cast<const float2 *>(row);
             cv[i].v[0] = t.x; cv[i].v[1] = t.y;
         } else if constexpr (C == 2 && sizeof(T) == 2) {
-            const __half2 t = *reinterpret_cast<const __half2 *>(row);
-            cv[i].v[0] = __low2float(t); cv[i].v[1] = __high2float(t);
+            if constexpr (XSWAP) {   // keep the packed row: blend_level_x swaps one register per corner, then unpacks
+                cv[i].v[0] = __uint_as_float(*reinterpret_cast<const uint32_t *>(row));
+                cv[i].v[1] = 0.0f;
+            } else {
+                const __half2 t = *reinterpret_cast<const __half2 *>(row);
+                cv[i].v[0] = __low2float(t); cv[i].v[1] = __high2float(t);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < C; ++c) cv[i].v[c] = table_ld<T>(row + c);
@@ -195,6 +229,34 @@ __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, cv[idx].v[c], acc[c]);
     }
+}
+
+// blend of a level whose gathers were issued with XSWAP: first give every lane its own corner values back
+template <typename T, int C>
+__device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corner<T, C> (&cv)[8], float (&acc)[C]) {
+    Corner<T, C> own[8];
+    if constexpr (C == 2 && sizeof(T) == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t a = __float_as_uint(cv[2 * p].v[0]), b = __float_as_uint(cv[2 * p + 1].v[0]);
+            half_wave_swap(a, b);
+            const __half2 ha = *reinterpret_cast<const __half2 *>(&a), hb = *reinterpret_cast<const __half2 *>(&b);
+            own[2 * p].v[0] = __low2float(ha); own[2 * p].v[1] = __high2float(ha);
+            own[2 * p + 1].v[0] = __low2float(hb); own[2 * p + 1].v[1] = __high2float(hb);
+        }
+        blend_level<T, C>(pos, own, acc);
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            uint32_t a = __float_as_uint(cv[2 * p].v[c]), b = __float_as_uint(cv[2 * p + 1].v[c]);
+            half_wave_swap(a, b);
+            own[2 * p].v[c] = __uint_as_float(a); own[2 * p + 1].v[c] = __uint_as_float(b);
+        }
+    }
+    blend_level<T, C>(pos, own, acc);
 }
 
 // Encodes all L levels; `emit(l, acc)` receives each level's C features (zeros when out of range).
@@ -249,18 +311,21 @@ __device__ __forceinline__ void issue_group(const T *__restrict__ table, const G
         constexpr int k = decltype(kk)::value;
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
-        issue_level<T, C, KIND, false>(table, g, l, x01, r.pos[k], r.cv[k]);
+        issue_level<T, C, KIND, false, xswap_level<T, KIND, l>()>(table, g, l, x01, r.pos[k], r.cv[k]);
     });
 }
 
-template <typename T, int C, int G, int GRP, typename Emit>
+template <typename T, int C, int G, int K, int GRP, typename Emit>
 __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit emit) {
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
+    static_for<0, G>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int l = GRP * G + k;
+        constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
         float acc[C];
-        blend_level<T, C>(r.pos[k], r.cv[k], acc);
-        emit(GRP * G + k, acc);
-    }
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, C>(r.pos[k], r.cv[k], acc);
+        emit(l, acc);
+    });
 }
 
 // all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
@@ -920,14 +985,14 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 row_hi[l] = ph;
                 row_lo[l] = pl;
             };
-            blend_group<TT, 2, PG, 0>(g0, emit);
+            blend_group<TT, 2, PG, K, 0>(g0, emit);
             __builtin_amdgcn_sched_barrier(0);
             static_for<1, L / PG>([&](auto gg) {
                 constexpr int GRP = decltype(gg)::value;
                 GroupRegs<TT, 2, PG> gr;
                 issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr);
                 __builtin_amdgcn_sched_barrier(0);
-                blend_group<TT, 2, PG, GRP>(gr, emit);
+                blend_group<TT, 2, PG, K, GRP>(gr, emit);
                 __builtin_amdgcn_sched_barrier(0);
             });
             {
