@@ -142,6 +142,9 @@ struct Corner { float v[C]; };
 #ifndef SN_XSWAP_FROM
 #define SN_XSWAP_FROM 0      // every hashed level (same-box A/B: 8.41 -> 7.78 ms for [128]; from level 9: 7.96, from 11: 8.19)
 #endif
+#ifndef SN_PAIR_ALIGNED
+#define SN_PAIR_ALIGNED 1    // A/B switch: aligned x-pair rows for the dense levels of the final stage (PairTab)
+#endif
 #ifndef SN_XSWAP_DENSE
 #define SN_XSWAP_DENSE 0
 #endif
@@ -158,13 +161,44 @@ __device__ __forceinline__ void half_wave_swap(uint32_t &a, uint32_t &b) {
     a = r[0]; b = r[1];
 }
 
-template <typename T, int C, int KIND, bool PAIR, bool XSWAP = false>
+// Dense levels re-laid out for the final stage (k_pack_pairs, once per render call, a few MB): pair row i of a level
+// = (row i, row of the +1 neighbour in x, clamped at the border) -> the two x-corners of a cell come from ONE
+// naturally aligned 16-byte (fp32) / 8-byte (fp16) load and the border case needs no select.  The gather address
+// rate (one wave instruction per 17.5 cycles per CU) is what bounds the final stage: 4 loads
+// instead of 8 on the 5 dense levels = 108 instead of 128 gather instructions per sample.
+struct PairTab {
+    const void *base;            // device; NULL = not available
+    uint32_t off[8];             // first pair row of each dense level
+};
+
+template <typename T, int C, int KIND, bool PAIR, bool XSWAP = false, bool PAIRA = false>
 __device__ __forceinline__ void issue_level(const T *__restrict__ table, const GridLevels &g, int l, const float (&x01)[3],
-                                            float (&pos)[3], Corner<T, C> (&cv)[8]) {
+                                            float (&pos)[3], Corner<T, C> (&cv)[8], const PairTab *pt = nullptr) {
     const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
     const T *tab = table + (size_t)g.off[l] * C;
     uint32_t cell[3], offs[8];
     locate_linear(x01, res, pos, cell);
+    if constexpr (PAIRA && KIND == 0 && C == 2) {
+        constexpr uint32_t PB = (uint32_t)(2 * C * sizeof(T));
+        const uint32_t sy = res * PB, sz = res * res * PB, top = res - 1u;
+        const uint32_t X0 = cell[0] * PB, Y0 = __umul24(cell[1], sy), Z0 = __umul24(cell[2], sz);
+        const uint32_t Y1 = umin(Y0 + sy, top * sy), Z1 = umin(Z0 + sz, top * sz);
+        const char *pbase = reinterpret_cast<const char *>(pt->base) + (size_t)pt->off[l] * PB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t off = X0 + ((i & 1) ? Y1 : Y0) + ((i & 2) ? Z1 : Z0);
+            if constexpr (sizeof(T) == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(pbase + off);
+                cv[2 * i].v[0] = t.x; cv[2 * i].v[1] = t.y; cv[2 * i + 1].v[0] = t.z; cv[2 * i + 1].v[1] = t.w;
+            } else {
+                const uint2 t = *reinterpret_cast<const uint2 *>(pbase + off);
+                const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
+                cv[2 * i].v[0] = __low2float(a); cv[2 * i].v[1] = __high2float(a);
+                cv[2 * i + 1].v[0] = __low2float(b); cv[2 * i + 1].v[1] = __high2float(b);
+            }
+        }
+        return;
+    }
     if constexpr (PAIR && KIND == 0 && C == 2 && sizeof(T) == 4) {
         // Dense level, fp32 rows: (x0, y, z) and (x0+1, y, z) are adjacent in memory, so ONE 16-byte load of two
         // rows serves both x-corners: 4 gathers per level instead of 8.  At the upper border x1 == x0
@@ -305,13 +339,13 @@ struct GroupRegs {
 
 template <typename T, int C, int G, int K, int GRP>
 __device__ __forceinline__ void issue_group(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
-                                            GroupRegs<T, C, G> &r) {
+                                            GroupRegs<T, C, G> &r, const PairTab &pt) {
     r.oob = false;   // out-of-range lanes are fixed up by the caller on a wave-uniform rare path
     static_for<0, G>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
-        issue_level<T, C, KIND, false, xswap_level<T, KIND, l>()>(table, g, l, x01, r.pos[k], r.cv[k]);
+        issue_level<T, C, KIND, false, xswap_level<T, KIND, l>(), (K > 0 && K <= 8 && SN_PAIR_ALIGNED)>(table, g, l, x01, r.pos[k], r.cv[k], &pt);
     });
 }
 
@@ -605,6 +639,7 @@ struct FinalArgs {
     float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
     float *w_out;                // scratch [T][Npad] for the feature stage, or NULL
     float stop_cum;              // > 0: a wave leaves the march once every lane's optical depth exceeds this (-ln eps)
+    PairTab pairs;               // dense levels of the main grid as aligned x-pairs (K > 0 instantiations)
 };
 
 // A-operand packing for the 32->64->64->16 MLP on v_mfma_f32_32x32x2_f32.
@@ -967,7 +1002,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     float p_n[3], x01_n[3];
     sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
     if constexpr (MODE == MLP_F16X3) {
-        issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0);
+        issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
         __builtin_amdgcn_sched_barrier(0);
     }
     for (uint32_t j = 0; j < T; ++j) {
@@ -990,7 +1025,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
             static_for<1, L / PG>([&](auto gg) {
                 constexpr int GRP = decltype(gg)::value;
                 GroupRegs<TT, 2, PG> gr;
-                issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr);
+                issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr, a.pairs);
                 __builtin_amdgcn_sched_barrier(0);
                 blend_group<TT, 2, PG, K, GRP>(gr, emit);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1008,7 +1043,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 const float rbp = j + 2u <= T ? rb_next : rb_prev;
                 tmid_n = (rb_next_n + rbp) / 2.0f;
                 sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-                issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0);
+                issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_wave_barrier();
@@ -1214,6 +1249,35 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
 // When enabled, every kernel launched by sn_rm_render_rays is bracketed by hipEvents recorded
 // on the caller's stream; sn_rm_profile_read() synchronises them and returns, per kernel class,
 // the launch count and the summed device time.  Off by default (no events, no overhead).
+// pair rows of the dense levels (see PairTab): one thread per (level < K, row)
+template <typename T>
+__global__ void k_pack_pairs(const T *__restrict__ table, GridLevels g, PairTab pt, uint32_t K) {
+    const uint32_t l = blockIdx.y;
+    if (l >= K) return;
+    const uint32_t res = g.res[l], rows = res * res * res;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const uint32_t x = i % res;
+    const uint32_t j = i + (x + 1u < res ? 1u : 0u);                     // gridencoder.cu:182: the +1 neighbour is clamped to res-1
+    const T *tab = table + (size_t)g.off[l] * 2u;
+    if constexpr (sizeof(T) == 4) {
+        const float2 a = reinterpret_cast<const float2 *>(tab)[i], b = reinterpret_cast<const float2 *>(tab)[j];
+        reinterpret_cast<float4 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+        const uint32_t a = reinterpret_cast<const uint32_t *>(tab)[i], b = reinterpret_cast<const uint32_t *>(tab)[j];
+        reinterpret_cast<uint2 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_uint2(a, b);
+    }
+}
+
+// pair-row offsets of the dense prefix; returns the total number of pair rows (0 if the grid has no usable prefix)
+static uint32_t pair_layout(const GridLevels &g, int K, uint32_t (&off)[8]) {
+    uint32_t total = 0;
+    for (int l = 0; l < 8; ++l) off[l] = 0;
+    if (K <= 0 || K > 8 || g.C != 2) return 0;
+    for (int l = 0; l < K; ++l) { off[l] = total; total += g.res[l] * g.res[l] * g.res[l]; }
+    return total;
+}
+
 enum { PK_PACK = 0, PK_PROP0, PK_PROP1, PK_PROP2, PK_FINAL, PK_FEAT, PK_CLASSES };
 struct ProfSpan { hipEvent_t a, b; int cls; };
 static bool g_prof_on = false;
@@ -1320,11 +1384,22 @@ int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
     return SN_OK;
 }
 
+// floats reserved after the packed MLP weights for the pair rows of the main grid's dense levels (4 per row: sized for
+// fp32 tables, fp16 uses half of it)
+static size_t pair_region_floats(const sn_render_cfg *cfg) {
+    GridLevels g;
+    if (cfg->grid.D != 3 || build_grid_levels(&g, cfg->grid.offsets, cfg->grid.D, cfg->grid.C, cfg->grid.L, cfg->grid.S, cfg->grid.H,
+                                              cfg->grid.gridtype, (int)cfg->grid.align_corners, cfg->grid.interp) != SN_OK) return 0;
+    if (!levels_fast(g)) return 0;
+    uint32_t off[8];
+    return (size_t)pair_layout(g, dense_prefix(g), off) * 4u;
+}
+
 size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w) {
     if (!cfg || N == 0) return (size_t)PACK_FLOATS * sizeof(float);
     const uint32_t nc = chunk_rays(N, tile_w);
     const size_t npad = (size_t)blocks_for(nc, tile_w) * 256u;
-    return (stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS) * sizeof(float);
+    return (stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS + pair_region_floats(cfg)) * sizeof(float);
 }
 
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
@@ -1395,9 +1470,16 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     const bool use_mfma = mlp_mode != MLP_VALU;
 
     SN_REQUIRE(io->workspace != nullptr, "render_rays: workspace is NULL");
+    SN_REQUIRE(table_aligned(io->workspace), "render_rays: workspace must be 16-byte aligned");
     float *pack = reinterpret_cast<float *>(io->workspace);
-    float *scratch = pack + PACK_FLOATS;
-    const size_t scratch_floats_avail = io->workspace_bytes / sizeof(float) > (size_t)PACK_FLOATS ? io->workspace_bytes / sizeof(float) - PACK_FLOATS : 0;
+    const size_t pair_floats = pair_region_floats(cfg);
+    float *pair_mem = pack + PACK_FLOATS;
+    float *scratch = pair_mem + pair_floats;
+    const size_t head_floats = (size_t)PACK_FLOATS + pair_floats;
+    const size_t scratch_floats_avail = io->workspace_bytes / sizeof(float) > head_floats ? io->workspace_bytes / sizeof(float) - head_floats : 0;
+    PairTab pairs;
+    pairs.base = nullptr;
+    for (int l = 0; l < 8; ++l) pairs.off[l] = 0;
     if (use_mfma) {
         ProfScope ps(st, PK_PACK);
         if (mlp_mode == MLP_F16X3)
@@ -1406,6 +1488,20 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         else
             hipLaunchKernelGGL(k_pack_grid_mlp, dim3(PACK_FLOATS / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0], cfg->grid_mlp.weight[1], cfg->grid_mlp.weight[2], pack);
         SN_LAUNCH_CHECK("k_pack_grid_mlp");
+        const int Kp = dense_prefix(gl_main);
+        if (mlp_mode == MLP_F16X3 && pair_floats > 0 && Kp > 0) {   // aligned x-pair rows of the dense levels (PairTab)
+            const uint32_t total = pair_layout(gl_main, Kp, pairs.off);
+            (void)total;
+            pairs.base = pair_mem;
+            uint32_t max_rows = 0;
+            for (int l = 0; l < Kp; ++l) { const uint32_t r3 = gl_main.res[l] * gl_main.res[l] * gl_main.res[l]; if (r3 > max_rows) max_rows = r3; }
+            const dim3 gp(div_up(max_rows, 256), (uint32_t)Kp);
+            if (cfg->grid.table_dtype == SN_F16)
+                hipLaunchKernelGGL(k_pack_pairs<__half>, gp, dim3(256), 0, st, (const __half *)cfg->grid.embeddings, gl_main, pairs, (uint32_t)Kp);
+            else
+                hipLaunchKernelGGL(k_pack_pairs<float>, gp, dim3(256), 0, st, (const float *)cfg->grid.embeddings, gl_main, pairs, (uint32_t)Kp);
+            SN_LAUNCH_CHECK("k_pack_pairs");
+        }
     }
 
     const uint32_t W = io->tile_w;
@@ -1416,7 +1512,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         const uint32_t Npad = nblk * 256u;
         if (stage_scratch_floats(cfg, Npad) > scratch_floats_avail) {
             set_error("render_rays: workspace too small (%zu bytes, need %zu)", io->workspace_bytes,
-                      (stage_scratch_floats(cfg, Npad) + PACK_FLOATS) * sizeof(float));
+                      (stage_scratch_floats(cfg, Npad) + head_floats) * sizeof(float));
             return SN_ERR_WORKSPACE;
         }
         RayCommon rc;
@@ -1484,6 +1580,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_xyz = io->xyzs_last ? io->xyzs_last + (size_t)first * fa.T * 3 : nullptr;
         fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * 15 : nullptr;
         fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
+        fa.pairs = pairs;
         fa.w_out = cfg->with_feat ? w_scr[S - 1] : nullptr;
         // early termination is honoured only when nothing per-sample leaves the kernel (those tensors would be left
         // unwritten past the stop)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--hw", type=int, default=800)
     ap.add_argument("--tiles", type=int, default=48)
     ap.add_argument("--row-bytes", type=int, default=8)
+    ap.add_argument("--xswap", type=int, default=1, help="model the half-wave x-pair exchange on hashed levels (0: plain corner order)")
     a = ap.parse_args()
     steps = [128] if a.schedule == "flat128" else [128, 64, 32]
     H = W = a.hw
@@ -71,8 +72,17 @@ def main():
                 row = q[..., 0] ^ (q[..., 1] * P1) ^ (q[..., 2] * P2)
             row = (row % np.uint32(size)) + np.uint32(offs[l])
             line = (row // rows_per_line).reshape(n_w, 64, T)
-            lines.append(np.array([[len(np.unique(line[w, :, j])) for j in range(T)] for w in range(n_w)]))
-        lines = np.stack(lines)                                          # [8, n_w, T]
+            lines.append(line)
+        if a.xswap and not dense:
+            # half-wave x-pair exchange (render.hip, XSWAP): instruction 2p serves corners 2p and 2p+1 of lanes 0-31,
+            # instruction 2p+1 those of lanes 32-63
+            ex = []
+            for pr in range(4):
+                lo = np.concatenate([lines[2 * pr][:, :32], lines[2 * pr + 1][:, :32]], axis=1)
+                hi = np.concatenate([lines[2 * pr][:, 32:], lines[2 * pr + 1][:, 32:]], axis=1)
+                ex += [lo, hi]
+            lines = ex
+        lines = np.stack([np.array([[len(np.unique(ln[w, :, j])) for j in range(T)] for w in range(n_w)]) for ln in lines])   # [8, n_w, T]
         clk = np.maximum(17.5, 2.3 * lines)
         pgw = pg.reshape(n_w, 64, T, 3).astype(np.int64)
         ext = pgw.max(axis=1) - pgw.min(axis=1) + 2                      # vertices per axis  [n_w, T, 3]
