@@ -171,7 +171,7 @@ struct PairTab {
     uint32_t off[8];             // first pair row of each dense level
 };
 
-template <typename T, int C, int KIND, bool PAIR, bool XSWAP = false, bool PAIRA = false>
+template <typename T, int C, int KIND, bool PAIRA, bool XSWAP = false>
 __device__ __forceinline__ void issue_level(const T *__restrict__ table, const GridLevels &g, int l, const float (&x01)[3],
                                             float (&pos)[3], Corner<T, C> (&cv)[8], const PairTab *pt = nullptr) {
     const uint32_t res = g.res[l], size = g.size[l], mode = g.mode[l];
@@ -196,32 +196,6 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
                 cv[2 * i].v[0] = __low2float(a); cv[2 * i].v[1] = __high2float(a);
                 cv[2 * i + 1].v[0] = __low2float(b); cv[2 * i + 1].v[1] = __high2float(b);
             }
-        }
-        return;
-    }
-    if constexpr (PAIR && KIND == 0 && C == 2 && sizeof(T) == 4) {
-        // Dense level, fp32 rows: (x0, y, z) and (x0+1, y, z) are adjacent in memory, so ONE 16-byte load of two
-        // rows serves both x-corners: 4 gathers per level instead of 8.  At the upper border x1 == x0
-        // (gridencoder.cu:182 clamps) and the reference re-reads row x0; the select below reproduces that, the
-        // extra row that was fetched is ignored (it is inside the table: a hashed level always follows, see
-        // dense_prefix()).  Measured: pays in the proposal stages (VALU/TA-bound, 3 of 5 levels dense), costs in
-        // the final stage (the 8-byte-aligned dwordx4 is slower per request), and an 8-byte load at 4-byte
-        // alignment (fp16 rows) does not return the expected bytes on gfx950 -> fp32 proposal stages only.
-        constexpr uint32_t SB = (uint32_t)(2 * sizeof(T));
-        const uint32_t x0 = cell[0], y0 = cell[1], z0 = cell[2];
-        const bool same_x = x0 + 1u > res - 1u;
-        // full-rate 24-bit multiplies (v_mul_lo_u32 is quarter rate; levels_fast() bounds the operands); the +1
-        // neighbour (clamped to res-1, gridencoder.cu:182) is the base term plus one stride, capped
-        const uint32_t sy = res * SB, sz = res * res * SB, top = res - 1u;
-        const uint32_t X0 = x0 * SB, Y0 = __umul24(y0, sy), Z0 = __umul24(z0, sz);
-        const uint32_t Y1 = umin(Y0 + sy, top * sy), Z1 = umin(Z0 + sz, top * sz);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t off = X0 + ((i & 1) ? Y1 : Y0) + ((i & 2) ? Z1 : Z0);
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-            const f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(tab) + off);
-            cv[2 * i].v[0] = t.x; cv[2 * i].v[1] = t.y;
-            cv[2 * i + 1].v[0] = same_x ? t.x : t.z; cv[2 * i + 1].v[1] = same_x ? t.y : t.w;
         }
         return;
     }
@@ -299,7 +273,8 @@ __device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corne
 // caller zeroes those lanes' features on a wave-uniform, practically never taken branch instead of paying a
 // select per level (positions are contracted into [0,1] on this path).
 template <typename T, int L, int C, int GROUP, int K, bool PAIR, typename Emit>
-__device__ __forceinline__ bool encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit) {
+__device__ __forceinline__ bool encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit,
+                                               const PairTab *pt = nullptr) {
     static_assert(L % GROUP == 0 || GROUP >= L, "GROUP must divide L");
     bool oob = false;
 #pragma unroll
@@ -312,7 +287,7 @@ __device__ __forceinline__ bool encode_grouped(const T *__restrict__ table, cons
         static_for<0, G>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int KIND = K < 0 ? -1 : ((l0 + k) < K ? 0 : 1);
-            issue_level<T, C, KIND, PAIR>(table, g, l0 + k, x01, pos[k], cv[k]);
+            issue_level<T, C, KIND, (PAIR && K > 0 && K <= 8 && SN_PAIR_ALIGNED)>(table, g, l0 + k, x01, pos[k], cv[k], pt);
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -345,7 +320,7 @@ __device__ __forceinline__ void issue_group(const T *__restrict__ table, const G
         constexpr int k = decltype(kk)::value;
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
-        issue_level<T, C, KIND, false, xswap_level<T, KIND, l>(), (K > 0 && K <= 8 && SN_PAIR_ALIGNED)>(table, g, l, x01, r.pos[k], r.cv[k], &pt);
+        issue_level<T, C, KIND, (K > 0 && K <= 8 && SN_PAIR_ALIGNED), xswap_level<T, KIND, l>()>(table, g, l, x01, r.pos[k], r.cv[k], &pt);
     });
 }
 
@@ -365,11 +340,11 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
 // all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
 template <typename T, int L, int C, int K, bool PAIRX, int GROUP = L>
 __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
-                                              float (&feat)[L * C]) {
+                                              float (&feat)[L * C], const PairTab *pt = nullptr) {
     const bool oob = encode_grouped<T, L, C, GROUP, K, PAIRX>(table, g, x01, [&](int l, const float (&acc)[C]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) feat[l * C + c] = acc[c];
-    });
+    }, pt);
     // register variant (proposal stages): L*C unconditional selects; a branch here costs more in scheduling than it saves
 #pragma unroll
     for (int i = 0; i < L * C; ++i) feat[i] = oob ? 0.0f : feat[i];
@@ -524,6 +499,7 @@ struct PropArgs {
     float *bins_out;             // scratch [Tn+1][Npad]
     float *dbg_bins, *dbg_w, *dbg_sigma;  // [N,T+1], [N,T], [N,T] or NULL
     int32_t *dbg_inds;                    // [N,Tn+1] or NULL
+    PairTab pairs;                        // dense levels as aligned x-pairs
 };
 
 template <typename TT, int L, int C, int HID, int K>
@@ -563,7 +539,7 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
         float feat[L * C];
-        encode_levels<TT, L, C, K, true>(table, a.g, x01, feat);
+        encode_levels<TT, L, C, K, true>(table, a.g, x01, feat, &a.pairs);
         float h[HID], raw[1];
         const uint32_t oz = opaque_zero();
         dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
@@ -1384,15 +1360,19 @@ int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
     return SN_OK;
 }
 
-// floats reserved after the packed MLP weights for the pair rows of the main grid's dense levels (4 per row: sized for
+// floats reserved after the packed MLP weights for the pair rows of one grid's dense levels (4 per row: sized for
 // fp32 tables, fp16 uses half of it)
-static size_t pair_region_floats(const sn_render_cfg *cfg) {
+static size_t pair_floats_of(const sn_grid_desc *d) {
     GridLevels g;
-    if (cfg->grid.D != 3 || build_grid_levels(&g, cfg->grid.offsets, cfg->grid.D, cfg->grid.C, cfg->grid.L, cfg->grid.S, cfg->grid.H,
-                                              cfg->grid.gridtype, (int)cfg->grid.align_corners, cfg->grid.interp) != SN_OK) return 0;
+    if (d->D != 3 || d->C != 2 || build_grid_levels(&g, d->offsets, d->D, d->C, d->L, d->S, d->H, d->gridtype, (int)d->align_corners, d->interp) != SN_OK) return 0;
     if (!levels_fast(g)) return 0;
     uint32_t off[8];
     return (size_t)pair_layout(g, dense_prefix(g), off) * 4u;
+}
+static size_t pair_region_floats(const sn_render_cfg *cfg) {
+    size_t f = pair_floats_of(&cfg->grid);
+    for (uint32_t k = 0; k + 1 < cfg->num_stages && k < SN_MAX_STAGES; ++k) f += pair_floats_of(&cfg->prop_grid[k]);
+    return f;
 }
 
 size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w) {
@@ -1488,20 +1468,32 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         else
             hipLaunchKernelGGL(k_pack_grid_mlp, dim3(PACK_FLOATS / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0], cfg->grid_mlp.weight[1], cfg->grid_mlp.weight[2], pack);
         SN_LAUNCH_CHECK("k_pack_grid_mlp");
-        const int Kp = dense_prefix(gl_main);
-        if (mlp_mode == MLP_F16X3 && pair_floats > 0 && Kp > 0) {   // aligned x-pair rows of the dense levels (PairTab)
-            const uint32_t total = pair_layout(gl_main, Kp, pairs.off);
-            (void)total;
-            pairs.base = pair_mem;
+    }
+    // aligned x-pair rows of every grid's dense levels (PairTab), re-packed on every call: the call stays stateless
+    PairTab prop_pairs[SN_MAX_STAGES];
+    {
+        float *cursor = pair_mem;
+        auto pack_pairs = [&](const sn_grid_desc *d, const GridLevels &gl, PairTab &pt) -> int {
+            pt.base = nullptr;
+            for (int l = 0; l < 8; ++l) pt.off[l] = 0;
+            const size_t fl = pair_floats_of(d);
+            const int Kp = dense_prefix(gl);
+            if (fl == 0 || Kp <= 0) return SN_OK;
+            pair_layout(gl, Kp, pt.off);
+            pt.base = cursor;
+            cursor += fl;
             uint32_t max_rows = 0;
-            for (int l = 0; l < Kp; ++l) { const uint32_t r3 = gl_main.res[l] * gl_main.res[l] * gl_main.res[l]; if (r3 > max_rows) max_rows = r3; }
+            for (int l = 0; l < Kp; ++l) { const uint32_t r3 = gl.res[l] * gl.res[l] * gl.res[l]; if (r3 > max_rows) max_rows = r3; }
             const dim3 gp(div_up(max_rows, 256), (uint32_t)Kp);
-            if (cfg->grid.table_dtype == SN_F16)
-                hipLaunchKernelGGL(k_pack_pairs<__half>, gp, dim3(256), 0, st, (const __half *)cfg->grid.embeddings, gl_main, pairs, (uint32_t)Kp);
-            else
-                hipLaunchKernelGGL(k_pack_pairs<float>, gp, dim3(256), 0, st, (const float *)cfg->grid.embeddings, gl_main, pairs, (uint32_t)Kp);
+            if (d->table_dtype == SN_F16) hipLaunchKernelGGL(k_pack_pairs<__half>, gp, dim3(256), 0, st, (const __half *)d->embeddings, gl, pt, (uint32_t)Kp);
+            else hipLaunchKernelGGL(k_pack_pairs<float>, gp, dim3(256), 0, st, (const float *)d->embeddings, gl, pt, (uint32_t)Kp);
             SN_LAUNCH_CHECK("k_pack_pairs");
-        }
+            return SN_OK;
+        };
+        ProfScope ps(st, PK_PACK);
+        int rcp = pack_pairs(&cfg->grid, gl_main, pairs);
+        if (rcp) return rcp;
+        for (uint32_t k = 0; k + 1 < S; ++k) { rcp = pack_pairs(&cfg->prop_grid[k], gl_prop[k], prop_pairs[k]); if (rcp) return rcp; }
     }
 
     const uint32_t W = io->tile_w;
@@ -1551,6 +1543,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             pa.dbg_w = io->weights[k] ? io->weights[k] + (size_t)first * pa.T : nullptr;
             pa.dbg_sigma = io->sigmas[k] ? io->sigmas[k] + (size_t)first * pa.T : nullptr;
             pa.dbg_inds = io->inds[k + 1] ? io->inds[k + 1] + (size_t)first * (pa.Tn + 1) : nullptr;
+            pa.pairs = prop_pairs[k];
             {
                 ProfScope ps(st, PK_PROP0 + (int)k);
                 const int K = dense_prefix(gl_prop[k]);
