@@ -156,6 +156,11 @@ def main():
                 "it can exceed the HBM peak because L1/L2 absorb the re-reads of neighbouring rays (see traffic)",
         "mlp_on_matrix_cores": {"achieved_tflops": round(flops_final / (final_ms * 1e-3) / 1e12, 2),
                                 "note": "algorithmic fp32-equivalent MLP FLOPs; executed as 3 fp16 MFMA products per fp32 product"},
+        "gather_address_rate": {   # the ceiling that binds after the caches (tools/ubench/gathers.hip)
+            "wave_instructions_per_launch": int(-(-n_local // 64) * steps[-1] * (5 * 4 + 11 * 8)),
+            "cycles_per_instruction_per_cu": 17.5,
+            "floor_ms": round(-(-n_local // 64) * steps[-1] * (5 * 4 + 11 * 8) * 17.5 / 256 / 2.4e9 * 1e3, 3),
+            "note": "one wave-wide gather per 17.5 cycles per CU (4 lanes/clk address rate, measured); 5 dense levels x 4 paired loads + 11 hashed levels x 8"},
         "other_kernels_ms": {"pack": round(m["pack_ms"], 4) if m["pack_ms"] else None,
                              "prop0": round(m["prop_ms"][0], 4) if m["prop_ms"][0] else None,
                              "prop1": round(m["prop_ms"][1], 4) if m["prop_ms"][1] else None},
