@@ -418,3 +418,50 @@ def test_rgb_training_step_vs_reference_fixture(gpu, orc):
             close(p.grad.cpu().numpy(), g[f"grad:{name}"], name)
         seen += 1
     assert seen == 13   # grid + 3 grid_mlp + 3 view_mlp + 2 proposal grids + 2x2 prop_mlp
+
+
+def test_sam_distillation_step_vs_reference_fixture(gpu, orc):
+    """SAM-feature distillation step (trainer.py:505-549): frozen field, s_grid + samvit_mlp trainable,
+    low-res feature render -> bilinear resize -> MSE; features, loss and gradients against the reference's autograd
+    (tests/golden/train_sam.npz, tools/gen_golden.py:fx_train_sam)."""
+    import torch.nn.functional as F
+    g = golden("train_sam")
+    params = params_from_spec(spec_of(g))
+    from helpers import make_opt
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    model = NeRFNetwork(make_opt(with_sam=True))
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    assert not unexpected
+    model = model.to(gpu).train()
+    for n_, p in model.named_parameters():
+        p.requires_grad_(n_.startswith("s_grid") or n_.startswith("samvit_mlp"))        # main.py:249-256
+    h, w = int(g["h"]), int(g["w"])
+    out = model.render(T(g["rays_o"], gpu), T(g["rays_d"], gpu), staged=False, bg_color=1, perturb=False, return_feats=1, H=h, W=w)
+    np.testing.assert_allclose(out["samvit"].detach().cpu().numpy(), g["samvit"], rtol=0, atol=RGB_TOL)
+    from sanerf_hq_amd import synth
+    gt = T(synth.hash_uniform(tuple(int(v) for v in g["gt_shape"]), int(g["gt_seed"]), -1.0, 1.0), gpu)
+    pred = F.interpolate(out["samvit"].reshape(1, h, w, 256).permute(0, 3, 1, 2).contiguous(), gt.shape[2:], mode="bilinear")
+    loss = torch.nn.MSELoss(reduction="none")(pred, gt).mean()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+
+    def close(got, ref, what):
+        got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert rel < 1e-3, f"{what}: relative L2 error {rel:.2e}"
+
+    ge = model.s_grid.embeddings.grad
+    close(ge[T(g["s_grid_rows"], gpu)].cpu().numpy(), g["s_grid_grad_rows"], "s_grid sampled rows")
+    touched = int((ge.abs().sum(-1) > 0).sum())
+    assert abs(touched - int(g["s_grid_touched"])) <= 2e-4 * int(g["s_grid_touched"]) + 1
+    assert abs(ge.double().abs().sum().item() - float(g["s_grid_grad_abssum"])) < 1e-3 * float(g["s_grid_grad_abssum"])
+    for name, p in model.named_parameters():
+        if name.startswith("samvit_mlp"):
+            gr = p.grad.detach().cpu().numpy().reshape(-1)
+            if f"grad:{name}" in g.files:
+                close(gr, g[f"grad:{name}"].reshape(-1), name)
+            else:
+                close(gr[::11], g[f"grad11:{name}"], name + " (every 11th entry)")
+                assert abs(np.linalg.norm(gr.astype(np.float64)) - float(g[f"gradnorm:{name}"])) < 1e-3 * float(g[f"gradnorm:{name}"])
+        elif not name.startswith("s_grid"):
+            assert p.grad is None, f"{name} is frozen"

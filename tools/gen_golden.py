@@ -620,6 +620,55 @@ def fx_train_rgb(rr, nn_, ru):
     np.savez_compressed(os.path.join(GOLD, "train_rgb.npz"), **sav)
 
 
+def fx_train_sam(rr, nn_, ru):
+    """SAM-feature distillation step (trainer.py:505-549, cache branch): radiance field frozen (main.py:249-256),
+    s_grid + samvit_mlp trainable; low-res feature render (return_feats=1, perturb=False) -> [1,256,h,w] ->
+    F.interpolate(bilinear) to the SAM feature map size -> MSE.  24x24 rays here (64x64 in the reference)."""
+    import torch.nn.functional as F
+    print("[train:sam] SAM-feature distillation step, 24x24 rays")
+    opt = make_opt(num_steps=[128, 64, 32], with_sam=True, with_mask=False)
+    torch.manual_seed(0)
+    model = nn_.NeRFNetwork(opt)
+    spec = param_spec_for(model, 31337, 1.0, 4.0)
+    load_params(model, spec)
+    for n_, p in model.named_parameters():
+        p.requires_grad_(n_.startswith("s_grid") or n_.startswith("samvit_mlp"))
+    model.train()
+    h = w = 24
+    pose = synth.orbit_pose(1.0, 30.0, 200.0)
+    fx, fy, cx, cy = synth.pinhole_intrinsics(h, w)
+    res = ru.get_rays(torch.from_numpy(pose)[None], np.array([fx, fy, cx, cy], dtype=np.float32), h, w, -1)
+    ro = res["rays_o"].reshape(-1, 3).contiguous(); rd = res["rays_d"].reshape(-1, 3).contiguous()
+    gt = torch.from_numpy(synth.hash_uniform((1, 256, 32, 32), 77, -1.0, 1.0))      # "SAM" map of another size: the resize is exercised
+    out = model.render(ro, rd, staged=False, bg_color=1, perturb=False, return_feats=1, H=h, W=w)
+    pred = out["samvit"].reshape(1, h, w, 256).permute(0, 3, 1, 2).contiguous()
+    pred = F.interpolate(pred, gt.shape[2:], mode="bilinear")
+    loss = torch.nn.MSELoss(reduction="none")(pred, gt).mean()
+    loss.backward()
+    # gt is regenerated by the test from its seed: synth.hash_uniform((1, 256, 32, 32), 77, -1, 1)
+    sav = dict(rays_o=np_(ro), rays_d=np_(rd), gt_seed=np.array(77), gt_shape=np.array([1, 256, 32, 32]), pose=pose,
+               h=np.array(h), w=np.array(w), samvit=np_(out["samvit"]),
+               loss=np.array(loss.item()), param_spec=np.array(json.dumps(spec)))
+    g = model.s_grid.embeddings.grad
+    touched = torch.nonzero(g.abs().sum(-1) > 0).squeeze(-1)
+    pick = np.unique((synth.hash_u01(2048, 13) * touched.numel()).astype(np.int64))
+    rows = touched[torch.from_numpy(pick)]
+    sav.update({"s_grid_rows": np_(rows).astype(np.int64), "s_grid_grad_rows": np_(g[rows]), "s_grid_touched": np.array(touched.numel()),
+                "s_grid_grad_abssum": np.array(g.double().abs().sum().item())})
+    for name, p in model.named_parameters():
+        if name.startswith("samvit_mlp"):
+            g_ = np_(p.grad).reshape(-1)
+            if g_.size > 20000:      # big layers: every 11th entry + the norm (keeps the fixture small)
+                sav[f"grad11:{name}"] = g_[::11].copy()
+                sav[f"gradnorm:{name}"] = np.array(np.linalg.norm(g_.astype(np.float64)))
+            else:
+                sav[f"grad:{name}"] = np_(p.grad)
+        elif not name.startswith("s_grid"):
+            assert p.grad is None, name
+    print(f"   loss {loss.item():.6f}; touched s_grid rows {touched.numel()}")
+    np.savez_compressed(os.path.join(GOLD, "train_sam.npz"), **sav)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -645,6 +694,8 @@ def main():
         fx_train(rr, nn_, ru)
     if on("train_rgb"):
         fx_train_rgb(rr, nn_, ru)
+    if on("train_sam"):
+        fx_train_sam(rr, nn_, ru)
 
 
 if __name__ == "__main__":
