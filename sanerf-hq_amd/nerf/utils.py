@@ -57,3 +57,45 @@ def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, coords=None, device="c
     cy = ((inds % W) * sy).long()
     results["inds_coarse"] = (cx * incoherent_mask_size + cy).long()
     return results
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoints in the reference's format (nerf/trainer.py:1685-1741 save, :1779-1800 load)
+# ---------------------------------------------------------------------------------------------
+def save_checkpoint(model, path, epoch=0, global_step=0, stats=None, optimizer=None, lr_scheduler=None):
+    """{'epoch', 'global_step', 'stats', 'model': state_dict[, 'optimizer', 'lr_scheduler']} -- what the reference's
+    Trainer.save_checkpoint writes (the `full=True` extras only when given), so its load_checkpoint reads it back."""
+    import torch
+    state = {"epoch": int(epoch), "global_step": int(global_step),
+             "stats": stats if stats is not None else {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None},
+             "model": model.state_dict()}
+    if optimizer is not None:
+        state["optimizer"] = optimizer.state_dict()
+    if lr_scheduler is not None:
+        state["lr_scheduler"] = lr_scheduler.state_dict()
+    torch.save(state, path)
+    return state
+
+
+def load_checkpoint(model, checkpoint, map_location=None):
+    """Load a reference checkpoint (file path or already-loaded dict).  Like trainer.py:1779-1800: a dict without a
+    'model' entry is taken as a bare state_dict (strict); otherwise state['model'] is loaded with strict=False and
+    (missing, unexpected, state) is returned so that the caller can restore epoch / optimizer."""
+    import torch
+    state = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__") else checkpoint
+    if "model" not in state:
+        model.load_state_dict(state)
+        return [], [], {}
+    missing, unexpected = model.load_state_dict(state["model"], strict=False)
+    return list(missing), list(unexpected), state
+
+
+def freeze_loaded_parameters(model, model_dict):
+    """main.py:249-256: after loading a pretrained radiance field into a SAM / mask model, every parameter that came
+    from the checkpoint is frozen; the new heads stay trainable."""
+    frozen = []
+    for k, v in model.named_parameters():
+        if k in model_dict:
+            v.requires_grad = False
+            frozen.append(k)
+    return frozen

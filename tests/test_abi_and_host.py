@@ -183,3 +183,31 @@ def test_losses_on_cpu():
     # a proposal histogram that upper-bounds the reference one has zero loss
     assert float(proposal_loss([bins, bins], [w * 2, w])) == 0.0
     assert float(proposal_loss([bins, bins], [w * 0.5, w])) > 0.0
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """nerf/trainer.py:1685-1741 / :1779-1800: {'epoch','global_step','stats','model'}; a pretrained radiance field
+    loads into a SAM/mask model with the heads missing (strict=False) and is frozen like main.py:249-256."""
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    from sanerf_hq_amd.nerf.utils import freeze_loaded_parameters, load_checkpoint, save_checkpoint
+    torch.manual_seed(3)
+    base = NeRFNetwork(make_opt())
+    with torch.no_grad():
+        for p in base.parameters():
+            p.uniform_(-0.5, 0.5)
+    path = str(tmp_path / "ngp_ep0007.pth")
+    state = save_checkpoint(base, path, epoch=7, global_step=1234)
+    assert set(state) == {"epoch", "global_step", "stats", "model"} and set(state["stats"]) >= {"loss", "valid_loss", "results", "checkpoints", "best_result"}
+    fresh = NeRFNetwork(make_opt())
+    missing, unexpected, st = load_checkpoint(fresh, path, map_location="cpu")
+    assert not missing and not unexpected and st["epoch"] == 7 and st["global_step"] == 1234
+    for (k, a), (_, b) in zip(base.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    heads = NeRFNetwork(make_opt(with_sam=True, with_mask=True))
+    missing, unexpected, st = load_checkpoint(heads, path, map_location="cpu")
+    assert not unexpected and all(m.split(".")[0] in ("s_grid", "samvit_mlp", "m_grid", "mask_mlp") for m in missing)
+    frozen = freeze_loaded_parameters(heads, st["model"])
+    assert "grid.embeddings" in frozen and all(not heads.get_parameter(k).requires_grad for k in frozen)
+    assert heads.s_grid.embeddings.requires_grad and heads.mask_mlp[0].net[0].weight.requires_grad
+    bare = NeRFNetwork(make_opt())
+    assert load_checkpoint(bare, base.state_dict()) == ([], [], {})          # bare state_dict branch (trainer.py:1793-1796)
