@@ -1,9 +1,8 @@
 """Ray generation with the reference's `get_rays` contract (nerf/utils.py:182-304).
 
-Full-image rays come from the HIP kernel (`raymarching.generate_rays`); pixel subsets
-(`coords`, random pixels, random patches) are gathered from it.  The error-map /
-incoherent-mask sampling branches belong to the reference's trainer-side data pipeline
- and raise NotImplementedError here.
+Full-image rays come from the HIP kernel (`raymarching.generate_rays`); pixel subsets (`coords`, random pixels,
+random patches, and the error-map / incoherent-mask draws of utils.py:214-259) are selected on the device with
+torch ops and gathered from it -- no host round trip in a training step.
 """
 from __future__ import annotations
 
@@ -31,18 +30,33 @@ def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, coords=None, device="c
         if coords is not None:
             inds = (coords[:, 0] * W + coords[:, 1]).to(device).long()
         elif patch_size > 1 and not random_sample:
-            if incoherent_mask is not None and include_incoherent_region:
-                raise NotImplementedError("incoherent-mask patch sampling is trainer-side data logic (out of scope)")
-            num_patch = N // (patch_size ** 2)
-            ix = torch.randint(0, H - patch_size, size=[num_patch], device=device)
-            iy = torch.randint(0, W - patch_size, size=[num_patch], device=device)
+            if incoherent_mask is not None and include_incoherent_region:      # utils.py:214-225: one patch around a drawn coarse cell
+                centre = torch.multinomial(incoherent_mask.to(device=device, dtype=torch.float32).reshape(1, -1), 1).reshape(-1)
+                cxm = torch.div(centre, incoherent_mask_size, rounding_mode="floor")
+                cym = centre % incoherent_mask_size
+                ix = torch.clamp(cxm * (H / incoherent_mask_size) - patch_size // 2, min=0, max=H - patch_size - 1).long()
+                iy = torch.clamp(cym * (W / incoherent_mask_size) - patch_size // 2, min=0, max=W - patch_size - 1).long()
+            else:
+                num_patch = N // (patch_size ** 2)
+                ix = torch.randint(0, H - patch_size, size=[num_patch], device=device)
+                iy = torch.randint(0, W - patch_size, size=[num_patch], device=device)
             base = torch.stack([ix, iy], dim=-1)
             pi, pj = torch.meshgrid(torch.arange(patch_size, device=device), torch.arange(patch_size, device=device), indexing="ij")
             offs = torch.stack([pi.reshape(-1), pj.reshape(-1)], dim=-1)
             pix = (base.unsqueeze(1) + offs.unsqueeze(0)).view(-1, 2)
             inds = pix[:, 0] * W + pix[:, 1]
-        elif patch_size == 1 and not random_sample:
-            raise NotImplementedError("error-map (incoherent_mask) pixel sampling is trainer-side data logic (out of scope)")
+        elif patch_size == 1 and not random_sample:                            # utils.py:245-257: error-map draw without replacement
+            if incoherent_mask is None:
+                raise RuntimeError("get_rays: patch_size=1 without random_sample draws from incoherent_mask (utils.py:246); none given")
+            m = incoherent_mask.to(device=device, dtype=torch.float32).reshape(1, -1)
+            inds_coarse = torch.multinomial(m, N, replacement=False)               # [1, N] in [0, size*size)
+            gx = torch.div(inds_coarse, incoherent_mask_size, rounding_mode="floor")
+            gy = inds_coarse % incoherent_mask_size
+            sx, sy = H / incoherent_mask_size, W / incoherent_mask_size
+            px = (gx * sx + torch.rand(1, N, device=device) * sx).long().clamp(max=H - 1)
+            py = (gy * sy + torch.rand(1, N, device=device) * sy).long().clamp(max=W - 1)
+            inds = (px * W + py)[0]
+            results["inds_coarse"] = inds_coarse                                   # the caller updates its error map with these
         else:
             inds = torch.randint(0, H * W, size=[N], device=device)
         rays_o, rays_d = rays_o[inds], rays_d[inds]
@@ -52,10 +66,11 @@ def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, coords=None, device="c
         inds = torch.arange(H * W, device=device)
     results["rays_o"] = rays_o
     results["rays_d"] = rays_d
-    sx, sy = incoherent_mask_size / H, incoherent_mask_size / W
-    cx = (torch.div(inds, W, rounding_mode="floor") * sx).long()
-    cy = ((inds % W) * sy).long()
-    results["inds_coarse"] = (cx * incoherent_mask_size + cy).long()
+    if results.get("inds_coarse") is None:                                      # utils.py:294-300
+        sx, sy = incoherent_mask_size / H, incoherent_mask_size / W
+        cx = (torch.div(inds, W, rounding_mode="floor") * sx).long()
+        cy = ((inds % W) * sy).long()
+        results["inds_coarse"] = (cx * incoherent_mask_size + cy).long()
     return results
 
 

@@ -202,6 +202,22 @@ def test_generate_rays_and_get_rays(gpu, orc):
     sub = get_rays(torch.from_numpy(pose)[None].to(gpu), np.array(intr, dtype=np.float32), H, W, 64, random_sample=True)
     idx = sub["j"] * W + sub["i"]
     assert torch.equal(sub["rays_d"], rd[idx])
+    # error-map / incoherent-mask draws (utils.py:214-259): device-side multinomial, pixels land inside the drawn coarse cells
+    M = 8
+    mask = torch.zeros(M * M, device=gpu)
+    hot = torch.tensor([3 * M + 5, 6 * M + 1, 0], device=gpu)
+    mask[hot] = 1.0
+    tposes, tintr = torch.from_numpy(pose)[None].to(gpu), np.array(intr, dtype=np.float32)
+    em = get_rays(tposes, tintr, H, W, 3, patch_size=1, incoherent_mask=mask, incoherent_mask_size=M)
+    assert em["inds_coarse"].shape == (1, 3) and set(em["inds_coarse"][0].tolist()) == set(hot.tolist())      # without replacement
+    gx, gy = em["inds_coarse"][0] // M, em["inds_coarse"][0] % M
+    assert bool(((em["j"] >= (gx * H / M).long()) & (em["j"] <= ((gx + 1) * H / M).long())).all())
+    assert bool(((em["i"] >= (gy * W / M).long()) & (em["i"] <= ((gy + 1) * W / M).long())).all())
+    assert torch.equal(em["rays_d"], rd[em["j"] * W + em["i"]])
+    pt = get_rays(tposes, tintr, H, W, 16, patch_size=4, incoherent_mask=mask, include_incoherent_region=True, incoherent_mask_size=M)
+    assert pt["rays_d"].shape == (16, 3) and int(pt["j"].max() - pt["j"].min()) == 3 and int(pt["i"].max() - pt["i"].min()) == 3
+    with pytest.raises(RuntimeError, match="incoherent_mask"):
+        get_rays(tposes, tintr, H, W, 4, patch_size=1)
 
 
 def test_near_far_contract_bit_exact(gpu, orc):
