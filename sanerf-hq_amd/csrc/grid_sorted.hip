@@ -216,8 +216,8 @@ size_t sn_grid_backward_sorted_workspace_bytes(uint32_t B, uint32_t D, uint32_t 
     const uint64_t n = (uint64_t)B * max_level * (1u << D);
     if (n == 0 || n >= (1ull << 31)) return 0;
     size_t temp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                       (uint32_t *)nullptr, (int)n, 0, 32);
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                           (uint32_t *)nullptr, (int)n, 0, 32) != hipSuccess) return 0;
     return 4 * align256((size_t)n * sizeof(uint32_t)) + align256((size_t)n * C * sizeof(float)) + align256(temp) + 256;
 }
 

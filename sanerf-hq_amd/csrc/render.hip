@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     float *fe;            // this lane's feature column base
     uint32_t fstride;     // distance between consecutive features of one lane
     float *actB = nullptr;
-    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value, VW2 = 3 * PadIn<VH>::value;
+    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;   // third layer: 3 * PadIn<VH> floats follow
     float *lds_vw;        // view_mlp weights (padded rows), all three layers back to back
     uint32_t *slab_hi = nullptr, *slab_lo = nullptr;      // MLP_F16X3: this wave's split feature images
     if constexpr (MODE == MLP_F16X3) {
@@ -1265,10 +1265,10 @@ struct ProfScope {
         if (!g_prof_on) return;
         ProfSpan sp; sp.cls = cls;
         if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return;
-        hipEventRecord(sp.a, st);
+        (void)hipEventRecord(sp.a, st);
         g_prof.push_back(sp); idx = (int)g_prof.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) hipEventRecord(g_prof[idx].b, st); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
 };
 
 static int to_levels(GridLevels *g, const sn_grid_desc *d) {
@@ -1323,7 +1323,7 @@ extern "C" {
 void sn_rm_profile_enable(int on) {
     g_prof_on = on != 0;
     if (!g_prof_on) {
-        for (auto &sp : g_prof) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+        for (auto &sp : g_prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         g_prof.clear();
     }
 }
@@ -1336,7 +1336,7 @@ int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_c
         float ms = 0.0f;
         SN_HIP_OK(hipEventElapsedTime(&ms, sp.a, sp.b));
         ms_per_class[sp.cls] += ms; launches_per_class[sp.cls] += 1;
-        hipEventDestroy(sp.a); hipEventDestroy(sp.b);
+        (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
     }
     g_prof.clear();
     return SN_OK;
