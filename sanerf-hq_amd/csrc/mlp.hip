@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     __syncthreads();                       // publishes lds_bias / lds_x
 
     // one chunk = one k-step x 8 output tiles; the B operand is supplied by the caller
-    auto run_chunk = [&](const uint4 &bh, const uint4 &bl) {
+    // npairs: output-tile pairs the layer really has (a narrow last layer -- the mask head's 256 -> n_inst -- skips the
+    // padded tiles: wave-uniform)
+    auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t npairs) {
         // chunk g has landed when at most the pieces of the chunks issued after it are still in flight
         const uint32_t later = total_chunks - 1u - g;
         if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #pragma unroll
         for (int pr = 0; pr < WIDE_MT / 2; ++pr) {
             const int cur = pr & 1, nxt = cur ^ 1;
+            if ((uint32_t)pr < npairs) {
             if (pr + 1 < WIDE_MT / 2) {
                 ah[nxt][0] = buf[(2 * pr + 2) * 128]; al[nxt][0] = buf[(2 * pr + 2) * 128 + 64];
                 ah[nxt][1] = buf[(2 * pr + 3) * 128]; al[nxt][1] = buf[(2 * pr + 3) * 128 + 64];
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
             acc[2 * pr] = c0; acc[2 * pr + 1] = c1;
+            }
             // the 4 DMA pieces of chunk g+3 go out one per pair (their issue overlaps the matrix pipe)
             if (more) dma16(nsrc + pr * 256, ndst + (uint32_t)pr * 4096u);
             __builtin_amdgcn_sched_barrier(0);
@@ -289,14 +293,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
                 acc[mt][4 * q] = b.x; acc[mt][4 * q + 1] = b.y; acc[mt][4 * q + 2] = b.z; acc[mt][4 * q + 3] = b.w;
             }
         }
+        const uint32_t npairs = (L.mt + 1u) >> 1;
         if (L.uses_h) {
 #pragma unroll
-            for (int k = 0; k < WIDE_HKS; ++k) run_chunk(hbh[k], hbl[k]);
+            for (int k = 0; k < WIDE_HKS; ++k) run_chunk(hbh[k], hbl[k], npairs);
         }
         for (uint32_t k = 0; k < L.x_ks; ++k) {
             uint4 bh, bl;
             x_operand(k, bh, bl);
-            run_chunk(bh, bl);
+            run_chunk(bh, bl, npairs);
         }
         if (l + 1u < a.nl) {
             // activation (network.py:65-66) + split into the next layer's B operands
