@@ -9,7 +9,8 @@ sigma/colour MLP, synthetic camera + random-init (hash-generated) weights, rays 
   --schedule flat128 (default): num_steps=[128]  = "128 samples/ray through the L=16 grid", configs[1] literally
   --schedule ref              : num_steps=[128,64,32] with both proposal grids = the reference's own default
 One "step" = one whole-image render: sn_rm_render_rays over this rank's row band (+ at N>1 the
-RCCL all-gather that assembles the image on every rank).  Weak scaling: the image grows to
+RCCL all-gather that assembles the image on every rank; the gather of frame k overlaps the render of
+frame k+1, all of them complete inside the timed region).  Weak scaling: the image grows to
 800 x (800*N) rows, each rank renders an 800-row band.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
@@ -72,7 +73,7 @@ def main():
 
     from helpers import product_model, synthetic_params
     from sanerf_hq_amd import _lib, raymarching as rm, synth
-    from sanerf_hq_amd.dist import gather_image, shard_rows
+    from sanerf_hq_amd.dist import PipelinedGather, shard_rows
 
     W = args.hw
     H = args.hw * world                      # weak scaling: one hw x hw band per rank
@@ -94,16 +95,20 @@ def main():
         params, model = models[schedule]
         plan = rm.RenderPlan(model, steps, torch.float16 if tables == "f16" else torch.float32)
         out = {}
+        # N > 1: the all-gather of frame k (RCCL, its own stream, over xGMI) overlaps the render of frame k+1; two
+        # rotating image buffers, everything in flight is drained inside the timed region
+        pipe = PipelinedGather(H, W, 5, dev, depth=2) if world > 1 else None
 
         def step():
             rm.render_rays(plan, rays_o, rays_d, tile_w=W, out=out)
             if world > 1:
                 band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
-                return gather_image(band, H, W)
-            return out["image"]
+                pipe.submit(band)
 
         for _ in range(n_warm):
             step()
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -112,6 +117,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

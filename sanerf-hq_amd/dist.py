@@ -86,3 +86,46 @@ def render_model_sharded(model, pose, intrinsics, H: int, W: int, group: Optiona
         return torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
 
     return render_image_sharded(rows, H, W, group, gather)
+
+
+class PipelinedGather:
+    """All-gather of frame k overlapped with the render of frame k+1.
+
+    `submit(local)` enqueues an asynchronous all-gather of this rank's band into one of `depth` rotating image
+    buffers and returns immediately: the collective runs on the communicator's own stream (over xGMI) while the next
+    frame's kernels run on the compute stream.  A buffer is reused only after its previous collective has finished.
+    `drain()` waits for everything in flight and returns the most recent complete image.  Requires equal bands
+    (H a multiple of 16*world); otherwise use `gather_image`."""
+
+    def __init__(self, H: int, W: int, K: int, device, depth: int = 2, group: Optional[dist.ProcessGroup] = None,
+                 dtype=torch.float32):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group = group
+        bands = all_shards(H, self.world)
+        rows = bands[0][1] - bands[0][0]
+        if any(e - b != rows for b, e in bands):
+            raise ValueError(f"PipelinedGather needs equal bands: image height {H} is not a multiple of {TILE_ROWS * self.world}")
+        self.local_numel = rows * W
+        self.images = [torch.empty(H * W, K, device=device, dtype=dtype) for _ in range(depth)]
+        self.works = [None] * depth
+        self.k = 0
+        self.last = None
+
+    def submit(self, local: torch.Tensor) -> None:
+        assert local.shape[0] == self.local_numel, f"expected a band of {self.local_numel} rays, got {local.shape[0]}"
+        slot = self.k % len(self.images)
+        if self.works[slot] is not None:
+            self.works[slot].wait()                 # the buffer's previous frame is complete
+        if self.world == 1:
+            self.images[slot].copy_(local)
+        else:
+            self.works[slot] = dist.all_gather_into_tensor(self.images[slot], local.contiguous(), group=self.group, async_op=True)
+        self.last = slot
+        self.k += 1
+
+    def drain(self) -> Optional[torch.Tensor]:
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
+        return None if self.last is None else self.images[self.last]

@@ -49,3 +49,30 @@ def test_sharded_render_equals_single_process(tmp_path, H, W):
         assert torch.equal(d["img"], full), f"rank {r} did not receive the full image"
         bands.append(d["band"])
     assert bands[0][0] == 0 and bands[0][1] == bands[1][0] and bands[1][1] == H
+
+
+def _pipe_worker(rank, world, port, H, W, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sanerf_hq_amd.dist import PipelinedGather, shard_rows
+    b, e = shard_rows(H, world, rank)
+    pg = PipelinedGather(H, W, 5, "cpu", depth=2)
+    frames = []
+    for k in range(5):                                   # five frames through two rotating buffers
+        pg.submit(_fake_render(H, W)(b, e) + float(k))
+    img = pg.drain().clone()
+    torch.save(img, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_overlaps_frames_and_keeps_order(tmp_path):
+    """bench.py's N>1 path: asynchronous all-gathers into rotating buffers; the drained image is the LAST frame."""
+    world, H, W = 2, 64, 24
+    mp.spawn(_pipe_worker, args=(world, _free_port(), H, W, str(tmp_path)), nprocs=world, join=True)
+    full = _fake_render(H, W)(0, H) + 4.0
+    for r in range(world):
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"p{r}.pt")), full)
