@@ -503,7 +503,7 @@ struct PropArgs {
 };
 
 template <typename TT, int L, int C, int HID, int K>
-__global__ __launch_bounds__(256, 3) void k_prop_stage(PropArgs a) {
+__global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
     constexpr int IN = L * C;
     __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];   // k-major [IN][HID]
     __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];        // [1][HID]
