@@ -27,6 +27,28 @@ __global__ __launch_bounds__(256) void k_gather(const float2 *__restrict__ tab, 
     }
     if (ax == 12345.678f) out[t] = ax + ay;
 }
+// cost of partially active gather instructions: ACT = 0 all lanes, 1 = even lanes only, 2 = lanes 0-31 only, 3 = random half;
+// every active lane reads its own line of an L2-resident table (the worst case for the line cost) or, COH, one shared line
+template <int ACT, bool COH>
+__global__ __launch_bounds__(256) void k_gather_masked(const float2 *__restrict__ tab, uint32_t mask, int iters, float *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = t >> 6, lane = t & 63u;
+    const bool act = ACT == 0 ? true : ACT == 1 ? (lane & 1u) == 0u : ACT == 2 ? lane < 32u : (hash32(lane * 7919u + 13u) & 1u) != 0u;
+    float ax = 0, ay = 0;
+    for (int it = 0; it < iters; ++it) {
+        float2 v[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const uint32_t row = COH ? ((hash32(wave * 977u + it * 131u + g) & mask & ~15u) | (lane & 15u)) : (hash32(t * 977u + it * 131u + g) & mask);
+            v[g] = make_float2(0.f, 0.f);
+            if (act) v[g] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(tab) + (size_t)row * 8u);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { ax += v[g].x; ay += v[g].y; }
+    }
+    if (ax == 12345.678f) out[t] = ax + ay;
+}
+
 int main() {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float *out; hipMalloc(&out, 1 << 24);
@@ -64,6 +86,19 @@ int main() {
             run(nm, [&] { hipLaunchKernelGGL((k_gather<16, L>), dim3(nblk), dim3(256), 0, 0, tab, mask, iters, out); }, n);
             LINES(4) LINES(8) LINES(16) LINES(32) LINES(64)
         }
+    }
+    // does the address path skip inactive lanes?
+    {
+        const uint32_t nblk = 2048; const double n = (double)nblk * 256 * iters * 16; const uint32_t mask = (1u << 19) - 1u;
+#define MASKED(A, C, label) run(label, [&] { hipLaunchKernelGGL((k_gather_masked<A, C>), dim3(nblk), dim3(256), 0, 0, tab, mask, iters, out); }, n);
+        MASKED(0, true, "coherent (1 line), all 64 lanes active")
+        MASKED(1, true, "coherent (1 line), even lanes active")
+        MASKED(2, true, "coherent (1 line), lanes 0-31 active")
+        MASKED(3, true, "coherent (1 line), random half active")
+        MASKED(0, false, "64 lines, all 64 lanes active")
+        MASKED(1, false, "64 lines, even lanes active (32 lines)")
+        MASKED(2, false, "64 lines, lanes 0-31 active (32 lines)")
+        MASKED(3, false, "64 lines, random half active (32 lines)")
     }
     return 0;
 }
