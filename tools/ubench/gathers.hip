@@ -49,6 +49,25 @@ __global__ __launch_bounds__(256) void k_gather_masked(const float2 *__restrict_
     if (ax == 12345.678f) out[t] = ax + ay;
 }
 
+// address-phase cost by element width: coherent gathers (one line per wave) of 4 / 8 / 16 bytes per lane
+template <typename V>
+__global__ __launch_bounds__(256) void k_gather_width(const char *__restrict__ tab, uint32_t mask, int iters, float *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = t >> 6, lane = t & 63u;
+    float ax = 0;
+    for (int it = 0; it < iters; ++it) {
+        V v[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const uint32_t line = hash32(wave * 977u + it * 131u + g) & (mask >> 4);
+            v[g] = *reinterpret_cast<const V *>(tab + (size_t)line * 128u + (lane * sizeof(V)) % 128u);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) ax += *reinterpret_cast<const float *>(&v[g]);
+    }
+    if (ax == 12345.678f) out[t] = ax;
+}
+
 int main() {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float *out; hipMalloc(&out, 1 << 24);
@@ -86,6 +105,12 @@ int main() {
             run(nm, [&] { hipLaunchKernelGGL((k_gather<16, L>), dim3(nblk), dim3(256), 0, 0, tab, mask, iters, out); }, n);
             LINES(4) LINES(8) LINES(16) LINES(32) LINES(64)
         }
+    }
+    {
+        const uint32_t nblk = 2048; const double n = (double)nblk * 256 * iters * 16; const uint32_t mask = (1u << 19) - 1u;
+        run("coherent, 4 bytes per lane (dword)", [&] { hipLaunchKernelGGL((k_gather_width<uint32_t>), dim3(nblk), dim3(256), 0, 0, (const char *)tab, mask, iters, out); }, n);
+        run("coherent, 8 bytes per lane (dwordx2)", [&] { hipLaunchKernelGGL((k_gather_width<uint2>), dim3(nblk), dim3(256), 0, 0, (const char *)tab, mask, iters, out); }, n);
+        run("coherent, 16 bytes per lane (dwordx4)", [&] { hipLaunchKernelGGL((k_gather_width<uint4>), dim3(nblk), dim3(256), 0, 0, (const char *)tab, mask, iters, out); }, n);
     }
     // does the address path skip inactive lanes?
     {
