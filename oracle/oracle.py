@@ -28,11 +28,22 @@ MAX_STAGES = 4
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with the committed Makefile (gcc, OpenMP)."""
+    import fcntl
     src = os.path.join(_HERE, "oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle.h"))
-    ):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+
+    def stale():
+        return force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle.h")))
+
+    if stale():
+        # several processes may get here at once (pytest -n, one rank per GPU): one builds, the others wait and re-check
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
