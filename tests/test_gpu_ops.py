@@ -202,6 +202,16 @@ def test_generate_rays_and_get_rays(gpu, orc):
     sub = get_rays(torch.from_numpy(pose)[None].to(gpu), np.array(intr, dtype=np.float32), H, W, 64, random_sample=True)
     idx = sub["j"] * W + sub["i"]
     assert torch.equal(sub["rays_d"], rd[idx])
+    # pixel-subset branch against the reference's own output (tests/golden/units.npz, coords = (row, col))
+    from helpers import golden
+    g = golden("units")
+    fx, fy, cx, cy, Hb, Wb = g["rays_b_intr"]
+    sub = get_rays(torch.from_numpy(g["rays_b_pose"])[None].to(gpu), np.array([fx, fy, cx, cy], dtype=np.float32), int(Hb), int(Wb),
+                   len(g["rays_b_coords"]), coords=torch.from_numpy(g["rays_b_coords"]).to(gpu))
+    assert np.array_equal(sub["rays_o"].cpu().numpy(), g["rays_b_sub_o"])
+    np.testing.assert_allclose(sub["rays_d"].cpu().numpy(), g["rays_b_sub_d"], rtol=0, atol=2e-7)
+    assert np.array_equal(sub["i"].cpu().numpy(), g["rays_b_sub_i"]) and np.array_equal(sub["j"].cpu().numpy(), g["rays_b_sub_j"])
+    assert np.array_equal(sub["inds_coarse"].cpu().numpy(), g["rays_b_sub_inds_coarse"])
     # error-map / incoherent-mask draws (utils.py:214-259): device-side multinomial, pixels land inside the drawn coarse cells
     M = 8
     mask = torch.zeros(M * M, device=gpu)

@@ -17,6 +17,13 @@ def test_get_rays(orc):
         np.testing.assert_allclose(rd, g[f"rays_{tag}_d"], rtol=0, atol=2e-7)   # torch bmm vs fmaf chain: 1 ulp
     # known answer from SURVEY.md §8a: 4x6 image, fovy 60, identity pose
     np.testing.assert_allclose(g["rays_a_d"][0], [-0.7217, 0.4330, -1.0], atol=1e-4)
+    # pixel-subset branch of the reference (coords = (row, col), utils.py:211-212): rows of the full image
+    fx, fy, cx, cy, H, W = g["rays_b_intr"]
+    ro, rd = orc.generate_rays(g["rays_b_pose"], fx, fy, cx, cy, int(H), int(W))
+    idx = g["rays_b_coords"][:, 0] * int(W) + g["rays_b_coords"][:, 1]
+    assert np.array_equal(ro[idx], g["rays_b_sub_o"])
+    np.testing.assert_allclose(rd[idx], g["rays_b_sub_d"], rtol=0, atol=2e-7)
+    assert np.array_equal(g["rays_b_sub_i"], g["rays_b_coords"][:, 1]) and np.array_equal(g["rays_b_sub_j"], g["rays_b_coords"][:, 0])
 
 
 def test_near_far_bit_exact(orc):

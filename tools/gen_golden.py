@@ -280,6 +280,13 @@ def fx_units(rr, ru, enc):
         out[f"rays_{tag}_o"], out[f"rays_{tag}_d"] = ro, rd
         o2, d2 = orc.generate_rays(pose, fx, fy, cx, cy, H, W)
         compare(f"get_rays[{tag}] rays_d", rd, d2, 1e-6); compare(f"get_rays[{tag}] rays_o", ro, o2, 0)
+        if tag == "b":   # pixel-subset branch (utils.py:211-212, 262-268, 294-300): coords = (row, col) pairs
+            coords = torch.tensor([[0, 0], [3, 5], [15, 23], [7, 11], [2, 20], [15, 0]])
+            sub = ru.get_rays(torch.from_numpy(pose)[None], np.array([fx, fy, cx, cy], dtype=np.float32), H, W, coords.shape[0], coords=coords)
+            out["rays_b_coords"] = np_(coords).astype(np.int64)
+            out["rays_b_sub_o"], out["rays_b_sub_d"] = np_(sub["rays_o"]).reshape(-1, 3), np_(sub["rays_d"]).reshape(-1, 3)
+            out["rays_b_sub_i"], out["rays_b_sub_j"] = np_(sub["i"]).reshape(-1).astype(np.int64), np_(sub["j"]).reshape(-1).astype(np.int64)
+            out["rays_b_sub_inds_coarse"] = np_(sub["inds_coarse"]).reshape(-1).astype(np.int64)
     # near_far (renderer.py:122-139), incl. rays that miss the box and axis-parallel rays
     g = torch.Generator().manual_seed(1)
     ro = (torch.rand(512, 3, generator=g) - 0.5) * 3
