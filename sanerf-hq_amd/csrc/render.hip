@@ -163,7 +163,7 @@ __device__ __forceinline__ void half_wave_swap(uint32_t &a, uint32_t &b) {
 
 // Dense levels re-laid out for the final stage (k_pack_pairs, once per render call, a few MB): pair row i of a level
 // = (row i, row of the +1 neighbour in x, clamped at the border) -> the two x-corners of a cell come from ONE
-// naturally aligned 16-byte (fp32) / 8-byte (fp16) load and the border case needs no select.  The gather address
+// naturally aligned 16-byte load and the border case needs no select (fp16: quad rows, the y-neighbours too).  The gather address
 // rate (one wave instruction per 17.5 cycles per CU) is what bounds the final stage: 4 loads
 // instead of 8 on the 5 dense levels = 108 instead of 128 gather instructions per sample.
 struct PairTab {
@@ -178,6 +178,26 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
     const T *tab = table + (size_t)g.off[l] * C;
     uint32_t cell[3], offs[8];
     locate_linear(x01, res, pos, cell);
+    if constexpr (PAIRA && KIND == 0 && C == 2 && sizeof(T) == 2) {
+        // fp16 rows are 4 bytes: a 16-byte load (which costs what an 8-byte one costs) carries the x- AND the
+        // y-neighbour: quad row i = rows (x,y), (x+1,y), (x,y+1), (x+1,y+1), clamped -> 2 loads per level
+        constexpr uint32_t QB = 16u;
+        const uint32_t sy = res * QB, sz = res * res * QB, top = res - 1u;
+        const uint32_t base_off = cell[0] * QB + __umul24(cell[1], sy);
+        const uint32_t Z0 = __umul24(cell[2], sz), Z1 = umin(Z0 + sz, top * sz);
+        const char *pbase = reinterpret_cast<const char *>(pt->base) + (size_t)pt->off[l] * QB;
+#pragma unroll
+        for (int zi = 0; zi < 2; ++zi) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(pbase + base_off + (zi ? Z1 : Z0));
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                   // q = x + 2 y -> corner index x + 2 y + 4 z
+                const __half2 h = *reinterpret_cast<const __half2 *>(&w[q]);
+                cv[4 * zi + q].v[0] = __low2float(h); cv[4 * zi + q].v[1] = __high2float(h);
+            }
+        }
+        return;
+    }
     if constexpr (PAIRA && KIND == 0 && C == 2) {
         constexpr uint32_t PB = (uint32_t)(2 * C * sizeof(T));
         const uint32_t sy = res * PB, sz = res * res * PB, top = res - 1u;
@@ -1225,7 +1245,8 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
 // When enabled, every kernel launched by sn_rm_render_rays is bracketed by hipEvents recorded
 // on the caller's stream; sn_rm_profile_read() synchronises them and returns, per kernel class,
 // the launch count and the summed device time.  Off by default (no events, no overhead).
-// pair rows of the dense levels (see PairTab): one thread per (level < K, row)
+// pair rows (fp32: row, +x neighbour) / quad rows (fp16: row, +x, +y, +x+y) of the dense levels (see PairTab): one
+// thread per (level < K, row); 16 bytes per vertex either way
 template <typename T>
 __global__ void k_pack_pairs(const T *__restrict__ table, GridLevels g, PairTab pt, uint32_t K) {
     const uint32_t l = blockIdx.y;
@@ -1240,8 +1261,10 @@ __global__ void k_pack_pairs(const T *__restrict__ table, GridLevels g, PairTab 
         const float2 a = reinterpret_cast<const float2 *>(tab)[i], b = reinterpret_cast<const float2 *>(tab)[j];
         reinterpret_cast<float4 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_float4(a.x, a.y, b.x, b.y);
     } else {
-        const uint32_t a = reinterpret_cast<const uint32_t *>(tab)[i], b = reinterpret_cast<const uint32_t *>(tab)[j];
-        reinterpret_cast<uint2 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_uint2(a, b);
+        const uint32_t y = (i / res) % res;
+        const uint32_t iy = i + (y + 1u < res ? res : 0u), jy = j + (y + 1u < res ? res : 0u);       // +1 in y, clamped
+        const uint32_t *tw = reinterpret_cast<const uint32_t *>(tab);
+        reinterpret_cast<uint4 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_uint4(tw[i], tw[j], tw[iy], tw[jy]);
     }
 }
 
@@ -1360,8 +1383,8 @@ int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
     return SN_OK;
 }
 
-// floats reserved after the packed MLP weights for the pair rows of one grid's dense levels (4 per row: sized for
-// fp32 tables, fp16 uses half of it)
+// floats reserved after the packed MLP weights for the pair / quad rows of one grid's dense levels (16 bytes per
+// vertex for either table type)
 static size_t pair_floats_of(const sn_grid_desc *d) {
     GridLevels g;
     if (d->D != 3 || d->C != 2 || build_grid_levels(&g, d->offsets, d->D, d->C, d->L, d->S, d->H, d->gridtype, (int)d->align_corners, d->interp) != SN_OK) return 0;
