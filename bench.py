@@ -206,7 +206,14 @@ def main():
         pick = (synth.hash_u01(n_cpu, 78) * n_local).astype(np.int64)
         t0 = time.perf_counter(); ref = orc.render(cfg, ro_h[pick], rd_h[pick]); t_cpu = time.perf_counter() - t0
         err = float(np.abs(out["image"][torch.from_numpy(pick).to(dev)].cpu().numpy() - ref["image"]).max())
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+        except OSError:
+            pass
         cpu_baseline = {"value": round(n_cpu / t_cpu, 1), "unit": "rays/s", "cores": orc.num_threads(), "kind": "port",
+                        "cpu_model": cpu_model, "nproc": os.cpu_count(),
                         "sample": f"{n_cpu} pseudo-random rays of the same {W}x{H} image, same weights, oracle/liboracle.so (C11+OpenMP), {t_cpu:.1f} s",
                         "max_abs_rgb_diff_vs_gpu": err}
 
