@@ -234,6 +234,12 @@ int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const fl
                         const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
                         sn_stream_t stream);
 
+/* Weight gradient of a small nn.Linear (the <= 64-wide radiance / proposal MLPs, nerf/network.py:9-29) over a
+ * training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order (deterministic).  K, N <= 64. */
+size_t sn_linear_wgrad_workspace_bytes(uint32_t M, uint32_t K, uint32_t N);
+int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uint32_t N, float *dw,
+                    void *workspace, size_t workspace_bytes, sn_stream_t stream);
+
 /* Measurement hook (bench.py): bracket every kernel sn_rm_render_rays launches with hipEvents on the
  * caller's stream.  Classes: 0 weight pack, 1..3 proposal stage k, 4 final stage.  profile_read
  * synchronises, returns summed device milliseconds and launch counts per class, and resets. */

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "sn_rm_grid_composite": (_int, [_vp, _vp, _u32, _u32, _f32, C.POINTER(GridDesc), _u32, _vp, _vp]),
     "sn_mlp_wide_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "sn_mlp_wide_forward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _f32, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
+    "sn_linear_wgrad_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32]),
+    "sn_linear_wgrad": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_render_workspace_bytes": (C.c_size_t, [C.POINTER(RenderCfg), _u32, _u32]),
     "sn_rm_render_rays": (_int, [C.POINTER(RenderCfg), C.POINTER(RenderIO), _vp]),
     "sn_rm_profile_enable": (None, [_int]),

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from ..activation import trunc_exp
 from ..encoding import get_encoder
+from ..ops import small_linear
 from .renderer import NeRFRenderer
 
 # constants the reference hard-codes in NeRFNetwork.__init__ (network.py:90-143)
@@ -41,8 +42,8 @@ class MLP(nn.Module):
     def forward(self, x):
         *hidden, last = self.net
         for layer in hidden:
-            x = F.relu(layer(x), inplace=True)
-        return last(x)
+            x = F.relu(small_linear(x, layer), inplace=True)
+        return small_linear(x, last)
 
 
 class SkipConnMLP(nn.Module):

@@ -336,3 +336,57 @@ class FreqEncoder(nn.Module):
         flat = inputs.reshape(-1, self.input_dim)
         out = freq_encode(flat, self.degree, self.output_dim)
         return out.reshape(lead + [self.output_dim])
+
+
+# ---------------------------------------------------------------------------------------------
+# small linear layers under autograd: weight gradient through sn_linear_wgrad
+# ---------------------------------------------------------------------------------------------
+LINEAR_WGRAD_MIN_ROWS = 16384      # below this the BLAS call is as fast
+
+_wgrad_ws: dict = {}
+
+
+class _small_linear(Function):
+    """y = x W^T (+ b) for a layer of at most 64 x 64 applied to many rows (the radiance / proposal MLPs of
+    nerf/network.py:9-29 during training).  Forward and input gradient are the usual GEMMs; the weight gradient --
+    a [<=64, <=64] result of a 1e5-long reduction, for which BLAS heuristics pick slow kernels -- is one call of
+    sn_linear_wgrad (deterministic summation order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
+        if ctx.needs_input_grad[0]:
+            gx = (gy2 @ weight).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1]).contiguous()
+            M, K, N = x2.shape[0], x2.shape[1], gy2.shape[1]
+            lib = _lib.lib()
+            need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
+            ws = _wgrad_ws.get(x2.device)
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x2.device)
+                _wgrad_ws[x2.device] = ws
+            gw = torch.empty(N, K, device=x2.device, dtype=torch.float32)
+            _lib.check(lib.sn_linear_wgrad(_lib.dev(x2, "x"), _lib.dev(gy2, "grad_output"), M, K, N, _lib.dev(gw, "grad_weight"),
+                                           ws.data_ptr(), ws.numel(), _lib.stream()), "sn_linear_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0)
+        return gx, gw, gb
+
+
+def small_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
+    """layer(x); with autograd on a large CUDA batch of a <= 64 x 64 fp32 layer the weight gradient uses the HIP kernel."""
+    w = layer.weight
+    rows = x.numel() // max(x.shape[-1], 1)
+    if (torch.is_grad_enabled() and w.requires_grad and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+            and w.shape[0] <= 64 and w.shape[1] <= 64 and rows >= LINEAR_WGRAD_MIN_ROWS):
+        return _small_linear.apply(x, w, layer.bias)
+    return layer(x)

@@ -382,3 +382,39 @@ def test_wide_mlp_rejects_unsupported_shapes(gpu):
     torch.manual_seed(1); m = MLP(32, 5, 256, 2, bias=False).to(gpu)
     with torch.no_grad():
         np.testing.assert_allclose(rm.mlp_forward(x, m).cpu().numpy(), m(x).cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,K,N", [(131072, 32, 64), (5000, 10, 16), (70001, 16, 1), (4096, 31, 32), (1, 64, 64)])
+def test_linear_wgrad_matches_matmul(gpu, M, K, N):
+    """sn_linear_wgrad: dw = dy^T x for the <= 64-wide layers of the radiance / proposal MLPs."""
+    import ctypes as C
+    from sanerf_hq_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(gpu)
+    dy = torch.randn(M, N, generator=g).to(gpu)
+    lib = _lib.lib()
+    need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=gpu)
+    dw = torch.empty(N, K, device=gpu)
+    _lib.check(lib.sn_linear_wgrad(x.data_ptr(), dy.data_ptr(), M, K, N, dw.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "wgrad")
+    ref = (dy.double().t() @ x.double()).float()
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((dw - ref).abs().max()) <= 2e-5 * scale * max(1.0, (M / 1e4) ** 0.5)
+    dw2 = torch.empty_like(dw)
+    _lib.check(lib.sn_linear_wgrad(x.data_ptr(), dy.data_ptr(), M, K, N, dw2.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "wgrad")
+    assert torch.equal(dw, dw2), "fixed summation order: bit-reproducible"
+    assert lib.sn_linear_wgrad_workspace_bytes(10, 65, 4) == 0
+
+
+def test_small_linear_autograd_equals_nn_linear(gpu):
+    from sanerf_hq_amd.ops import small_linear
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(32, 64, bias=True).to(gpu)
+    x = torch.randn(40000, 32, device=gpu, requires_grad=True)
+    y1 = small_linear(x, lin); (y1 * y1).sum().backward()
+    g1 = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None; lin.zero_grad()
+    y2 = lin(x); (y2 * y2).sum().backward()
+    assert torch.equal(y1, y2)
+    for a, b in zip(g1, (x.grad, lin.weight.grad, lin.bias.grad)):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
