@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import camera_rays, golden, oracle_cfg, params_from_spec, product_model, spec_of, synthetic_params
+from helpers import camera_rays, golden, make_opt as make_opt_local, oracle_cfg, params_from_spec, product_model, spec_of, synthetic_params
 
 pytestmark = pytest.mark.gpu
 
@@ -493,3 +493,30 @@ def test_randomised_shapes_vs_oracle(gpu, orc, case):
     np.testing.assert_allclose(tiled["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(tiled["depth"].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(tiled["weights_sum"].cpu().numpy(), want["weights_sum"], rtol=0, atol=1e-6)
+
+
+def test_uncontracted_scene_and_transparent_background(gpu, orc):
+    """Branches main.py never takes but the renderer has: contract=False (grid bound = scene bound, renderer.py:152-155,
+    positions are not warped) and a background other than 'last_sample' (no opaque last sample: weights_sum < 1 and
+    (1 - weights_sum) * bg_color shows through, renderer.py:313-315, 353)."""
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    steps = [64, 32, 16]
+    params = synthetic_params(steps, seed=41)
+    opt = make_opt_local(num_steps=steps, bound=2, contract=False, background="random")
+    model = NeRFNetwork(opt)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    assert not unexpected
+    model = model.to(gpu).eval()
+    assert model.bound == 2 and float(model.aabb_infer.abs().max()) == 2.0
+    _, _, ro, rd = camera_rays(orc, 24, 40, radius=0.8)
+    with torch.no_grad():
+        got = model.render(T(ro, gpu), T(rd, gpu), staged=False, perturb=False, bg_color=0.3, tile_w=40)
+    cfg = oracle_cfg(orc, params, steps)
+    cfg.contract, cfg.last_sample_opaque, cfg.bg_color, cfg.bound = 0, 0, 0.3, 2.0
+    for i, v in enumerate([-2.0] * 3 + [2.0] * 3):
+        cfg.aabb[i] = v
+    want = orc.render(cfg, ro, rd)
+    assert float(want["weights_sum"].min()) < 0.999, "the fixture must contain rays that stay partly transparent"
+    np.testing.assert_allclose(got["weights_sum"].cpu().numpy(), want["weights_sum"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got["depth"].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
