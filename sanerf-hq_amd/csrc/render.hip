@@ -618,6 +618,133 @@ __global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// proposal stage, sample-parallel variant for small ray batches (training steps: a few thousand rays)
+// ------------------------------------------------------------------------------------------
+// k_prop_stage walks one ray per lane: 4096 rays are 64 waves on a 1024-SIMD chip, each alone with its memory
+// latency, and a 128-sample stage takes 128 serial steps (0.55 ms for 4096 rays).  Here 8 lanes share a ray: each
+// evaluates a contiguous chunk of T/8 samples (the expensive part: position, grid, MLP), everything that must keep
+// the oracle's sequential order -- the fp64 optical-depth prefix, the cdf -- is done by the ray's first lane over
+// values parked in LDS (a few adds per sample), and the T_next + 1 resampled bins are found by a binary search
+// per output, 8 outputs at a time.  Same arithmetic, same order where order matters: bit-identical results.
+// Linear ray order only (scratch column = ray index), T <= SP_MAX_T.
+constexpr uint32_t SP_LPR = 8;            // lanes per ray
+constexpr uint32_t SP_MAX_T = 128;        // 3 arrays x 32 rays x (T+4) floats = 50 KiB of static LDS
+constexpr uint32_t SP_STRIDE = SP_MAX_T + 4;   // floats per ray per LDS array
+
+template <typename TT, int L, int C, int HID, int K>
+__global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
+    constexpr int IN = L * C;
+    __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];
+    __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];
+    __shared__ float l_bins[32][SP_STRIDE];     // stage bins b_0..b_T of the 32 rays of this workgroup
+    __shared__ float l_ds[32][SP_STRIDE];       // delta*sigma, then reused for the weights
+    __shared__ float l_cum[32][SP_STRIDE];      // (float) of the fp64 exclusive prefix of delta*sigma, then the cdf
+    stage_weights_t<IN, HID>(lds_w0, a.w0);
+    stage_weights<HID, 1>(lds_w1, a.w1);
+    const uint32_t tid = threadIdx.x, c = tid & (SP_LPR - 1u), rl = tid >> 3;          // chunk index, local ray
+    const uint32_t n_raw = blockIdx.x * 32u + rl;
+    const bool ok = n_raw < a.rc.N;
+    const uint32_t n = ok ? n_raw : 0u, r = n_raw;                                     // scratch column = ray index (linear order)
+    const uint32_t Npad = a.rc.Npad, T = a.T;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    const float b0step = 1.0f / (float)T;
+    auto bin_src = [&](uint32_t j) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
+        if (a.bins0_tab) return a.bins0_tab[j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+    for (uint32_t j = c; j <= T; j += SP_LPR) l_bins[rl][j] = bin_src(j);
+    __syncthreads();                                                                   // weights + bins in LDS
+    if (ok && a.dbg_bins) for (uint32_t j = c; j <= T; j += SP_LPR) a.dbg_bins[(size_t)n * (T + 1) + j] = l_bins[rl][j];
+
+    // ---- per-sample work, T/8 consecutive samples per lane ----
+    const uint32_t spl = (T + SP_LPR - 1u) / SP_LPR;
+    const TT *table = reinterpret_cast<const TT *>(a.table);
+    for (uint32_t i = 0; i < spl; ++i) {
+        const uint32_t jr = c * spl + i;
+        const uint32_t j = jr < T ? jr : T - 1u;                                       // lanes past the end redo the last sample
+        const float rb_prev = real_bin(rs, l_bins[rl][j]), rb_next = real_bin(rs, l_bins[rl][j + 1u]);
+        const float tmid = (rb_next + rb_prev) / 2.0f;
+        float p[3], x01[3];
+        sample_x01(a.rc, rs, tmid, p, x01);
+        float feat[L * C];
+        encode_levels<TT, L, C, K, true>(table, a.g, x01, feat, &a.pairs);
+        float h[HID], raw[1];
+        const uint32_t oz = opaque_zero();
+        dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
+        dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, raw);
+        const float sigma = expf_det(raw[0]);
+        float ds = (rb_next - rb_prev) * sigma;
+        if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+        if (jr < T) {
+            l_ds[rl][j] = ds;
+            if (ok && a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
+        }
+    }
+    __syncthreads();
+    // ---- exclusive prefix of delta*sigma in the oracle's order: fp64 running sum, rounded per prefix ----
+    if (c == 0u) {
+        double cum = 0.0;
+        for (uint32_t j = 0; j < T; ++j) { l_cum[rl][j] = (float)cum; cum += (double)l_ds[rl][j]; }
+    }
+    __syncthreads();
+    // ---- weights (renderer.py:308-325); their fp64 sum is exact in any order (addends within 2^7 of each other) ----
+    double wacc = 0.0;
+    for (uint32_t i = 0; i < spl; ++i) {
+        const uint32_t j = c * spl + i;
+        if (j < T) {
+            const float alpha = 1.0f - expf_det(-l_ds[rl][j]);
+            const float tr = expf_det(-l_cum[rl][j]);
+            float w = alpha * tr;
+            if (w != w) w = 0.0f;
+            wacc += (double)(w + 0.01f);
+            l_ds[rl][j] = w;                                                             // own slot: no hazard
+            a.w_scr[(size_t)j * Npad + r] = w;                                           // padding columns too, like k_prop_stage
+            if (ok && a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < (int)SP_LPR; d <<= 1) wacc += __shfl_xor(wacc, d, SP_LPR);
+    const float wsum = (float)wacc;
+    __syncthreads();
+    // ---- cdf (renderer.py:92-96): fp64 running sum of the pdf, rounded per prefix, clamped at 1 ----
+    if (c == 0u) {
+        double acc = 0.0;
+        l_cum[rl][0] = 0.0f;
+        for (uint32_t j = 0; j < T; ++j) {
+            const float pdf = (l_ds[rl][j] + 0.01f) / wsum;
+            acc += (double)pdf;
+            const float cv = (float)acc;
+            l_cum[rl][j + 1u] = cv > 1.0f ? 1.0f : cv;
+        }
+    }
+    __syncthreads();
+    // ---- resample: searchsorted(cdf, u, right=True) per output, then the interpolation of renderer.py:104-119 ----
+    const uint32_t Tq = a.Tn + 1u;
+    const float ustart = (float)(0.5 / Tq), uend = (float)(1 - 0.5 / Tq);
+    const float ustep = (uend - ustart) / (float)(Tq - 1u);
+    for (uint32_t jq = c; jq < Tq; jq += SP_LPR) {
+        const float uj = a.u_tab ? a.u_tab[jq] : linspace_at(ustart, uend, ustep, Tq, jq);
+        uint32_t lo = 0u, hi = T + 1u;                                                   // number of cdf[0..T] entries <= uj
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (l_cum[rl][mid] <= uj) lo = mid + 1u; else hi = mid;
+        }
+        const uint32_t i = lo;
+        float c0, c1, bb0, bb1;
+        if (i == 0u) { c0 = c1 = l_cum[rl][0]; bb0 = bb1 = l_bins[rl][0]; }
+        else if (i > T) { c0 = c1 = l_cum[rl][T]; bb0 = bb1 = l_bins[rl][T]; }
+        else { c0 = l_cum[rl][i - 1u]; c1 = l_cum[rl][i]; bb0 = l_bins[rl][i - 1u]; bb1 = l_bins[rl][i]; }
+        float t = nan_to_num((uj - c0) / (c1 - c0));
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        const float m = t * (bb1 - bb0);
+        a.bins_out[(size_t)jq * Npad + r] = bb0 + m;
+        if (ok && a.dbg_inds) a.dbg_inds[(size_t)n * Tq + jq] = (int32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // final stage
 // ------------------------------------------------------------------------------------------
 struct FinalArgs {
@@ -1143,6 +1270,205 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
 }
 
 // ------------------------------------------------------------------------------------------
+// final stage, sample-parallel variant for small linear-order batches (the counterpart of k_prop_stage_sp)
+// ------------------------------------------------------------------------------------------
+// 4096 rays are 16 workgroups of k_final_stage, each wave alone on its SIMD for T serial samples of ~19 us.  Here
+// lpr = 2^lpr_log2 lanes share a ray and evaluate spl consecutive samples each (lpr * spl >= T) with the same
+// pipelined gather / split-f16 MFMA code; per-sample results (delta*sigma, 15 geometry features, t_mid) are parked
+// in LDS.  The order-sensitive parts then run exactly as in the one-lane-per-ray kernel: the ray's first lane forms
+// the fp64 optical-depth prefix, every lane turns its own samples into weights, and each output channel is one
+// sample-ascending fmaf chain (channels dealt out to the ray's lanes).  The view MLP runs redundantly on all lanes of
+// a ray; the first one stores.  Bit-identical to k_final_stage<MLP_F16X3>.  No early termination here.
+constexpr int FSP_ROW = 65;                  // floats per (sample slot, channel) row: 64 lanes + 1 (bank spread)
+constexpr int FSP_CH = 16;                   // 15 geometry features + t_mid
+constexpr int FSP_DEPTH_ROW = 31;            // activation row that carries the depth (view MLP reads rows 0..30)
+constexpr uint32_t FSP_MAX_SPL = 4;
+static size_t final_sp_lds_floats(uint32_t spl) {
+    return (size_t)PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE + 4 * 512 + 4 * (size_t)spl * FSP_CH * FSP_ROW;
+}
+
+template <typename TT, int K>
+__global__ __launch_bounds__(256, 1) void k_final_stage_sp(FinalArgs a, uint32_t lpr_log2, uint32_t spl_log2) {
+    constexpr int L = 16, GEO = 15, NSH = 16, NCOL = GEO + NSH, VH = 32, PG = 4;
+    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;
+    constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += 256u)
+        reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, spl = 1u << spl_log2;
+    float *wave_base = lds + PACK_FLOATS + wave * WAVE_SLAB;
+    uint32_t *slab_hi = reinterpret_cast<uint32_t *>(wave_base), *slab_lo = slab_hi + 64 * SLAB_STRIDE;
+    float *fe = wave_base + lane;                           // activation column of this lane (after the march)
+    float *l_w = lds + PACK_FLOATS + 4 * WAVE_SLAB + wave * 512u;     // [ray][sample]: delta*sigma, then the weight
+    float *l_cum = l_w + 256;                                         // [ray][sample]: (float) fp64 prefix of delta*sigma
+    float *hs = lds + PACK_FLOATS + 4 * WAVE_SLAB + 4 * 512 + wave * (spl * FSP_CH * FSP_ROW);   // [slot][channel][lane]
+    __syncthreads();
+
+    const uint32_t lpr = 1u << lpr_log2, c = lane & (lpr - 1u), rw = lane >> lpr_log2, rpw = 64u >> lpr_log2;
+    const uint32_t r = (blockIdx.x * 4u + wave) * rpw + rw;           // scratch column = ray index; the grid covers Npad
+    const bool ok = r < a.rc.N;
+    const uint32_t n = ok ? r : 0u;
+    const uint32_t Npad = a.rc.Npad, T = a.T;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    const float b0step = 1.0f / (float)T;
+    auto bin_at = [&](uint32_t j) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
+        if (a.bins0_tab) return a.bins0_tab[j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+    float dirn[3] = {rs.d[0], rs.d[1], rs.d[2]};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float aa = dirn[0] * dirn[0], bb = dirn[1] * dirn[1], cc = dirn[2] * dirn[2];
+        const float nrm = sqrtf((aa + bb) + cc);
+        dirn[0] = dirn[0] / nrm; dirn[1] = dirn[1] / nrm; dirn[2] = dirn[2] / nrm;
+    }
+    const TT *table = reinterpret_cast<const TT *>(a.table);
+    const uint32_t jbase = c << spl_log2, rbase = rw << (lpr_log2 + spl_log2);   // first sample of this lane; ray's LDS row
+    if (ok && a.dbg_bins && c == 0u) a.dbg_bins[(size_t)n * (T + 1)] = bin_at(0);
+
+    // ---- march over this lane's samples; slots past T redo sample T-1 and store nothing ----
+    GroupRegs<TT, 2, PG> g0;
+    uint32_t j_n = jbase < T ? jbase : T - 1u;
+    float rb_prev_n = real_bin(rs, bin_at(j_n));
+    float bnext_n = bin_at(j_n + 1u);
+    float rb_next_n = real_bin(rs, bnext_n);
+    float tmid_n = (rb_next_n + rb_prev_n) / 2.0f;
+    float p_n[3], x01_n[3];
+    sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+    issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
+    __builtin_amdgcn_sched_barrier(0);
+    for (uint32_t i = 0; i < spl; ++i) {
+        const uint32_t jr = jbase + i, j = j_n;
+        const float bnext = bnext_n, rb_next = rb_next_n, rb_prev = rb_prev_n, tmid = tmid_n;
+        const float p[3] = {p_n[0], p_n[1], p_n[2]}, x01[3] = {x01_n[0], x01_n[1], x01_n[2]};
+        float h[16];
+        uint32_t *row_hi = slab_hi + lane * SLAB_STRIDE, *row_lo = slab_lo + lane * SLAB_STRIDE;
+        auto emit = [&](int l, const float (&acc)[2]) {
+            uint32_t ph, pl;
+            split2(acc[0], acc[1], ph, pl);
+            row_hi[l] = ph;
+            row_lo[l] = pl;
+        };
+        blend_group<TT, 2, PG, K, 0>(g0, emit);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<1, L / PG>([&](auto gg) {
+            constexpr int GRP = decltype(gg)::value;
+            GroupRegs<TT, 2, PG> gr;
+            issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr, a.pairs);
+            __builtin_amdgcn_sched_barrier(0);
+            blend_group<TT, 2, PG, K, GRP>(gr, emit);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        {
+            const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+            if (__builtin_expect(__any(oob), 0)) {
+                if (oob) for (int l = 0; l < L; ++l) { row_hi[l] = 0u; row_lo[l] = 0u; }
+            }
+        }
+        {   // geometry and first gather group of this lane's next sample (the last slot re-issues its own)
+            const uint32_t jq = jr + 1u;
+            j_n = (i + 1u < spl && jq < T) ? jq : j;
+            rb_prev_n = real_bin(rs, bin_at(j_n));
+            bnext_n = bin_at(j_n + 1u);
+            rb_next_n = real_bin(rs, bnext_n);
+            tmid_n = (rb_next_n + rb_prev_n) / 2.0f;
+            sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+            issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+        __builtin_amdgcn_wave_barrier();
+        const float sigma = expf_det(h[0]);
+        float ds = (rb_next - rb_prev) * sigma;
+        if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+        if (jr < T) {
+            l_w[rbase + jr] = ds;
+            float *rec = hs + (size_t)(i * FSP_CH) * FSP_ROW + lane;
+#pragma unroll
+            for (int ch = 0; ch < GEO; ++ch) rec[ch * FSP_ROW] = h[1 + ch];
+            rec[GEO * FSP_ROW] = tmid;
+            if (ok) {
+                if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + jr + 1] = bnext;
+                if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + jr] = sigma;
+                if (a.dbg_xyz) { float *q = a.dbg_xyz + ((size_t)n * T + jr) * 3; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+                if (a.dbg_geo) { float *q = a.dbg_geo + ((size_t)n * T + jr) * GEO;
+#pragma unroll
+                    for (int ch = 0; ch < GEO; ++ch) q[ch] = h[1 + ch]; }
+            }
+        }
+    }
+    __syncthreads();                          // per-sample records visible; the packed MLP weights are dead
+    stage_weights<NCOL, VH>(lds, a.vw[0]);
+    stage_weights<VH, VH>(lds + VW0, a.vw[1]);
+    stage_weights<VH, 3>(lds + VW0 + VW1, a.vw[2]);
+    if (c == 0u) {                            // optical depth before each sample: fp64 running sum, rounded per prefix
+        double cum = 0.0;
+        for (uint32_t j = 0; j < T; ++j) { l_cum[rbase + j] = (float)cum; cum += (double)l_w[rbase + j]; }
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < spl; ++i) {      // weights of this lane's samples (renderer.py:308-325)
+        const uint32_t j = jbase + i;
+        if (j < T) {
+            const float alpha = 1.0f - expf_det(-l_w[rbase + j]);
+            const float tr = expf_det(-l_cum[rbase + j]);
+            float w = alpha * tr;
+            if (w != w) w = 0.0f;
+            l_w[rbase + j] = w;
+            if (a.w_out) a.w_out[(size_t)j * Npad + r] = w;
+            if (ok && a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
+        }
+    }
+    __syncthreads();
+    // ---- compositing: one sample-ascending fmaf chain per channel, channels dealt out to the ray's lanes ----
+    double wsum = 0.0;
+    for (uint32_t j = 0; j < T; ++j) wsum += (double)l_w[rbase + j];
+    float *ray_col = wave_base + (rw << lpr_log2);           // activation column of the ray's first lane (slab is dead)
+    for (uint32_t ch = c; ch < (uint32_t)FSP_CH; ch += lpr) {
+        float acc = 0.0f;
+        for (uint32_t j = 0; j < T; ++j) {
+            const uint32_t cj = j >> spl_log2, ij = j & (spl - 1u);
+            acc = __builtin_fmaf(l_w[rbase + j], hs[(size_t)(ij * FSP_CH + ch) * FSP_ROW + (rw << lpr_log2) + cj], acc);
+        }
+        ray_col[(ch < (uint32_t)GEO ? ch : (uint32_t)FSP_DEPTH_ROW) * 64u] = acc;
+    }
+    const float ws = (float)wsum;
+    if (c == 0u) {
+        float sh[NSH];
+        sh_degree4(dirn[0], dirn[1], dirn[2], sh);
+#pragma unroll
+        for (int k = 0; k < NSH; ++k) ray_col[(GEO + k) * 64] = sh[k] * ws;
+    }
+    __builtin_amdgcn_wave_barrier();          // the ray's lanes live in one wave; LDS serves a wave in order
+    const float dep = ray_col[FSP_DEPTH_ROW * 64];
+    if (ok && c == 0u && a.dbg_fimg) {
+        for (int k = 0; k < NCOL; ++k) a.dbg_fimg[(size_t)n * NCOL + k] = ray_col[k * 64];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float rgb[3];
+    dense_ldsw_col<NCOL, VH, 1>(lds, ray_col, fe, 64u);       // every lane of the ray: same inputs, own output column
+    dense_ldsw_col<VH, VH, 1>(lds + VW0, fe, fe, 64u);
+    {
+        float v2[VH];
+#pragma unroll
+        for (int k = 0; k < VH; ++k) v2[k] = fe[k * 64];
+        dense_ldsw<VH, 3, 0>(lds + VW0 + VW1, v2, rgb);
+    }
+    if (ok && c == 0u) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sg = 1.0f / (1.0f + expf_det(-rgb[k]));
+            const float bgm = (1.0f - ws) * a.rc.bg;
+            a.image[(size_t)n * 3 + k] = sg + bgm;
+        }
+        a.depth[n] = dep;
+        a.wsum[n] = ws;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // feature stage: f[n, :] = sum_j w[n,j] * feat_grid(xyz[n,j])   (renderer.py:301-302 + 361, the SAM head's f_sam)
 // ------------------------------------------------------------------------------------------
 // Runs after the final stage on the same lane -> ray mapping.  Sample positions are recomputed from the last
@@ -1322,6 +1648,17 @@ static uint32_t chunk_rays(uint32_t N, uint32_t W) {
     if (N <= cap) return N;
     if (W) { uint32_t rows = (cap / W) & ~15u; if (rows < 16) rows = 16; return rows * W; }
     return cap;
+}
+
+// rays per render_rays chunk up to which the proposal stages run sample-parallel; SN_PROP_SP_MAX overrides (0 = never)
+static uint32_t prop_sp_max_rays() {
+    const char *e = getenv("SN_PROP_SP_MAX");
+    return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;   // tools/prop_sp_ab.py: faster up to 32k rays, slower from 64k
+}
+
+static uint32_t final_sp_max_rays() {
+    const char *e = getenv("SN_FINAL_SP_MAX");
+    return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u;
 }
 
 static uint32_t blocks_for(uint32_t n, uint32_t W) {
@@ -1571,9 +1908,14 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 ProfScope ps(st, PK_PROP0 + (int)k);
                 const int K = dense_prefix(gl_prop[k]);
                 const bool h16 = cfg->prop_grid[k].table_dtype != SN_F32;
+                // few rays in linear order (training batches): 8 lanes per ray instead of one (k_prop_stage_sp)
+                const bool sp = W == 0 && n <= prop_sp_max_rays() && pa.T <= SP_MAX_T;
+                const uint32_t nblk_sp = Npad / 32u;            // every scratch column, like the one-lane-per-ray launch
 #define SN_LAUNCH_PROP(KK)                                                                                         \
                 do {                                                                                               \
-                    if (h16) hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa); \
+                    if (sp && h16) hipLaunchKernelGGL((k_prop_stage_sp<__half, 5, 2, 16, KK>), dim3(nblk_sp), dim3(256), 0, st, pa); \
+                    else if (sp) hipLaunchKernelGGL((k_prop_stage_sp<float, 5, 2, 16, KK>), dim3(nblk_sp), dim3(256), 0, st, pa);  \
+                    else if (h16) hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa); \
                     else hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa);     \
                 } while (0)
                 if (K == 3) SN_LAUNCH_PROP(3);          // prop0: res 16, 27, 46 dense (network.py:135)
@@ -1626,7 +1968,26 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = dense_prefix(gl_main);
-        if (mlp_mode == MLP_F16X3) {
+        // few rays in linear order: lanes share rays (k_final_stage_sp); fewer samples per lane while CUs would idle
+        const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && n <= final_sp_max_rays() &&
+                              fa.T <= 64u * FSP_MAX_SPL;
+        if (final_sp) {
+            auto lpr_log2_of = [&](uint32_t sl) { const uint32_t need = div_up(fa.T, 1u << sl); uint32_t l2 = 0; while ((1u << l2) < need) ++l2; return l2; };
+            uint32_t spl_log2 = 2;
+            while (spl_log2 > 0 && div_up(fa.T, 1u << (spl_log2 - 1)) <= 64u && (((size_t)Npad << lpr_log2_of(spl_log2)) >> 8) < 256u) --spl_log2;
+            const uint32_t lpr_log2 = lpr_log2_of(spl_log2);
+            const uint32_t blocks = (uint32_t)(((size_t)Npad << lpr_log2) >> 8);
+            const size_t lds_bytes = final_sp_lds_floats(1u << spl_log2) * sizeof(float);
+#define SN_LAUNCH_FINAL_SP(TT_, KK)                                                                                              \
+            do {                                                                                                             \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_sp<TT_, KK>),                    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
+                hipLaunchKernelGGL((k_final_stage_sp<TT_, KK>), dim3(blocks), dim3(256), lds_bytes, st, fa, lpr_log2, spl_log2); \
+            } while (0)
+            if (Kmain == 5) { if (f16) SN_LAUNCH_FINAL_SP(__half, 5); else SN_LAUNCH_FINAL_SP(float, 5); }
+            else { if (f16) SN_LAUNCH_FINAL_SP(__half, -1); else SN_LAUNCH_FINAL_SP(float, -1); }
+#undef SN_LAUNCH_FINAL_SP
+        } else if (mlp_mode == MLP_F16X3) {
             if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
             else SN_LAUNCH_FINAL_AUX(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);
         } else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, -1, PACK_FLOATS + 4 * 32 * 64);       // 64 KiB

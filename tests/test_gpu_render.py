@@ -495,6 +495,56 @@ def test_randomised_shapes_vs_oracle(gpu, orc, case):
     np.testing.assert_allclose(tiled["weights_sum"].cpu().numpy(), want["weights_sum"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("steps,f16", [([128, 64, 32], False), ([33, 17, 9], True), ([20, 40, 10], False), ([128, 128], True),
+                                        ([128], False), ([200], True), ([7], False)])
+def test_sample_parallel_stages_are_bit_identical(gpu, orc, steps, f16, monkeypatch):
+    """Small linear-order batches (training steps) run every stage with several lanes per ray (k_prop_stage_sp,
+    k_final_stage_sp); every tensor must equal the one-lane-per-ray kernels' bit for bit, and the sample indices the
+    oracle's.  Ray counts that are not multiples of 32 / 256 exercise the padding columns, step counts that are not
+    multiples of the samples per lane the masked slots."""
+    from sanerf_hq_amd import raymarching as rm
+    params = synthetic_params(steps, seed=77)
+    model = product_model(params, steps, False, gpu)
+    _, _, ro, rd = camera_rays(orc, 23, 31, radius=0.9, elev=35.0, azim=200.0)      # 713 rays
+    plan = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32)
+    want = ("bins", "weights", "sigmas", "inds", "xyzs_last", "geo_feat_last", "f_image")
+
+    def run(limit):
+        monkeypatch.setenv("SN_PROP_SP_MAX", limit)
+        monkeypatch.setenv("SN_FINAL_SP_MAX", limit)
+        res = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, want=want, out={})
+        plain = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, out={})       # no per-sample outputs requested
+        assert torch.equal(res["image"], plain["image"]) and torch.equal(res["depth"], plain["depth"])
+        return {k: v.clone() for k, v in res.items()}
+    lane, sp = run("0"), run("1000000")
+    assert set(lane) == set(sp)
+    for k in lane:
+        assert torch.equal(lane[k], sp[k]), k
+    ref = orc.render(oracle_cfg(orc, params, steps, table_f16=f16), ro, rd, debug=True)
+    for k in range(1, len(steps)):
+        assert np.array_equal(sp[f"inds{k}"].cpu().numpy(), ref[f"inds{k}"])
+    np.testing.assert_allclose(sp["image"].cpu().numpy(), ref["image"], rtol=0, atol=1e-5)
+
+
+def test_sample_parallel_final_stage_feeds_the_feature_stage(gpu, orc, monkeypatch):
+    """The SAM feature stage reads the final stage's weights from scratch: same f_feat from either final-stage kernel."""
+    from sanerf_hq_amd import raymarching as rm
+    steps = [64, 32]
+    params = synthetic_params(steps, heads=True, seed=5)
+    model = product_model(params, steps, True, gpu)
+    _, _, ro, rd = camera_rays(orc, 19, 27)
+    plan = rm.RenderPlan(model, steps, feat_encoder=model.s_grid)
+    outs = []
+    for limit in ("0", "1000000"):
+        monkeypatch.setenv("SN_PROP_SP_MAX", limit)
+        monkeypatch.setenv("SN_FINAL_SP_MAX", limit)
+        res = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, out={})
+        outs.append({k: v.clone() for k, v in res.items()})
+    assert float(outs[0]["f_feat"].abs().max()) > 0
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_uncontracted_scene_and_transparent_background(gpu, orc):
     """Branches main.py never takes but the renderer has: contract=False (grid bound = scene bound, renderer.py:152-155,
     positions are not warped) and a background other than 'last_sample' (no opaque last sample: weights_sum < 1 and
