@@ -234,8 +234,11 @@ int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const fl
                         const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
                         sn_stream_t stream);
 
-/* Weight gradient of a small nn.Linear (the <= 64-wide radiance / proposal MLPs, nerf/network.py:9-29) over a
- * training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order (deterministic).  K, N <= 64. */
+/* Weight gradient of an nn.Linear over a training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order
+ * (deterministic).  K, N <= 64 (the radiance / proposal MLPs, nerf/network.py:9-29): register-tiled VALU kernel.
+ * Otherwise N <= 256, any K (the per-sample mask head and the SAM head, network.py:31-66): v_mfma_f32_32x32x2_f32 over
+ * row slabs, one per CU.  workspace: >= sn_linear_wgrad_workspace_bytes() (0 = shape not supported), holds the
+ * per-slab partial results. */
 size_t sn_linear_wgrad_workspace_bytes(uint32_t M, uint32_t K, uint32_t N);
 int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uint32_t N, float *dw,
                     void *workspace, size_t workspace_bytes, sn_stream_t stream);

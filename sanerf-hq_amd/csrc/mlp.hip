@@ -22,6 +22,7 @@
 // layer's 256 outputs, 16 k-steps), then x-input k-steps (layer 0 and skip layers; input width padded
 // to a multiple of 16).  Chunk = [mt 8][hi|lo][lane 64] uint4.
 #include "sn_common.h"
+#include <type_traits>
 
 namespace sn {
 
@@ -581,23 +582,196 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_sum(const float *__restric
     if (o < NK && s == 0u) dw[o] = v;
 }
 
+
+// the same sum for large outputs (NK % 4 == 0): 16 lanes x float4 = 256 contiguous bytes per slab, 16 slab groups per
+// workgroup each walking its slabs in order, then the 16 group sums are added in order through LDS
+__global__ __launch_bounds__(256) void k_linear_wgrad_sum4(const float4 *__restrict__ partial, uint32_t nslab, uint32_t NK4, float4 *__restrict__ dw) {
+    __shared__ float4 red[16][16];
+    const uint32_t ol = threadIdx.x & 15u, sg = threadIdx.x >> 4, o = blockIdx.x * 16u + ol;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (o < NK4)
+        for (uint32_t b = sg; b < nslab; b += 16u) {
+            const float4 p = partial[(size_t)b * NK4 + o];
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+    red[sg][ol] = v;
+    __syncthreads();
+    if (sg == 0u && o < NK4) {
+        float4 t = red[0][ol];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) { const float4 p = red[g][ol]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+        dw[o] = t;
+    }
+}
+
+// ---- the same reduction for wide layers (mask / SAM head MLPs: up to 256 outputs, any fan-in) on the matrix cores ----
+// dw = dy^T x is a [N x K] result of an M-long reduction (M = 131072 samples per mask-mode step): BLAS picks 32x64
+// macro-tiles, i.e. 32 workgroups walking all of M (0.39 ms per 256 x 256 layer, 0.31 ms for the 2 x 256 one).  Here
+// the reduction is split instead: a workgroup owns a slab of rows and the whole output (4 waves x 64 output rows x up
+// to 256 columns = all 256 accumulator registers of a lane), feeds v_mfma_f32_32x32x2_f32 straight from coalesced
+// global loads (lane l supplies A[i = l%32][k = l/32] = dy[m0 + l/32][i] and B[k][j = l%32] = x[m0 + l/32][j]: rows
+// of the row-major operands, no transpose, no LDS), and writes its partial result; k_linear_wgrad_sum adds the slabs
+// in a fixed order.  True fp32 products and accumulation.
+//   VEC : x rows and dy rows are read as float4 / float2; the MFMA row / column index is then a permutation of the
+//         real one (tile column jj of block cb <-> real column 4*jj + cb%4 of a 128-wide group), undone on store.
+//   FLAT: N <= 32 (the 2-output last layer): one row block, the four waves split the columns instead.
+
+template <int CBW, bool VEC, bool FLAT>
+__global__ __launch_bounds__(256, 1) void k_linear_wgrad_mfma(const float *__restrict__ x, const float *__restrict__ dy, uint32_t M,
+                                                              uint32_t K, uint32_t N, uint32_t rows_per_slab, float *__restrict__ partial) {
+    constexpr int RBW = FLAT ? 1 : 2;
+    // steps (of 2 rows) whose operands are in flight ahead of the matrix cores: ~8k clocks of MFMA work, the latency
+    // of a loaded HBM system (4 steps = 4k clocks left the 256 x 256 case waiting on loads: 193 us instead of ~110)
+    constexpr int WGM_PF = FLAT ? 32 : (CBW <= 4 ? 16 : 8);
+    static_assert(!VEC || (CBW % 4 == 0 && !FLAT), "vector loads cover four column blocks / two row blocks at a time");
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, lo = lane & 31u, hi = lane >> 5;
+    const uint32_t r0 = FLAT ? 0u : 64u * wave;                                        // first output row of this wave
+    const uint32_t c0 = (FLAT ? (blockIdx.y * 4u + wave) : blockIdx.y) * (CBW * 32u);  // first column of this wave
+    const uint32_t m_begin = blockIdx.x * rows_per_slab;
+    const uint32_t m_end = m_begin + rows_per_slab < M ? m_begin + rows_per_slab : M;
+    struct Step { float a[RBW]; float b[CBW]; };
+    // Output rows >= N / columns >= K are never stored, so their operands may be anything finite or not: addresses
+    // are clamped into the arrays and nothing is selected after the load (a select per loaded value made the
+    // compiler wait for every load of an unrolled group at once: 193 us instead of ~120 for the 256 x 256 layer).
+    // Only the reduction index needs real masking, and only in the tail of a slab (MASK).
+    auto load = [&](Step &s, uint32_t t, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const uint32_t m = m_begin + 2u * t + hi;
+        const bool mv = !MASK || m < m_end;
+        const size_t mr = mv ? m : m_begin;
+        if constexpr (VEC) {
+            const uint32_t i = r0 + 2u * lo;
+            const float2 v = *reinterpret_cast<const float2 *>(dy + mr * N + (i < N ? i : N - 2u));
+            s.a[0] = mv ? v.x : 0.0f; s.a[1] = mv ? v.y : 0.0f;
+#pragma unroll
+            for (int g = 0; g < CBW / 4; ++g) {
+                const uint32_t j = c0 + 128u * g + 4u * lo;
+                const float4 w = *reinterpret_cast<const float4 *>(x + mr * K + (j < K ? j : K - 4u));
+                s.b[4 * g + 0] = mv ? w.x : 0.0f; s.b[4 * g + 1] = mv ? w.y : 0.0f;
+                s.b[4 * g + 2] = mv ? w.z : 0.0f; s.b[4 * g + 3] = mv ? w.w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                const uint32_t i = r0 + 32u * rb + lo;
+                const float v = dy[mr * N + (i < N ? i : N - 1u)];
+                s.a[rb] = mv ? v : 0.0f;
+            }
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const uint32_t j = c0 + 32u * cb + lo;
+                const float v = x[mr * K + (j < K ? j : K - 1u)];
+                s.b[cb] = mv ? v : 0.0f;
+            }
+        }
+    };
+    floatx16 acc[RBW][CBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto fma_step = [&](const Step &cur) {
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[rb], cur.b[cb], acc[rb][cb], 0, 0, 0);
+    };
+    const uint32_t rows = m_end > m_begin ? m_end - m_begin : 0u;
+    const uint32_t nmain = (rows / 2u) / WGM_PF * WGM_PF;        // whole steps taken by the pipelined loop
+    if (nmain) {
+        Step ring[WGM_PF];
+#pragma unroll
+        for (int u = 0; u < WGM_PF; ++u) load(ring[u], (uint32_t)u, std::false_type{});
+        for (uint32_t t = 0; t < nmain; t += WGM_PF) {
+#pragma unroll
+            for (int u = 0; u < WGM_PF; ++u) {
+                // the scheduler would sink each load to its first use (no prefetch left): pin the order
+                fma_step(ring[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t tn = t + WGM_PF + u;
+                load(ring[u], tn < nmain ? tn : nmain - 1u, std::false_type{});     // last round: a valid step again, unused
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    for (uint32_t t = nmain; 2u * t < rows; ++t) {               // fewer than WGM_PF steps, the last one maybe half
+        Step cur;
+        load(cur, t, std::true_type{});
+        fma_step(cur);
+    }
+    // accumulator register r of lane l holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+    float *out = partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t rho = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if constexpr (VEC) {
+                const uint32_t i = r0 + 2u * rho + rb;
+#pragma unroll
+                for (int g = 0; g < CBW / 4; ++g) {
+                    const uint32_t j = c0 + 128u * g + 4u * lo;
+                    if (i < N && j < K)
+                        *reinterpret_cast<float4 *>(out + (size_t)i * K + j) =
+                            make_float4(acc[rb][4 * g][r], acc[rb][4 * g + 1][r], acc[rb][4 * g + 2][r], acc[rb][4 * g + 3][r]);
+                }
+            } else {
+                const uint32_t i = r0 + 32u * rb + rho;
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) {
+                    const uint32_t j = c0 + 32u * cb + lo;
+                    if (i < N && j < K) out[(size_t)i * K + j] = acc[rb][cb][r];
+                }
+            }
+        }
+}
+
+constexpr uint32_t WGM_MAX_N = 256;      // 4 waves x 64 output rows
+static uint32_t wgm_rows_per_slab(uint32_t M) {      // one slab per CU, at least 64 rows, an even count
+    uint32_t r = div_up(M ? M : 1u, 256u);
+    if (r < 64u) r = 64u;
+    return (r + 1u) & ~1u;
+}
 }  // namespace sn
 
 extern "C" size_t sn_linear_wgrad_workspace_bytes(uint32_t M, uint32_t K, uint32_t N) {
-    if (K == 0 || N == 0 || K > 64 || N > 64) return 0;
+    if (K == 0 || N == 0 || N > sn::WGM_MAX_N) return 0;
+    if (K > 64 || N > 64) return (size_t)sn::div_up(M ? M : 1u, sn::wgm_rows_per_slab(M)) * N * K * sizeof(float);
     const uint32_t tiles = sn::div_up(M ? M : 1u, sn::WG_ROWS);
     return (size_t)(tiles < sn::WG_MAX_SLABS ? tiles : sn::WG_MAX_SLABS) * N * K * sizeof(float);
 }
 
 extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uint32_t N, float *dw,
                                void *workspace, size_t workspace_bytes, sn_stream_t stream) {
-    SN_REQUIRE(K >= 1 && N >= 1 && K <= 64 && N <= 64, "linear_wgrad: built for layers up to 64 x 64 (got %u x %u)", N, K);
+    SN_REQUIRE(K >= 1 && N >= 1 && N <= sn::WGM_MAX_N, "linear_wgrad: built for layers of up to %u outputs (got %u x %u)", sn::WGM_MAX_N, N, K);
     SN_REQUIRE(dw, "linear_wgrad: dw is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) { SN_HIP_OK(hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), st)); return SN_OK; }
     SN_REQUIRE(x && dy && workspace, "linear_wgrad: x/dy/workspace must be device pointers");
     const size_t need = sn_linear_wgrad_workspace_bytes(M, K, N);
     SN_REQUIRE(workspace_bytes >= need, "linear_wgrad: workspace too small (%zu bytes, need %zu)", workspace_bytes, need);
+    if (K > 64 || N > 64) {      // wide layer: matrix cores, split over row slabs
+        const uint32_t rps = sn::wgm_rows_per_slab(M), nslab = sn::div_up(M, rps);
+        float *part = reinterpret_cast<float *>(workspace);
+        const bool vec = K % 4 == 0 && N % 2 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 8 == 0) && ((uintptr_t)part % 16 == 0);
+#define SN_WGM(CBW, VEC, FLAT, GY) hipLaunchKernelGGL((sn::k_linear_wgrad_mfma<CBW, VEC, FLAT>), dim3(nslab, GY), dim3(256), 0, st, x, dy, M, K, N, rps, part)
+        if (N <= 32) SN_WGM(2, false, true, sn::div_up(K, 256));
+        else if (vec) { if (K <= 128) SN_WGM(4, true, false, 1); else SN_WGM(8, true, false, sn::div_up(K, 256)); }   // (two half-width workgroups per CU: slower)
+        else if (K <= 64) SN_WGM(2, false, false, 1);
+        else if (K <= 128) SN_WGM(4, false, false, 1);
+        else if (K <= 192) SN_WGM(6, false, false, 1);
+        else SN_WGM(8, false, false, sn::div_up(K, 256));
+#undef SN_WGM
+        SN_LAUNCH_CHECK("k_linear_wgrad_mfma");
+        if ((N * K) % 4u == 0 && (uintptr_t)dw % 16 == 0 && (uintptr_t)part % 16 == 0)
+            hipLaunchKernelGGL(sn::k_linear_wgrad_sum4, dim3(sn::div_up(N * K / 4u, 16)), dim3(256), 0, st, reinterpret_cast<const float4 *>(part), nslab,
+                               N * K / 4u, reinterpret_cast<float4 *>(dw));
+        else
+            hipLaunchKernelGGL(sn::k_linear_wgrad_sum, dim3(sn::div_up(N * K, 16)), dim3(256), 0, st, part, nslab, N * K, dw);
+        SN_LAUNCH_CHECK("k_linear_wgrad_sum");
+        return SN_OK;
+    }
     const uint32_t tiles = sn::div_up(M, sn::WG_ROWS);
     const uint32_t nslab = tiles < sn::WG_MAX_SLABS ? tiles : sn::WG_MAX_SLABS;
     hipLaunchKernelGGL(sn::k_linear_wgrad_partial, dim3(nslab), dim3(256), 0, st, x, dy, M, K, N, reinterpret_cast<float *>(workspace));

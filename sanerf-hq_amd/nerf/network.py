@@ -62,7 +62,7 @@ class SkipConnMLP(nn.Module):
         for i, layer in enumerate(self.net):
             if i in self.skip_layers:
                 h = torch.cat([h, x], dim=-1)
-            h = layer(h)
+            h = small_linear(h, layer)
             if i != self.num_layers - 1:
                 h = F.leaky_relu(h, inplace=True)
         return h

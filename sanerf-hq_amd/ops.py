@@ -342,15 +342,16 @@ class FreqEncoder(nn.Module):
 # small linear layers under autograd: weight gradient through sn_linear_wgrad
 # ---------------------------------------------------------------------------------------------
 LINEAR_WGRAD_MIN_ROWS = 16384      # below this the BLAS call is as fast
+LINEAR_WGRAD_MAX_OUT = 256         # sn_linear_wgrad's output rows (any fan-in)
 
 _wgrad_ws: dict = {}
 
 
 class _small_linear(Function):
-    """y = x W^T (+ b) for a layer of at most 64 x 64 applied to many rows (the radiance / proposal MLPs of
-    nerf/network.py:9-29 during training).  Forward and input gradient are the usual GEMMs; the weight gradient --
-    a [<=64, <=64] result of a 1e5-long reduction, for which BLAS heuristics pick slow kernels -- is one call of
-    sn_linear_wgrad (deterministic summation order)."""
+    """y = x W^T (+ b) for a layer of at most 256 outputs applied to many rows (the radiance / proposal MLPs of
+    nerf/network.py:9-29 and the per-sample mask head of network.py:31-66 during training).  Forward and input
+    gradient are the usual GEMMs; the weight gradient -- a small result of a 1e5-long reduction, for which BLAS
+    heuristics pick slow kernels -- is one call of sn_linear_wgrad (deterministic summation order)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -383,10 +384,10 @@ class _small_linear(Function):
 
 
 def small_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
-    """layer(x); with autograd on a large CUDA batch of a <= 64 x 64 fp32 layer the weight gradient uses the HIP kernel."""
+    """layer(x); with autograd on a large CUDA batch of an fp32 layer of <= 256 outputs the weight gradient uses the HIP kernel."""
     w = layer.weight
     rows = x.numel() // max(x.shape[-1], 1)
     if (torch.is_grad_enabled() and w.requires_grad and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
-            and w.shape[0] <= 64 and w.shape[1] <= 64 and rows >= LINEAR_WGRAD_MIN_ROWS):
+            and w.shape[0] <= LINEAR_WGRAD_MAX_OUT and rows >= LINEAR_WGRAD_MIN_ROWS):
         return _small_linear.apply(x, w, layer.bias)
     return layer(x)

@@ -403,7 +403,35 @@ def test_linear_wgrad_matches_matmul(gpu, M, K, N):
     dw2 = torch.empty_like(dw)
     _lib.check(lib.sn_linear_wgrad(x.data_ptr(), dy.data_ptr(), M, K, N, dw2.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "wgrad")
     assert torch.equal(dw, dw2), "fixed summation order: bit-reproducible"
-    assert lib.sn_linear_wgrad_workspace_bytes(10, 65, 4) == 0
+    assert lib.sn_linear_wgrad_workspace_bytes(10, 65, 257) == 0, "more than 256 outputs: not this kernel's shape"
+
+
+@pytest.mark.parametrize("M,K,N", [(131072, 256, 256), (131072, 143, 256), (131072, 256, 2), (20001, 419, 256), (16385, 77, 100),
+                                   (4097, 256, 33), (70000, 128, 128), (3, 200, 256), (50000, 66, 30)])
+def test_linear_wgrad_wide_layers(gpu, M, K, N):
+    """The matrix-core path of sn_linear_wgrad (mask / SAM head MLP shapes, network.py:31-66): fp32 products, slabs summed
+    in a fixed order.  Shapes cover the vector and scalar operand loads, the 2-output layer, column groups beyond 256,
+    ragged row counts and fewer rows than one slab."""
+    from sanerf_hq_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(gpu)
+    dy = torch.randn(M, N, generator=g).to(gpu)
+    lib = _lib.lib()
+    need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=gpu)
+    dw = torch.full((N, K), float("nan"), device=gpu)
+    _lib.check(lib.sn_linear_wgrad(x.data_ptr(), dy.data_ptr(), M, K, N, dw.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "wgrad")
+    ref = (dy.double().t() @ x.double()).float()
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((dw - ref).abs().max()) <= 2e-5 * scale * max(1.0, (M / 1e4) ** 0.5)
+    dw2 = torch.empty_like(dw)
+    _lib.check(lib.sn_linear_wgrad(x.data_ptr(), dy.data_ptr(), M, K, N, dw2.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "wgrad")
+    assert torch.equal(dw, dw2), "fixed summation order: bit-reproducible"
+    # unaligned operands take the scalar-load instantiation: same values
+    xo = torch.empty(M * K + 1, device=gpu)[1:].view(M, K).copy_(x)
+    _lib.check(lib.sn_linear_wgrad(xo.data_ptr(), dy.data_ptr(), M, K, N, dw2.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "wgrad")
+    assert float((dw2 - ref).abs().max()) <= 2e-5 * scale * max(1.0, (M / 1e4) ** 0.5)
 
 
 def test_small_linear_autograd_equals_nn_linear(gpu):
@@ -418,3 +446,9 @@ def test_small_linear_autograd_equals_nn_linear(gpu):
     assert torch.equal(y1, y2)
     for a, b in zip(g1, (x.grad, lin.weight.grad, lin.bias.grad)):
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    wide = torch.nn.Linear(143, 256, bias=False).to(gpu)       # mask head, first layer (network.py:180)
+    xw = torch.randn(40000, 143, device=gpu)
+    small_linear(xw, wide).square().sum().backward()
+    gw = wide.weight.grad.clone(); wide.zero_grad()
+    wide(xw).square().sum().backward()
+    assert float((gw - wide.weight.grad).abs().max()) <= 1e-4 * float(wide.weight.grad.abs().max())
