@@ -59,14 +59,20 @@ def main():
     ap.add_argument("--tables", choices=["f32", "f16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true", help="world size 1 only: still go through RCCL (init, all-gather pipeline, barriers)")
     ap.add_argument("--primary-only", action="store_true", help="skip the extra configurations reported under `also`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    force_dist = args.force_dist and world == 1      # exercise the RCCL code path on a one-GPU box
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dist:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
+    multi = world > 1 or force_dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
@@ -97,11 +103,11 @@ def main():
         out = {}
         # N > 1: the all-gather of frame k (RCCL, its own stream, over xGMI) overlaps the render of frame k+1; two
         # rotating image buffers, everything in flight is drained inside the timed region
-        pipe = PipelinedGather(H, W, 5, dev, depth=2) if world > 1 else None
+        pipe = PipelinedGather(H, W, 5, dev, depth=2) if multi else None
 
         def step():
             rm.render_rays(plan, rays_o, rays_d, tile_w=W, out=out)
-            if world > 1:
+            if multi:
                 band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
                 pipe.submit(band)
 
@@ -110,7 +116,7 @@ def main():
         if pipe is not None:
             pipe.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         lib.sn_rm_profile_enable(1)
         torch.cuda.synchronize()
@@ -120,14 +126,14 @@ def main():
         if pipe is not None:
             pipe.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         ms = (C.c_float * 8)()
         cnt = (C.c_int32 * 8)()
         _lib.check(lib.sn_rm_profile_read(ms, cnt, 8), "profile_read")
         lib.sn_rm_profile_enable(0)
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -232,7 +238,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "also": also,
         }
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
