@@ -43,6 +43,9 @@ python $root/tools/traffic_from_pmc.py $out > $out/latest_traffic.json
 # micro-benchmarks
 [ -x $root/tools/ubench/gathers_ub ] && timeout 300 $root/tools/ubench/gathers_ub > $out/ubench_gathers.txt 2>&1
 python $root/tools/mlp_bench.py > $out/ubench_head_mlp.txt 2>&1
+python $root/tools/wgrad_bench.py 2>/dev/null | tail -1 > $out/ubench_wgrad.json
+python $root/tools/prop_sp_ab.py 2>/dev/null | tail -1 > $out/small_batch_kernels_ab.json
+SN_AB_STEPS=128 python $root/tools/prop_sp_ab.py 2>/dev/null | tail -1 > $out/small_batch_kernels_ab_flat128.json
 # un-profiled numbers
 cd $root
 python tools/bench_configs.py 2>/dev/null | tail -1 > $out/bench_configs.json

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     import re
-    for key in ("k_final_stage", "k_prop_stage", "k_feat_stage", "k_pack_grid_mlp_f16", "k_pack_grid_mlp", "k_pack_mlp_wide", "k_mlp_wide",
+    for key in ("k_final_stage_sp", "k_prop_stage_sp", "k_final_stage", "k_prop_stage", "k_feat_stage", "k_linear_wgrad_mfma", "k_linear_wgrad_sum4", "k_pack_grid_mlp_f16", "k_pack_grid_mlp", "k_pack_mlp_wide", "k_mlp_wide",
                 "k_grid_composite", "k_grid_forward", "k_grid_backward", "k_bwd_reduce", "k_bwd_keys",
                 "k_composite", "k_generate_rays", "k_sample_pdf", "k_weights"):
         if key in name:
@@ -22,6 +22,14 @@ def short(name: str) -> str:
                     tag = {"0": "<valu>", "1": "<mfma_f32>", "2": "<mfma_f16x3>"}[m.group(1)]
                 if "ELb1EEE" in name:
                     tag += "<aux>"
+            if key == "k_prop_stage_sp":
+                m = re.search(r"Li16ELi(n?\d+)E", name)
+                if m:
+                    tag = {"3": "<prop0,K=3>", "2": "<prop1,K=2>"}.get(m.group(1), "<generic>")
+            if key == "k_linear_wgrad_mfma":
+                m = re.search(r"<(\d), (true|false), (true|false)>", name) or re.search(r"ILi(\d)ELb([01])ELb([01])E", name)
+                if m:
+                    tag = f"<{m.group(1)} column blocks{', vector loads' if m.group(2) in ('true', '1') else ''}{', flat' if m.group(3) in ('true', '1') else ''}>"
             if key == "k_prop_stage":
                 m = re.search(r"Li16ELi(n?\d+)E", name)
                 if m:
