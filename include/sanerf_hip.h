@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 2
+#define SN_ABI_VERSION 3
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -132,6 +132,17 @@ int sn_rm_sample_pdf(const float *bins, const float *weights, uint32_t N, uint32
 /* nerf/renderer.py:308-325.  real_bins [N,T+1], sigmas [N,T] -> weights [N,T]. */
 int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32_t N, uint32_t T,
                              int last_sample_opaque, float *weights, sn_stream_t stream);
+/* Backward of sn_rm_weights_from_sigma w.r.t. sigmas (what autograd derives from renderer.py:308-325; the bin edges
+ * carry no gradient on this path).  grad_weights [N,T] -> grad_sigmas [N,T]; T <= 256. */
+int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigmas, const float *grad_weights, uint32_t N, uint32_t T,
+                                      int last_sample_opaque, float *grad_sigmas, sn_stream_t stream);
+
+/* One stage's sample geometry (renderer.py:277-285): bins [N,T+1] in [0,1] -> real_bins [N,T+1] (distances along the
+ * ray through the Mip-360 spacing of nears/fars [N]), rays_t [N,T] (mid-points), xyzs [N,T,3] (positions, contracted
+ * into [-2,2]^3 like sn_rm_contract if `contract`).  Nothing here is differentiated by the reference. */
+int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
+                           uint32_t N, uint32_t T, int contract, float *real_bins, float *rays_t, float *xyzs, sn_stream_t stream);
+
 /* nerf/renderer.py:333-338,361,384: out[n,k] = sum_t weights[n,t] * values[n,t,k]  (K may be 1). */
 int sn_rm_composite(const float *weights, const float *values, uint32_t N, uint32_t T, uint32_t K,
                     float *out, sn_stream_t stream);

@@ -55,7 +55,7 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 2   # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 3   # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),
@@ -76,6 +76,8 @@ _SIGNATURES = {
     "sn_rm_contract": (_int, [_vp, _u32, _vp, _vp]),
     "sn_rm_sample_pdf": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp]),
     "sn_rm_weights_from_sigma": (_int, [_vp, _vp, _u32, _u32, _int, _vp, _vp]),
+    "sn_rm_weights_from_sigma_backward": (_int, [_vp, _vp, _vp, _u32, _u32, _int, _vp, _vp]),
+    "sn_rm_sample_positions": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _vp, _vp, _vp, _vp]),
     "sn_rm_composite": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     "sn_rm_composite_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     "sn_rm_grid_composite": (_int, [_vp, _vp, _u32, _u32, _f32, C.POINTER(GridDesc), _u32, _vp, _vp]),

@@ -135,6 +135,91 @@ __global__ __launch_bounds__(256) void k_weights(const float *__restrict__ real_
     }
 }
 
+// Backward of k_weights w.r.t. sigma (the bin edges carry no gradient: sample_pdf's output is not differentiated and
+// the encoders have no input gradient).  w_j = (1 - e^{-ds_j}) T_j with T_j = e^{-sum_{i<j} ds_i}, ds_j = delta_j sigma_j:
+//   dL/dds_i = g_i e^{-ds_i} T_i - sum_{j>i} g_j w_j,   dL/dsigma_i = delta_i dL/dds_i,
+// the opaque last sample (ds = inf) is a constant (torch: cat([ds[:-1], inf])), NaN weights pass no gradient
+// (nan_to_num).  One wave per ray: lane l owns samples l, l+64, ...; the prefix of ds (fp64) and the suffix of g*w are
+// wave scans carried from one 64-sample segment to the next.
+__global__ __launch_bounds__(256) void k_weights_backward(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
+                                                          const float *__restrict__ grad_w, uint32_t N, uint32_t T, int last_opaque,
+                                                          float *__restrict__ grad_sigmas) {
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const float *rb = real_bins + (size_t)n * (T + 1);
+    const float *sg = sigmas + (size_t)n * T;
+    const float *gw = grad_w + (size_t)n * T;
+    float *gs = grad_sigmas + (size_t)n * T;
+    constexpr uint32_t MAXSEG = 4;                      // T <= 256; loops fully unrolled so the per-lane arrays stay in registers
+    const uint32_t nseg = (T + 63u) / 64u;
+    float gwv[MAXSEG];                                  // g_j * w_j of this lane's samples
+    float dterm[MAXSEG], delta[MAXSEG];
+    // ---- forward sweep: prefix of ds -> T_j, w_j ----
+    double carry = 0.0;
+#pragma unroll
+    for (uint32_t s = 0; s < MAXSEG; ++s) {
+        gwv[s] = dterm[s] = delta[s] = 0.0f;
+        if (s >= nseg) continue;
+        const uint32_t j = s * 64u + lane;
+        const bool live = j < T;
+        const float d = live ? rb[j + 1] - rb[j] : 0.0f;
+        float ds = live ? d * sg[j] : 0.0f;
+        const bool opaque = last_opaque && j == T - 1u;
+        double incl = (live && !opaque) ? (double)ds : 0.0;      // the opaque sample is last: nothing comes after it
+#pragma unroll
+        for (uint32_t k = 1; k < 64u; k <<= 1) { const double v = __shfl_up(incl, k); if (lane >= k) incl += v; }
+        const double excl = carry + incl - ((live && !opaque) ? (double)ds : 0.0);
+        carry += __shfl(incl, 63);
+        if (opaque) ds = __builtin_inff();
+        const float tr = expf_det(-(float)excl);
+        const float e = expf_det(-ds);
+        const float w = (1.0f - e) * tr;
+        const bool bad = w != w;
+        const float g = live ? gw[j] : 0.0f;
+        gwv[s] = (live && !bad) ? g * w : 0.0f;
+        dterm[s] = (live && !bad && !opaque) ? g * e * tr : 0.0f;
+        delta[s] = (live && !opaque) ? d : 0.0f;
+    }
+    // ---- backward sweep: suffix of g*w ----
+    float tail = 0.0f;                                  // sum over later segments
+#pragma unroll
+    for (int s = (int)MAXSEG - 1; s >= 0; --s) {
+        if ((uint32_t)s >= nseg) continue;
+        float incl = gwv[s];
+#pragma unroll
+        for (uint32_t k = 1; k < 64u; k <<= 1) { const float v = __shfl_down(incl, k); if (lane + k < 64u) incl += v; }
+        const float after = tail + incl - gwv[s];       // strictly later samples
+        tail += __shfl(incl, 0);
+        const uint32_t j = (uint32_t)s * 64u + lane;
+        if (j < T) gs[j] = delta[s] * (dterm[s] - after);
+    }
+}
+
+// renderer.py:277-285 for one stage, no gradient anywhere on this chain: bins -> real_bins, mid-points, positions
+// (contracted if asked).  Same arithmetic as the fused renderer's real_bin / sample position.
+__global__ __launch_bounds__(256) void k_sample_positions(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                          const float *__restrict__ nears, const float *__restrict__ fars,
+                                                          const float *__restrict__ bins, uint32_t N, uint32_t T, int contract,
+                                                          float *__restrict__ real_bins, float *__restrict__ rays_t, float *__restrict__ xyzs) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)N * (T + 1)) return;
+    const uint32_t n = (uint32_t)(t / (T + 1)), j = (uint32_t)(t - (uint64_t)n * (T + 1));
+    const float s_near = spacing_fn(nears[n]), s_far = spacing_fn(fars[n]);
+    auto rbin = [&](float b) { const float a = s_near * (1.0f - b); const float c = s_far * b; return spacing_inv(a + c); };
+    const float r0 = rbin(bins[t]);
+    real_bins[t] = r0;
+    if (j == T) return;
+    const float r1 = rbin(bins[t + 1]);
+    const float tmid = (r1 + r0) / 2.0f;
+    const size_t o = (size_t)n * T + j;
+    rays_t[o] = tmid;
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float m = rays_d[(size_t)n * 3 + k] * tmid; p[k] = rays_o[(size_t)n * 3 + k] + m; }
+    if (contract) contract3(p[0], p[1], p[2]);
+    xyzs[o * 3 + 0] = p[0]; xyzs[o * 3 + 1] = p[1]; xyzs[o * 3 + 2] = p[2];
+}
+
 // out[n,k] = sum_t w[n,t] * v[n,t,k], sequential fmaf over t (renderer.py:333-338,361,384)
 __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ weights, const float *__restrict__ values,
                                                    uint32_t N, uint32_t T, uint32_t K, float *__restrict__ out) {
@@ -214,6 +299,27 @@ int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32
     if (N == 0 || T == 0) return SN_OK;
     hipLaunchKernelGGL(k_weights, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, N, T, last_sample_opaque, weights);
     SN_LAUNCH_CHECK("k_weights");
+    return SN_OK;
+}
+
+int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigmas, const float *grad_weights, uint32_t N, uint32_t T,
+                                      int last_sample_opaque, float *grad_sigmas, sn_stream_t stream) {
+    SN_REQUIRE(real_bins && sigmas && grad_weights && grad_sigmas, "weights_from_sigma_backward: NULL pointer");
+    SN_REQUIRE(T <= 256, "weights_from_sigma_backward: at most 256 samples per ray (got %u)", T);
+    if (N == 0 || T == 0) return SN_OK;
+    hipLaunchKernelGGL(k_weights_backward, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, grad_weights, N, T,
+                       last_sample_opaque, grad_sigmas);
+    SN_LAUNCH_CHECK("k_weights_backward");
+    return SN_OK;
+}
+
+int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
+                           uint32_t N, uint32_t T, int contract, float *real_bins, float *rays_t, float *xyzs, sn_stream_t stream) {
+    SN_REQUIRE(rays_o && rays_d && nears && fars && bins && real_bins && rays_t && xyzs, "sample_positions: NULL pointer");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_sample_positions, dim3(div_up((uint64_t)N * (T + 1), 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars,
+                       bins, N, T, contract, real_bins, rays_t, xyzs);
+    SN_LAUNCH_CHECK("k_sample_positions");
     return SN_OK;
 }
 

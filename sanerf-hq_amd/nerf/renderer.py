@@ -241,13 +241,6 @@ class NeRFRenderer(nn.Module):
             nears = torch.maximum(nears, cam_near_far[:, [0]])
             fars = torch.minimum(fars, cam_near_far[:, [1]])
 
-        def spacing(x):
-            return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
-
-        def spacing_inv(x):
-            return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
-
-        s_near, s_far = spacing(nears), spacing(fars)
         all_bins, all_weights = [], []
         steps = opt.num_steps
         bins = weights = None
@@ -258,11 +251,9 @@ class NeRFRenderer(nn.Module):
                     bins = (bins + (torch.rand_like(bins) - 0.5) / T).clamp(0, 1)
             else:
                 bins = rm.sample_pdf(bins, weights, T + 1, perturb)
-            real_bins = spacing_inv(s_near * (1 - bins) + s_far * bins)
-            rays_t = (real_bins[..., 1:] + real_bins[..., :-1]) / 2
-            xyzs = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * rays_t.unsqueeze(2)
-            if opt.contract:
-                xyzs = rm.contract(xyzs)
+            # bins -> distances, mid-points, (contracted) positions: nothing on this chain is differentiated
+            # (sample_pdf's output carries no gradient, the encoders have no input gradient), so it is one kernel
+            real_bins, rays_t, xyzs = rm.sample_positions(rays_o, rays_d, nears, fars, bins, contract=opt.contract)
             if k != len(steps) - 1:
                 with torch.set_grad_enabled(update_proposal and torch.is_grad_enabled()):
                     sigmas = self.density(xyzs, proposal=k)["sigma"]
@@ -271,13 +262,8 @@ class NeRFRenderer(nn.Module):
                 dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
                 field = self(xyzs, dirs)
                 sigmas, colors, geo_feat = field["sigma"], field["color"], field["geo_feat"]
-            ds = (real_bins[..., 1:] - real_bins[..., :-1]) * sigmas
-            if opt.background == "last_sample":
-                ds = torch.cat([ds[..., :-1], torch.full_like(ds[..., -1:], torch.inf)], dim=-1)
-            alphas = 1 - torch.exp(-ds)
-            trans = torch.cumsum(ds[..., :-1], dim=-1)
-            trans = torch.exp(-torch.cat([torch.zeros_like(trans[..., :1]), trans], dim=-1))
-            weights = (alphas * trans).nan_to_num(0)
+            # renderer.py:308-325 (delta*sigma -> alpha, transmittance, weights) forward and backward in one kernel each
+            weights = rm.weights_from_sigma(real_bins, sigmas, opt.background == "last_sample")
             if self.training:
                 all_bins.append(bins)
                 all_weights.append(weights)

@@ -100,16 +100,70 @@ def sample_pdf(bins, weights, T: int, perturb: bool = False, return_inds: bool =
     return (out, inds) if return_inds else out
 
 
+class _weights_from_sigma(Function):
+    """weights [N,T] of renderer.py:308-325 from real_bins [N,T+1] and sigmas [N,T]; differentiable w.r.t. sigmas (the
+    bin edges carry no gradient on this path: sample_pdf's output is not differentiated)."""
+
+    @staticmethod
+    def forward(ctx, real_bins, sigmas, last_sample_opaque):
+        real_bins = real_bins.detach().contiguous().float()
+        sig = sigmas.detach().contiguous().float()
+        N, T = sig.shape
+        w = torch.empty(N, T, device=sig.device, dtype=torch.float32)
+        _lib.check(_lib.lib().sn_rm_weights_from_sigma(_lib.dev(real_bins, "real_bins"), _lib.dev(sig, "sigmas"), N, T,
+                                                       int(last_sample_opaque), _lib.dev(w, "weights"), _lib.stream()),
+                   "weights_from_sigma")
+        ctx.save_for_backward(real_bins, sig)
+        ctx.last = int(last_sample_opaque)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        real_bins, sig = ctx.saved_tensors
+        N, T = sig.shape
+        gw = gw.contiguous().float()
+        gs = torch.empty_like(sig)
+        _lib.check(_lib.lib().sn_rm_weights_from_sigma_backward(_lib.dev(real_bins, "real_bins"), _lib.dev(sig, "sigmas"),
+                                                                _lib.dev(gw, "grad_weights"), N, T, ctx.last,
+                                                                _lib.dev(gs, "grad_sigmas"), _lib.stream()), "weights_from_sigma_backward")
+        return None, gs, None
+
+
+WEIGHTS_BACKWARD_MAX_T = 256      # sn_rm_weights_from_sigma_backward keeps a ray's samples in one wave's registers
+
+
 def weights_from_sigma(real_bins, sigmas, last_sample_opaque: bool = True):
-    """real_bins [N,T+1], sigmas [N,T] -> weights [N,T] (forward only; training uses torch's scan)."""
-    real_bins = real_bins.detach().contiguous().float()
-    sigmas = sigmas.detach().contiguous().float()
-    N, T = sigmas.shape
-    w = torch.empty(N, T, device=sigmas.device, dtype=torch.float32)
-    _lib.check(_lib.lib().sn_rm_weights_from_sigma(_lib.dev(real_bins, "real_bins"), _lib.dev(sigmas, "sigmas"), N, T,
-                                                   int(last_sample_opaque), _lib.dev(w, "weights"), _lib.stream()),
-               "weights_from_sigma")
-    return w
+    """real_bins [N,T+1], sigmas [N,T] -> weights [N,T]; under autograd the gradient reaches `sigmas` (T <= 256)."""
+    if torch.is_grad_enabled() and sigmas.requires_grad:
+        if sigmas.shape[-1] > WEIGHTS_BACKWARD_MAX_T:
+            raise ValueError(f"weights_from_sigma: autograd supports at most {WEIGHTS_BACKWARD_MAX_T} samples per ray")
+        return _weights_from_sigma.apply(real_bins, sigmas, bool(last_sample_opaque))
+    return _weights_from_sigma.forward(_NoCtx(), real_bins, sigmas, bool(last_sample_opaque))
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
+def sample_positions(rays_o, rays_d, nears, fars, bins, contract: bool = True):
+    """One stage's geometry (renderer.py:277-285), no autograd: bins [N,T+1] -> (real_bins [N,T+1], rays_t [N,T],
+    xyzs [N,T,3]); positions are contracted into [-2,2]^3 when `contract`."""
+    rays_o, rays_d = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+    bins = bins.detach().contiguous().float()
+    N, T = bins.shape[0], bins.shape[1] - 1
+    nears = nears.detach().reshape(-1).contiguous().float()
+    fars = fars.detach().reshape(-1).contiguous().float()
+    assert nears.numel() == N and fars.numel() == N and rays_o.shape == (N, 3)
+    dev = bins.device
+    real_bins = torch.empty(N, T + 1, device=dev, dtype=torch.float32)
+    rays_t = torch.empty(N, T, device=dev, dtype=torch.float32)
+    xyzs = torch.empty(N, T, 3, device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().sn_rm_sample_positions(_lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.dev(nears, "nears"),
+                                                 _lib.dev(fars, "fars"), _lib.dev(bins, "bins"), N, T, int(contract),
+                                                 _lib.dev(real_bins, "real_bins"), _lib.dev(rays_t, "rays_t"), _lib.dev(xyzs, "xyzs"),
+                                                 _lib.stream()), "sample_positions")
+    return real_bins, rays_t, xyzs
 
 
 class _composite(Function):

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import camera_rays, product_model, synthetic_params
+
 pytestmark = pytest.mark.gpu
 
 
@@ -271,6 +273,62 @@ def test_sample_pdf_large_random(gpu, orc):
     want_b, want_i = orc.sample_pdf(b, w, T_)
     got_b, got_i = rm.sample_pdf(T(b, gpu), T(w, gpu), T_, return_inds=True)
     assert np.array_equal(got_i.cpu().numpy(), want_i) and np.array_equal(got_b.cpu().numpy(), want_b)
+
+
+@pytest.mark.parametrize("T_,opaque", [(1, True), (33, True), (64, False), (128, True), (200, False), (256, True)])
+def test_weights_from_sigma_autograd(gpu, orc, T_, opaque):
+    """The autograd form of weights_from_sigma against torch's own derivative of renderer.py:308-325 evaluated in fp64
+    (delta*sigma -> alpha, exclusive cumsum -> transmittance, product, nan_to_num)."""
+    from sanerf_hq_amd import raymarching as rm
+    rng = np.random.default_rng(7 + T_)
+    N = 777
+    rb = np.sort(rng.uniform(0.2, 30, (N, T_ + 1)), axis=1).astype(np.float32)
+    sg = np.exp(rng.uniform(-6, 3, (N, T_))).astype(np.float32)
+    go = rng.standard_normal((N, T_)).astype(np.float32)
+    s1 = T(sg, gpu).requires_grad_(True)
+    w = rm.weights_from_sigma(T(rb, gpu), s1, opaque)
+    assert np.array_equal(w.detach().cpu().numpy(), orc.weights_from_sigma(rb, sg, opaque))
+    w.backward(T(go, gpu))
+    s2 = T(sg, gpu).double().requires_grad_(True)
+    rbd = T(rb, gpu).double()
+    ds = (rbd[..., 1:] - rbd[..., :-1]) * s2
+    if opaque:
+        ds = torch.cat([ds[..., :-1], torch.full_like(ds[..., -1:], torch.inf)], dim=-1)
+    alphas = 1 - torch.exp(-ds)
+    trans = torch.cumsum(ds[..., :-1], dim=-1)
+    trans = torch.exp(-torch.cat([torch.zeros_like(ds[..., :1]), trans], dim=-1))
+    ((alphas * trans).nan_to_num(0) * T(go, gpu).double()).sum().backward()
+    ref = s2.grad.float()
+    err = float((s1.grad - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert err < 2e-5, err
+    if opaque:
+        assert float(s1.grad[:, -1].abs().max()) == 0.0, "the opaque last sample is a constant"
+
+
+def test_sample_positions_match_the_fused_renderer(gpu, orc):
+    """rm.sample_positions (the training path's geometry kernel) == what the fused renderer computes for the same bins:
+    bit-equal to its per-sample positions, and real_bins/rays_t equal to the torch expressions of renderer.py:277-282."""
+    from sanerf_hq_amd import raymarching as rm
+    steps = [48]
+    params = synthetic_params(steps, seed=12)
+    model = product_model(params, steps, False, gpu)
+    _, _, ro, rd = camera_rays(orc, 17, 29, radius=1.3, elev=-10.0, azim=77.0)
+    plan = rm.RenderPlan(model, steps)
+    out = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, want=("bins", "xyzs_last"), out={})
+    nears, fars = rm.near_far_from_aabb(T(ro, gpu), T(rd, gpu), model.aabb_infer, model.min_near)
+    real_bins, rays_t, xyzs = rm.sample_positions(T(ro, gpu), T(rd, gpu), nears, fars, out["bins0"], contract=True)
+    assert torch.equal(xyzs, out["xyzs_last"])
+
+    def g(x):
+        return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
+
+    def ginv(x):
+        return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
+    rb = ginv(g(nears) * (1 - out["bins0"]) + g(fars) * out["bins0"])
+    np.testing.assert_allclose(real_bins.cpu().numpy(), rb.cpu().numpy(), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(rays_t.cpu().numpy(), ((rb[:, 1:] + rb[:, :-1]) / 2).cpu().numpy(), rtol=2e-6, atol=0)
+    _, _, flat = rm.sample_positions(T(ro, gpu), T(rd, gpu), nears, fars, out["bins0"], contract=False)
+    assert torch.equal(rm.contract(flat), xyzs)
 
 
 def test_weights_and_composite(gpu, orc):
