@@ -571,14 +571,18 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_partial(const float *__res
         }
 }
 
-// dw[i] = sum over slabs, in a fixed order: 16 lanes per output stride over the slabs, then a shuffle tree
+// dw[i] = sum over slabs, in a fixed order: LPO lanes per output stride over the slabs, then a shuffle tree.  The small
+// layers have <= 4096 outputs and up to 1024 slabs: with 16 lanes per output each lane walked 64 dependent-latency
+// loads (20 us per layer, seven layers per RGB-mode step); 64 lanes per output walk 16.
+template <uint32_t LPO>
 __global__ __launch_bounds__(256) void k_linear_wgrad_sum(const float *__restrict__ partial, uint32_t nslab, uint32_t NK, float *__restrict__ dw) {
-    const uint32_t o = blockIdx.x * 16u + (threadIdx.x >> 4), s = threadIdx.x & 15u;
+    constexpr uint32_t OPB = 256u / LPO;                 // outputs per workgroup
+    const uint32_t o = blockIdx.x * OPB + threadIdx.x / LPO, s = threadIdx.x % LPO;
     float v = 0.0f;
     if (o < NK)
-        for (uint32_t b = s; b < nslab; b += 16u) v += partial[(size_t)b * NK + o];
+        for (uint32_t b = s; b < nslab; b += LPO) v += partial[(size_t)b * NK + o];
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+    for (int d = (int)LPO / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, LPO);
     if (o < NK && s == 0u) dw[o] = v;
 }
 
@@ -768,7 +772,7 @@ extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint
             hipLaunchKernelGGL(sn::k_linear_wgrad_sum4, dim3(sn::div_up(N * K / 4u, 16)), dim3(256), 0, st, reinterpret_cast<const float4 *>(part), nslab,
                                N * K / 4u, reinterpret_cast<float4 *>(dw));
         else
-            hipLaunchKernelGGL(sn::k_linear_wgrad_sum, dim3(sn::div_up(N * K, 16)), dim3(256), 0, st, part, nslab, N * K, dw);
+            hipLaunchKernelGGL(sn::k_linear_wgrad_sum<16>, dim3(sn::div_up(N * K, 16)), dim3(256), 0, st, part, nslab, N * K, dw);
         SN_LAUNCH_CHECK("k_linear_wgrad_sum");
         return SN_OK;
     }
@@ -776,7 +780,7 @@ extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint
     const uint32_t nslab = tiles < sn::WG_MAX_SLABS ? tiles : sn::WG_MAX_SLABS;
     hipLaunchKernelGGL(sn::k_linear_wgrad_partial, dim3(nslab), dim3(256), 0, st, x, dy, M, K, N, reinterpret_cast<float *>(workspace));
     SN_LAUNCH_CHECK("k_linear_wgrad_partial");
-    hipLaunchKernelGGL(sn::k_linear_wgrad_sum, dim3(sn::div_up(N * K, 16)), dim3(256), 0, st, reinterpret_cast<const float *>(workspace), nslab, N * K, dw);
+    hipLaunchKernelGGL(sn::k_linear_wgrad_sum<64>, dim3(sn::div_up(N * K, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(workspace), nslab, N * K, dw);
     SN_LAUNCH_CHECK("k_linear_wgrad_sum");
     return SN_OK;
 }

@@ -64,6 +64,8 @@ __device__ __forceinline__ float nan_to_num(float v) {
     return v;
 }
 
+constexpr uint32_t RM_WAVE_PER_RAY_MAX = 65536;     // rays up to which sample_pdf / weights_from_sigma run one wave per ray
+
 // nerf/renderer.py:84-119.  cdf and u are both non-decreasing, so searchsorted(right=True)
 // is one merge pass; the cdf is a running fp64 sum rounded to fp32 per prefix (= torch.cumsum
 // on CPU) and the normaliser is the fp64-accumulated sum.
@@ -132,6 +134,91 @@ __global__ __launch_bounds__(256) void k_weights(const float *__restrict__ real_
         if (w != w) w = 0.0f;
         weights[(size_t)n * T + j] = w;
         cum += (double)ds;
+    }
+}
+
+// The same two operators with one WAVE per ray, for the few thousand rays of a training step (one lane per ray is 16
+// workgroups of serial T-step loops: 60-130 us per call).  Loads, exponentials, divisions and the output search are
+// spread over the lanes; the fp64 running sums keep the sequential order of the kernels above (every lane adds the
+// same values in the same order), so the results are bit-identical.
+__global__ __launch_bounds__(256) void k_weights_wave(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
+                                                      uint32_t N, uint32_t T, int last_opaque, float *__restrict__ weights) {
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (n >= N) return;
+    const float *rb = real_bins + (size_t)n * (T + 1);
+    const float *sg = sigmas + (size_t)n * T;
+    double cum = 0.0;
+    for (uint32_t j0 = 0; j0 < T; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        const bool live = j < T;
+        float ds = live ? (rb[j + 1] - rb[j]) * sg[j] : 0.0f;
+        if (live && last_opaque && j == T - 1u) ds = __builtin_inff();
+        const float add = (live && ds != __builtin_inff()) ? ds : 0.0f;      // +inf is the last sample: nothing follows it
+        double excl = 0.0;
+#pragma unroll
+        for (uint32_t q = 0; q < 64u; ++q) {
+            const float d = __shfl(add, q);
+            if (lane == q) excl = cum;
+            cum += (double)d;
+        }
+        if (live) {
+            const float alpha = 1.0f - expf_det(-ds);
+            const float tr = expf_det(-(float)excl);
+            float w = alpha * tr;
+            if (w != w) w = 0.0f;
+            weights[(size_t)n * T + j] = w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_pdf_wave(const float *__restrict__ bins, const float *__restrict__ weights,
+                                                         uint32_t N, uint32_t T0, uint32_t T, const float *__restrict__ u,
+                                                         uint32_t u_stride, float *__restrict__ out_bins, int32_t *__restrict__ inds) {
+    extern __shared__ float pdf_lds[];                   // per wave: cdf[T0+1] | bins[T0+1]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_raw = blockIdx.x * 4u + wave;
+    const uint32_t n = n_raw < N ? n_raw : N - 1u;       // spare waves redo the last ray (no early exit: plain loops below)
+    float *cdf = pdf_lds + (size_t)wave * 2u * (T0 + 1u), *bl = cdf + (T0 + 1u);
+    const float *w = weights + (size_t)n * T0;
+    const float *b = bins + (size_t)n * (T0 + 1);
+    for (uint32_t i = lane; i < T0; i += 64u) cdf[i + 1u] = w[i] + 0.01f;
+    for (uint32_t i = lane; i <= T0; i += 64u) bl[i] = b[i];
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0;
+    for (uint32_t i = 0; i < T0; ++i) acc += (double)cdf[i + 1u];                 // every lane, same order
+    const float wsum = (float)acc;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < T0; i += 64u) cdf[i + 1u] = cdf[i + 1u] / wsum;    // pdf
+    __builtin_amdgcn_wave_barrier();
+    acc = 0.0;
+    for (uint32_t i = 0; i < T0; ++i) {                                           // running fp64 sum, rounded per prefix
+        acc += (double)cdf[i + 1u];
+        const float c = (float)acc;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0u) cdf[i + 1u] = c > 1.0f ? 1.0f : c;
+    }
+    if (lane == 0u) cdf[0] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    if (n_raw >= N) return;
+    const float ustart = (float)(0.5 / T), uend = (float)(1 - 0.5 / T);
+    const float ustep = T > 1 ? (uend - ustart) / (float)(T - 1) : 0.0f;
+    for (uint32_t j = lane; j < T; j += 64u) {
+        const float uj = u ? u[(size_t)n * u_stride + j] : linspace_at(ustart, uend, ustep, T, j);
+        uint32_t lo = 0u, hi = T0 + 1u;                                           // searchsorted(cdf, u, right=True)
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uj) lo = mid + 1u; else hi = mid;
+        }
+        const uint32_t i = lo;
+        float c0, c1, b0, b1;
+        if (i == 0u) { c0 = c1 = cdf[0]; b0 = b1 = bl[0]; }
+        else if (i > T0) { c0 = c1 = cdf[T0]; b0 = b1 = bl[T0]; }
+        else { c0 = cdf[i - 1u]; c1 = cdf[i]; b0 = bl[i - 1u]; b1 = bl[i]; }
+        float t = nan_to_num((uj - c0) / (c1 - c0));
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        const float m = t * (b1 - b0);
+        out_bins[(size_t)n * T + j] = b0 + m;
+        if (inds) inds[(size_t)n * T + j] = (int32_t)i;
     }
 }
 
@@ -288,7 +375,11 @@ int sn_rm_sample_pdf(const float *bins, const float *weights, uint32_t N, uint32
     SN_REQUIRE(T0 >= 1 && T >= 1, "sample_pdf: T0=%u T=%u must be >= 1", T0, T);
     SN_REQUIRE(u_stride == 0 || u_stride == T, "sample_pdf: u_stride must be 0 (shared table) or T (per-ray rows)");
     if (N == 0) return SN_OK;
-    hipLaunchKernelGGL(k_sample_pdf, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, bins, weights, N, T0, T, u, u_stride, out_bins, inds);
+    const size_t wave_lds = (size_t)4 * 2 * (T0 + 1) * sizeof(float);
+    if (N <= RM_WAVE_PER_RAY_MAX && wave_lds <= 64 * 1024)       // few rays: one wave per ray (bit-identical)
+        hipLaunchKernelGGL(k_sample_pdf_wave, dim3(div_up(N, 4)), dim3(256), wave_lds, (hipStream_t)stream, bins, weights, N, T0, T, u, u_stride, out_bins, inds);
+    else
+        hipLaunchKernelGGL(k_sample_pdf, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, bins, weights, N, T0, T, u, u_stride, out_bins, inds);
     SN_LAUNCH_CHECK("k_sample_pdf");
     return SN_OK;
 }
@@ -297,7 +388,10 @@ int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32
                              int last_sample_opaque, float *weights, sn_stream_t stream) {
     SN_REQUIRE(real_bins && sigmas && weights, "weights_from_sigma: NULL pointer");
     if (N == 0 || T == 0) return SN_OK;
-    hipLaunchKernelGGL(k_weights, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, N, T, last_sample_opaque, weights);
+    if (N <= RM_WAVE_PER_RAY_MAX)
+        hipLaunchKernelGGL(k_weights_wave, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, N, T, last_sample_opaque, weights);
+    else
+        hipLaunchKernelGGL(k_weights, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, N, T, last_sample_opaque, weights);
     SN_LAUNCH_CHECK("k_weights");
     return SN_OK;
 }

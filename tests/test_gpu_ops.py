@@ -331,6 +331,28 @@ def test_sample_positions_match_the_fused_renderer(gpu, orc):
     assert torch.equal(rm.contract(flat), xyzs)
 
 
+def test_wave_per_ray_and_lane_per_ray_operators_agree(gpu, orc):
+    """sample_pdf / weights_from_sigma switch to one wave per ray up to 65 536 rays: same bits as the one-lane kernels
+    (the fp64 running sums keep their order), including perturbed per-ray u rows and step counts that are not
+    multiples of 64."""
+    from sanerf_hq_amd import raymarching as rm
+    rng = np.random.default_rng(11)
+    big, small = 66000, 1500                                   # lane-per-ray kernel, wave-per-ray kernel
+    for T0, T_ in ((128, 65), (37, 90), (64, 33)):
+        w = (rng.uniform(0, 1, (big, T0)) ** 5).astype(np.float32)
+        b = np.sort(rng.uniform(0, 1, (big, T0 + 1)), axis=1).astype(np.float32)
+        u = np.sort(rng.uniform(0, 1, (big, T_)), axis=1).astype(np.float32)
+        for uu in (None, u):
+            gb, gi = rm.sample_pdf(T(b, gpu), T(w, gpu), T_, return_inds=True, u=None if uu is None else T(uu, gpu))
+            sb, si = rm.sample_pdf(T(b[:small], gpu), T(w[:small], gpu), T_, return_inds=True, u=None if uu is None else T(uu[:small], gpu))
+            assert torch.equal(gb[:small], sb) and torch.equal(gi[:small], si)
+        rb = np.sort(rng.uniform(0.2, 40, (big, T0 + 1)), axis=1).astype(np.float32)
+        sg = np.exp(rng.uniform(-6, 4, (big, T0))).astype(np.float32)
+        for opaque in (True, False):
+            assert torch.equal(rm.weights_from_sigma(T(rb, gpu), T(sg, gpu), opaque)[:small],
+                               rm.weights_from_sigma(T(rb[:small], gpu), T(sg[:small], gpu), opaque))
+
+
 def test_weights_and_composite(gpu, orc):
     from sanerf_hq_amd import raymarching as rm
     rng = np.random.default_rng(70)
