@@ -145,6 +145,9 @@ struct Corner { float v[C]; };
 #ifndef SN_PAIR_ALIGNED
 #define SN_PAIR_ALIGNED 1    // A/B switch: aligned x-pair rows for the dense levels of the final stage (PairTab)
 #endif
+#ifndef SN_BLEND_PKW
+#define SN_BLEND_PKW 1       // packed corner-weight products in the final stage's blends, fp32 tables (same-box: 7.25 -> 7.19 ms; fp16 tables 6.75 -> 6.90, so not there)
+#endif
 #ifndef SN_XSWAP_DENSE
 #define SN_XSWAP_DENSE 0
 #endif
@@ -245,10 +248,26 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
     }
 }
 
-template <typename T, int C>
+// PKW: the 8 corner weights as 6 packed multiplies (x-pairs: (wx0, wx1) * wy, then * wz) instead of 12 scalar ones;
+// every weight is still (wx * wy) * wz, every channel still one corner-ascending fma chain.  Final stage only (the
+// proposal kernels have no registers to spare for the even-aligned pairs).
+template <typename T, int C, bool PKW = false>
 __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<T, C> (&cv)[8], float (&acc)[C]) {
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    if constexpr (PKW && C == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 wx = {1.0f - pos[0], pos[0]};
+        const float wy0 = 1.0f - pos[1], wz0 = 1.0f - pos[2];
+        const f2 xy0 = wx * f2{wy0, wy0}, xy1 = wx * f2{pos[1], pos[1]};
+        const f2 w01 = xy0 * f2{wz0, wz0}, w23 = xy1 * f2{wz0, wz0}, w45 = xy0 * f2{pos[2], pos[2]}, w67 = xy1 * f2{pos[2], pos[2]};
+        const float w[8] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y, w67.x, w67.y};
+        f2 a = {0.0f, 0.0f};
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) a = __builtin_elementwise_fma(f2{w[idx], w[idx]}, f2{cv[idx].v[0], cv[idx].v[1]}, a);
+        acc[0] = a.x; acc[1] = a.y;
+        return;
+    }
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; ++idx) {   // corner order and weight products exactly as gridencoder.cu:171-192
         float w = 1.0f;
@@ -260,7 +279,7 @@ __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<
 }
 
 // blend of a level whose gathers were issued with XSWAP: first give every lane its own corner values back
-template <typename T, int C>
+template <typename T, int C, bool PKW = false>
 __device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corner<T, C> (&cv)[8], float (&acc)[C]) {
     Corner<T, C> own[8];
     if constexpr (C == 2 && sizeof(T) == 2) {
@@ -272,7 +291,7 @@ __device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corne
             own[2 * p].v[0] = __low2float(ha); own[2 * p].v[1] = __high2float(ha);
             own[2 * p + 1].v[0] = __low2float(hb); own[2 * p + 1].v[1] = __high2float(hb);
         }
-        blend_level<T, C>(pos, own, acc);
+        blend_level<T, C, PKW>(pos, own, acc);
         return;
     }
 #pragma unroll
@@ -284,7 +303,7 @@ __device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corne
             own[2 * p].v[c] = __uint_as_float(a); own[2 * p + 1].v[c] = __uint_as_float(b);
         }
     }
-    blend_level<T, C>(pos, own, acc);
+    blend_level<T, C, PKW>(pos, own, acc);
 }
 
 // Encodes all L levels; `emit(l, acc)` receives each level's C features (zeros when out of range).
@@ -351,8 +370,8 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
         float acc[C];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, C>(r.pos[k], r.cv[k], acc);
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, C, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
         emit(l, acc);
     });
 }
