@@ -66,9 +66,13 @@ struct PackArgs {
 
 __device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo) {
     const half2_t h = {(_Float16)a, (_Float16)b};
-    // x - hi is exact in fp32 (hi is x rounded to 11 bits), so the single-rounding fma equals the subtraction
-    const half2_t l = {(_Float16)__builtin_fmaf((float)h[0], -1.0f, a), (_Float16)__builtin_fmaf((float)h[1], -1.0f, b)};
     hi = __builtin_bit_cast(uint32_t, h);
+    // x - hi (exact in fp32) straight from the packed halves: v_fma_mix_f32 widens its f16 operand for free
+    // (render.hip:split2 -- two v_cvt_f32_f16 + a packed subtract otherwise)
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(b));
+    const half2_t l = {(_Float16)l0, (_Float16)l1};
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     if constexpr (XMODE == 2) {
         // 16-byte pieces, 1 KiB per wave instruction, round-robin over the 4 waves.  Addresses are clamped to the last
         // whole 16 bytes of the array: rows past N receive (finite or not) garbage that only reaches their own,
-        // never stored, outputs.  Asynchronous: the first chunk's wait + barrier below also covers these.
+        // never stored, outputs.  Asynchronous; waited for (in issue order) just before the barrier that publishes lds_x.
         const uint32_t tile_bytes = (uint32_t)WIDE_ROWS * a.din * 4u;
         const uint64_t arr_bytes = (uint64_t)a.N * a.din * 4u;
         const uint64_t tile0 = (uint64_t)blockIdx.x * tile_bytes;
@@ -206,6 +210,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) dma16(src + i * 256, lds_w_off + c * CHUNK_BYTES + (uint32_t)i * 4096u);
         }
+    }
+    if constexpr (XMODE == 2) {
+        // The input tile's DMA pieces were issued before the weight pieces and the counter retires in order: allow
+        // only the weight pieces to be outstanding.  (Without this wait the first k-step's x_operand could read rows
+        // whose pieces -- issued by another wave -- had not landed: seen as 2 wrong rows, the tile's last, in one of
+        // a few 160 000-row runs.)
+        if (total_chunks >= (uint32_t)WIDE_NBUF - 1u) asm volatile("s_waitcnt vmcnt(12)" : : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        static_assert(PIECES * (WIDE_NBUF - 1) == 12, "vmcnt immediate = weight pieces in flight");
     }
     __syncthreads();                       // publishes lds_bias / lds_x
 

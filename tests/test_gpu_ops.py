@@ -464,6 +464,24 @@ def test_wide_mlp_rejects_unsupported_shapes(gpu):
         np.testing.assert_allclose(rm.mlp_forward(x, m).cpu().numpy(), m(x).cpu().numpy(), rtol=0, atol=2e-5)
 
 
+def test_wide_mlp_large_batch_is_race_free(gpu):
+    """C3-sized batch (160 000 rows = 1250 tiles) of the SAM head MLP, repeated: the input tile reaches LDS by an
+    asynchronous DMA that the first k-step must wait for (a missing wait once showed up as two wrong rows -- a tile's
+    last -- in roughly one run out of five).  Every repetition must be bit-equal and close to the torch module."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(0)
+    mlp = SkipConnMLP(163, 256, 256, 5, skip_layers=[2], bias=True).to(gpu)
+    ln = torch.nn.LayerNorm(256).to(gpu)
+    x = torch.randn(160000, 163, device=gpu)
+    with torch.no_grad():
+        ref = ln(mlp(x))
+    first = rm.mlp_forward(x, mlp, ln)
+    assert float((first - ref).abs().max()) < 5e-5
+    for _ in range(25):
+        assert torch.equal(rm.mlp_forward(x, mlp, ln), first)
+
+
 @pytest.mark.parametrize("M,K,N", [(131072, 32, 64), (5000, 10, 16), (70001, 16, 1), (4096, 31, 32), (1, 64, 64)])
 def test_linear_wgrad_matches_matmul(gpu, M, K, N):
     """sn_linear_wgrad: dw = dy^T x for the <= 64-wide layers of the radiance / proposal MLPs."""
