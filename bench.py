@@ -92,8 +92,11 @@ def main():
     total_rays = H * W
     models = {}
 
-    def measure(schedule, tables, n_steps, n_warm):
-        """K timed whole-image renders (+ all-gather at N>1) of one configuration; returns the bench numbers."""
+    def measure(schedule, tables, n_steps, n_warm, rays=None):
+        """K timed whole-image renders (+ all-gather at N>1) of one configuration; returns the bench numbers.
+        rays = (rays_o, rays_d, width): another image than the bench line's (N = 1 only)."""
+        r_o, r_d, r_w = rays if rays is not None else (rays_o, rays_d, W)
+        n_total = r_o.shape[0] if rays is not None else total_rays
         steps = [128] if schedule == "flat128" else [128, 64, 32]
         if schedule not in models:
             params = synthetic_params(steps, seed=0)
@@ -106,7 +109,7 @@ def main():
         pipe = PipelinedGather(H, W, 5, dev, depth=2) if multi else None
 
         def step():
-            rm.render_rays(plan, rays_o, rays_d, tile_w=W, out=out)
+            rm.render_rays(plan, r_o, r_d, tile_w=r_w, out=out)
             if multi:
                 band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
                 pipe.submit(band)
@@ -139,7 +142,7 @@ def main():
             elapsed = float(t.item())
         s_bytes = 2 if tables == "f16" else 4
         per = lambda i: (ms[i] / cnt[i]) if cnt[i] else None
-        return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=total_rays / (elapsed / n_steps),
+        return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=n_total / (elapsed / n_steps),
                     ms_per_step=elapsed / n_steps * 1e3, s_bytes=s_bytes, final_ms=per(4), final_launches=int(cnt[4]),
                     pack_ms=per(0), prop_ms=[per(1), per(2)])
 
@@ -173,7 +176,8 @@ def main():
             "wave_instructions_per_launch": int(-(-n_local // 64) * steps[-1] * (5 * 4 + 11 * 8)),
             "cycles_per_instruction_per_cu": 17.5,
             "floor_ms": round(-(-n_local // 64) * steps[-1] * (5 * 4 + 11 * 8) * 17.5 / 256 / 2.4e9 * 1e3, 3),
-            "note": "one wave-wide gather per 17.5 cycles per CU (4 lanes/clk address rate, measured); 5 dense levels x 4 paired loads + 11 hashed levels x 8"},
+            "note": "one wave-wide gather per 17.5 cycles per CU (4 lanes/clk address rate, measured); 5 dense levels x 4 paired loads + 11 hashed levels x 8; "
+                    "priced at the 2.4 GHz peak clock -- under this kernel the shader clock is ~1.97 GHz (GRBM_GUI_ACTIVE, profiles/r01/pmc_flat128.txt), i.e. floor x 1.22"},
         "other_kernels_ms": {"pack": round(m["pack_ms"], 4) if m["pack_ms"] else None,
                              "prop0": round(m["prop_ms"][0], 4) if m["prop_ms"][0] else None,
                              "prop1": round(m["prop_ms"][1], 4) if m["prop_ms"][1] else None},
@@ -196,6 +200,15 @@ def main():
                                    "kernel_ms": {"final": round(r["final_ms"], 4),
                                                  "prop0": round(r["prop_ms"][0], 4) if r["prop_ms"][0] else None,
                                                  "prop1": round(r["prop_ms"][1], 4) if r["prop_ms"][1] else None}}
+        # BASELINE configs C4 at one GPU: 1600 x 1600 rays of the same view (same field of view: rays twice as dense, so
+        # neighbouring lanes share more table lines -- higher rays/s than the 800 x 800 bench line)
+        H4 = 1600
+        ro4, rd4 = rm.generate_rays(pose, synth.pinhole_intrinsics(H4, H4), H4, H4, device=dev)
+        for sch in ("flat128", "ref"):
+            r = measure(sch, "f32", 3, 1, rays=(ro4, rd4, H4))
+            also[f"c4_1600x1600_{sch}_f32"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
+                                               "num_steps": r["steps"], "tables": "f32", "rays": H4 * H4}
+        del ro4, rd4
         out = m["out"]
 
     cpu_baseline = None
