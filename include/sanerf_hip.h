@@ -137,6 +137,14 @@ int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32
 int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigmas, const float *grad_weights, uint32_t N, uint32_t T,
                                       int last_sample_opaque, float *grad_sigmas, sn_stream_t stream);
 
+/* Inter-level proposal loss of one proposal stage (nerf/renderer.py:30-57): bins [N,T+1], weights [N,T] of the proposal
+ * stage against ref_bins [N,Tr+1], ref_weights [N,Tr] of the final stage (detached in the reference).
+ * Forward (loss_per_ray != NULL, grad_weights NULL): loss_per_ray[n] = sum_j max(rw_j - bound_j, 0)^2 / (rw_j + 1e-8);
+ * the reference's value is sum(loss_per_ray) / (N * Tr).  Backward (grad_weights != NULL, loss_per_ray NULL):
+ * grad_weights[n,i] = d(sum_j term_j)/d w_i (scale by upstream / (N * Tr)).  Deterministic (no atomics). */
+int sn_rm_proposal_loss(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                        uint32_t Tr, float *loss_per_ray, float *grad_weights, sn_stream_t stream);
+
 /* One stage's sample geometry (renderer.py:277-285): bins [N,T+1] in [0,1] -> real_bins [N,T+1] (distances along the
  * ray through the Mip-360 spacing of nears/fars [N]), rays_t [N,T] (mid-points), xyzs [N,T,3] (positions, contracted
  * into [-2,2]^3 like sn_rm_contract if `contract`).  Nothing here is differentiated by the reference. */

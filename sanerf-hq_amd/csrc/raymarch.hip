@@ -307,6 +307,88 @@ __global__ __launch_bounds__(256) void k_sample_positions(const float *__restric
     xyzs[o * 3 + 0] = p[0]; xyzs[o * 3 + 1] = p[1]; xyzs[o * 3 + 2] = p[2];
 }
 
+// Inter-level proposal loss of one proposal stage against the final stage (nerf/renderer.py:30-57), one wave per ray:
+//   cum = [0, cumsum(w)];  lo_j = clamp(searchsorted(b[:-1], rb_j, right) - 1, 0, T-1);  hi_j = clamp(searchsorted(b[1:], rb_{j+1}, right), 0, T-1)
+//   bound_j = cum[hi_j + 1] - cum[lo_j];   term_j = max(rw_j - bound_j, 0)^2 / (rw_j + 1e-8)
+// forward: loss_ray[n] = sum_j term_j (the caller divides the grand total by N*Tr = torch's .mean());
+// backward: bound_j = sum of w_i over lo_j <= i <= hi_j and lo, hi are non-decreasing in j (rb is sorted), so the js that
+// contain a given i form one contiguous range [ja, jb]:  dL/dw_i = G[jb+1] - G[ja] with G the prefix sum of
+// g_j = -2 max(rw_j - bound_j, 0) / (rw_j + 1e-8)  -- two binary searches per i, no atomics (deterministic).
+// The reference's own proposal bins/weights of the final stage (rb, rw) are detached there too.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__ bins, const float *__restrict__ weights,
+                                                       const float *__restrict__ ref_bins, const float *__restrict__ ref_w,
+                                                       uint32_t N, uint32_t T, uint32_t Tr, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(8))) double pl_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_raw = blockIdx.x * 4u + wave;
+    const uint32_t n = n_raw < N ? n_raw : N - 1u;           // spare waves redo the last ray and store nothing
+    // per wave: cum[T+1] (fp64: bound = cum[hi+1] - cum[lo] cancels), G[Tr+1] (fp64, backward), then the fp32 / int arrays
+    const uint32_t nd = (T + 1u) + (BACKWARD ? Tr + 1u : 0u);
+    const uint32_t nf = (T + 1u) + (BACKWARD ? 3u * Tr : 0u);
+    const uint32_t per_wave_d = nd + (nf + 1u) / 2u;         // in doubles
+    double *cum = pl_lds + (size_t)wave * per_wave_d, *G = cum + (T + 1u);
+    float *b = reinterpret_cast<float *>(cum + nd);
+    float *g = b + (T + 1u);
+    int32_t *lo_s = reinterpret_cast<int32_t *>(g + Tr), *hi_s = lo_s + Tr;
+    const float *w = weights + (size_t)n * T;
+    const float *rb = ref_bins + (size_t)n * (Tr + 1);
+    const float *rw = ref_w + (size_t)n * Tr;
+    for (uint32_t i = lane; i <= T; i += 64u) b[i] = bins[(size_t)n * (T + 1) + i];
+    for (uint32_t i = lane; i < T; i += 64u) cum[i + 1u] = (double)w[i];
+    __builtin_amdgcn_wave_barrier();
+    {
+        double acc = 0.0;
+        for (uint32_t i = 0; i < T; ++i) {                   // every lane, same order; lane 0 writes the prefixes back
+            acc += cum[i + 1u];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0u) cum[i + 1u] = acc;
+        }
+        if (lane == 0u) cum[0] = 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto upper = [&](const float *a, uint32_t len, float v) {   // number of a[0..len) <= v
+        uint32_t lo = 0u, hi = len;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1u; else hi = mid; }
+        return lo;
+    };
+    float part = 0.0f;
+    for (uint32_t j = lane; j < Tr; j += 64u) {
+        int32_t lo = (int32_t)upper(b, T, rb[j]) - 1;
+        lo = lo < 0 ? 0 : (lo > (int32_t)T - 1 ? (int32_t)T - 1 : lo);
+        int32_t hi = (int32_t)upper(b + 1, T, rb[j + 1u]);
+        hi = hi > (int32_t)T - 1 ? (int32_t)T - 1 : hi;
+        const float r = rw[j];
+        const float diff = (float)((double)r - (cum[hi + 1] - cum[lo]));
+        const float d = diff > 0.0f ? diff : 0.0f;
+        const float den = r + 1e-8f;
+        if constexpr (BACKWARD) { g[j] = -2.0f * d / den; lo_s[j] = lo; hi_s[j] = hi; }
+        else part += d * d / den;
+    }
+    if constexpr (!BACKWARD) {
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) part += __shfl_xor(part, k);
+        if (lane == 0u && n_raw < N) out[n] = part;
+    } else {
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        for (uint32_t j = 0; j < Tr; ++j) {
+            if (lane == 0u) G[j] = acc;
+            acc += (double)g[j];
+        }
+        if (lane == 0u) G[Tr] = acc;
+        __builtin_amdgcn_wave_barrier();
+        if (n_raw >= N) return;
+        for (uint32_t i = lane; i < T; i += 64u) {
+            uint32_t a0 = 0u, a1 = Tr;                       // ja = first j with hi_j >= i
+            while (a0 < a1) { const uint32_t mid = (a0 + a1) >> 1; if (hi_s[mid] >= (int32_t)i) a1 = mid; else a0 = mid + 1u; }
+            uint32_t c0 = 0u, c1 = Tr;                       // jb + 1 = number of j with lo_j <= i
+            while (c0 < c1) { const uint32_t mid = (c0 + c1) >> 1; if (lo_s[mid] <= (int32_t)i) c0 = mid + 1u; else c1 = mid; }
+            out[(size_t)n * T + i] = c0 > a0 ? (float)(G[c0] - G[a0]) : 0.0f;
+        }
+    }
+}
+
 // out[n,k] = sum_t w[n,t] * v[n,t,k], sequential fmaf over t (renderer.py:333-338,361,384)
 __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ weights, const float *__restrict__ values,
                                                    uint32_t N, uint32_t T, uint32_t K, float *__restrict__ out) {
@@ -414,6 +496,28 @@ int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float
     hipLaunchKernelGGL(k_sample_positions, dim3(div_up((uint64_t)N * (T + 1), 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars,
                        bins, N, T, contract, real_bins, rays_t, xyzs);
     SN_LAUNCH_CHECK("k_sample_positions");
+    return SN_OK;
+}
+
+int sn_rm_proposal_loss(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                        uint32_t Tr, float *loss_per_ray, float *grad_weights, sn_stream_t stream) {
+    SN_REQUIRE(bins && weights && ref_bins && ref_weights, "proposal_loss: NULL pointer");
+    SN_REQUIRE((loss_per_ray != nullptr) != (grad_weights != nullptr), "proposal_loss: pass exactly one of loss_per_ray (forward) / grad_weights (backward)");
+    SN_REQUIRE(T >= 1 && Tr >= 1 && T <= 512 && Tr <= 512, "proposal_loss: 1..512 samples per ray (got %u, %u)", T, Tr);
+    if (N == 0) return SN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    auto lds_bytes = [&](bool backward) {        // mirrors the carve-up in k_proposal_loss
+        const size_t nd = (T + 1) + (backward ? Tr + 1 : 0), nf = (T + 1) + (backward ? 3 * (size_t)Tr : 0);
+        return (size_t)4 * (nd + (nf + 1) / 2) * sizeof(double);
+    };
+    if (loss_per_ray) {
+        const size_t lds = lds_bytes(false);
+        hipLaunchKernelGGL(k_proposal_loss<false>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, loss_per_ray);
+    } else {
+        const size_t lds = lds_bytes(true);
+        hipLaunchKernelGGL(k_proposal_loss<true>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, grad_weights);
+    }
+    SN_LAUNCH_CHECK("k_proposal_loss");
     return SN_OK;
 }
 

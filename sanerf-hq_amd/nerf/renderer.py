@@ -41,6 +41,9 @@ def proposal_loss(all_bins, all_weights):
     ref_w = all_weights[-1].detach()
     total = 0
     for bins, w in zip(all_bins[:-1], all_weights[:-1]):
+        if w.is_cuda and max(w.shape[-1], ref_w.shape[-1]) <= rm.PROPOSAL_LOSS_MAX_T and w.dim() == 2:
+            total = total + rm.proposal_loss_stage(bins, w, ref_bins, ref_w)      # one kernel forward, one backward
+            continue
         cum = torch.cat([torch.zeros_like(w[..., :1]), torch.cumsum(w, dim=-1)], dim=-1)
         last = w.shape[-1] - 1
         lo = (torch.searchsorted(bins[..., :-1].contiguous(), ref_bins[..., :-1].contiguous(), right=True) - 1).clamp(0, last)

@@ -166,6 +166,44 @@ def sample_positions(rays_o, rays_d, nears, fars, bins, contract: bool = True):
     return real_bins, rays_t, xyzs
 
 
+class _proposal_loss_stage(Function):
+    """One proposal stage's term of the inter-level loss (nerf/renderer.py:30-57): mean over rays and final-stage
+    intervals of max(w_ref - bound, 0)^2 / (w_ref + 1e-8); differentiable w.r.t. the proposal weights only (bins come
+    from sample_pdf, the final stage's bins and weights are detached in the reference)."""
+
+    @staticmethod
+    def forward(ctx, bins, weights, ref_bins, ref_weights):
+        bins, ref_bins = bins.detach().contiguous().float(), ref_bins.detach().contiguous().float()
+        w, ref_w = weights.detach().contiguous().float(), ref_weights.detach().contiguous().float()
+        N, T = w.shape
+        Tr = ref_w.shape[1]
+        per_ray = torch.empty(N, device=w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().sn_rm_proposal_loss(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), _lib.dev(ref_bins, "ref_bins"),
+                                                  _lib.dev(ref_w, "ref_weights"), N, T, Tr, _lib.dev(per_ray, "loss_per_ray"), None,
+                                                  _lib.stream()), "proposal_loss")
+        ctx.save_for_backward(bins, w, ref_bins, ref_w)
+        return per_ray.sum() / float(N * Tr)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        bins, w, ref_bins, ref_w = ctx.saved_tensors
+        N, T = w.shape
+        Tr = ref_w.shape[1]
+        gw = torch.empty_like(w)
+        _lib.check(_lib.lib().sn_rm_proposal_loss(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), _lib.dev(ref_bins, "ref_bins"),
+                                                  _lib.dev(ref_w, "ref_weights"), N, T, Tr, None, _lib.dev(gw, "grad_weights"),
+                                                  _lib.stream()), "proposal_loss_backward")
+        return None, gw * (grad_out / float(N * Tr)), None, None      # no host sync: the scale stays a device scalar
+
+
+PROPOSAL_LOSS_MAX_T = 512
+
+
+def proposal_loss_stage(bins, weights, ref_bins, ref_weights):
+    """bins [N,T+1], weights [N,T] of a proposal stage; ref_* of the final stage -> scalar (renderer.py:37-56, one stage)."""
+    return _proposal_loss_stage.apply(bins, weights, ref_bins, ref_weights)
+
+
 class _composite(Function):
     """out[n,k] = sum_t w[n,t] * v[n,t,k]."""
 
