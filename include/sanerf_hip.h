@@ -64,6 +64,11 @@ int sn_grid_encode_forward(const float *inputs, const void *embeddings, int tabl
                            float S, uint32_t H, float *dy_dx,
                            uint32_t gridtype, int align_corners, uint32_t interp,
                            int layout, sn_stream_t stream);
+/* outputs [B, L*C + E] = cat([grid_encode(inputs) in the [B, L*C] layout, extra [B, E]], -1): the mask head's MLP input
+ * (nerf/renderer.py:380) in one pass.  D = 3, C in {2, 4, 8}, forward only (inference). */
+int sn_grid_encode_forward_cat(const float *inputs, const void *embeddings, int table_dtype, const int32_t *offsets_host,
+                               const float *extra, uint32_t E, float *outputs, uint32_t B, uint32_t C, uint32_t L,
+                               float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, sn_stream_t stream);
 /* grad f32 in `layout`; grad_embeddings [rows,C] f32, zero-initialised by the caller
  * (grid.py:83); grad_inputs [B,D] f32 written when dy_dx != NULL. */
 int sn_grid_encode_backward(const float *grad, const float *inputs, const void *embeddings, int table_dtype,

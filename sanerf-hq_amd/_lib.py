@@ -62,6 +62,7 @@ _SIGNATURES = {
     "sn_last_error": (C.c_char_p, []),
     "sn_device_count": (_int, []),
     "sn_grid_encode_forward": (_int, [_vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _int, _u32, _int, _vp]),
+    "sn_grid_encode_forward_cat": (_int, [_vp, _vp, _int, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _vp]),
     "sn_grid_encode_backward": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _int, _u32, _int, _vp]),
     "sn_grid_backward_sorted_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32, _u32]),
     "sn_grid_encode_backward_sorted": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp, C.c_size_t, _vp]),

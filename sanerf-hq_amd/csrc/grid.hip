@@ -316,6 +316,88 @@ __global__ __launch_bounds__(256) void k_grid_wd(const float *__restrict__ table
         }                                                                                       \
     } while (0)
 
+
+// Forward for the [B, L*C] layout (what the MLPs consume), D = 3, no dy_dx: in k_grid_forward a lane writes its C floats
+// at a stride of L*C floats -- 8 or 32 bytes of every 128/512 -- so each store instruction of a wave touches 64 partial
+// lines (3.6 ms for the 5.12 M samples of a 400x400 mask render, 2.6 GB of output).  Here a workgroup owns 64
+// consecutive samples and ALL levels: wave w evaluates levels w, w+4, ... (still one level per wave instruction, so the
+// lanes of a gather stay in one level's table), rows are parked in LDS (row stride padded by 4 floats: conflict-free
+// 16-byte stores) and the 64 x L*C block -- contiguous in memory -- leaves with fully coalesced 16-byte stores.
+// `extra` [B, E] (may be NULL, E = 0): appended to every row, i.e. outputs = cat([grid(inputs), extra], -1) -- the mask
+// head's MLP input (renderer.py:380: cat([m_grid(xyz), geo_feat])) without the 2 ms concatenation pass at 400x400.
+template <typename T, uint32_t C>
+__global__ __launch_bounds__(256) void k_grid_forward_rows(const float *__restrict__ inputs, const T *__restrict__ table,
+                                                           float *__restrict__ outputs, uint32_t B, GridLevels g, uint32_t max_level,
+                                                           const float *__restrict__ extra, uint32_t E) {
+    constexpr uint32_t D = 3;
+    extern __shared__ __attribute__((aligned(16))) float rows[];           // [64][L*C + 4]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t L = g.L, row_f = L * C, stride = row_f + 4u;
+    const uint32_t b0 = blockIdx.x * 64u, b_raw = b0 + lane;
+    const uint32_t b = b_raw < B ? b_raw : B - 1u;
+    float x01[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        x01[d] = inputs[(size_t)b * D + d];
+        if (x01[d] < 0 || x01[d] > 1) oob = true;
+    }
+    for (uint32_t level = wave; level < L; level += 4u) {
+        float acc[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) acc[c] = 0;
+        if (!oob && level < max_level) {                                    // gridencoder.cu:113-130: zeros outside [0,1]
+            const uint32_t res = g.res[level], size = g.size[level], mode = g.mode[level];
+            const T *tab = table + (size_t)g.off[level] * C;
+            float pos[D], deriv[D];
+            uint32_t cell[D];
+            grid_locate<D>(x01, res, g.align_corners != 0, g.interp, pos, deriv, cell);
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+                float w = 1;
+                uint32_t p[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; ++d) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; p[d] = cell[d]; }
+                    else { w *= pos[d]; p[d] = umin(cell[d] + 1, res - 1); }
+                }
+                float v[C];
+                load_row<T, (int)C>(tab + (size_t)grid_row<D>(p, res, size, mode) * C, v);
+#pragma unroll
+                for (uint32_t c = 0; c < C; ++c) acc[c] = __builtin_fmaf(w, v[c], acc[c]);
+            }
+        }
+        float *dst = rows + lane * stride + level * C;
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+            for (uint32_t q = 0; q < C / 4; ++q)
+                reinterpret_cast<float4 *>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) dst[c] = acc[c];
+        }
+    }
+    __syncthreads();
+    // the block's 64 rows are one contiguous span of the output
+    const uint32_t nrows = B - b0 < 64u ? B - b0 : 64u;
+    if (E == 0u) {
+        const uint32_t q_per_row = row_f / 4u;                              // row_f % 4 == 0 (checked on the host)
+        float4 *out4 = reinterpret_cast<float4 *>(outputs + (size_t)b0 * row_f);
+        for (uint32_t q = threadIdx.x; q < nrows * q_per_row; q += 256u) {
+            const uint32_t r = q / q_per_row, cq = q - r * q_per_row;
+            out4[q] = *reinterpret_cast<const float4 *>(rows + r * stride + 4u * cq);
+        }
+    } else {                                                                // rows of row_f + E floats: 4-byte stores, still one contiguous span
+        const uint32_t wide = row_f + E;
+        float *out = outputs + (size_t)b0 * wide;
+        const float *ex = extra + (size_t)b0 * E;
+        for (uint32_t q = threadIdx.x; q < nrows * wide; q += 256u) {
+            const uint32_t r = q / wide, c = q - r * wide;
+            out[q] = c < row_f ? rows[r * stride + c] : ex[r * E + (c - row_f)];
+        }
+    }
+}
+
 }  // namespace sn
 
 using namespace sn;
@@ -349,8 +431,25 @@ int sn_grid_encode_forward(const float *inputs, const void *embeddings, int tabl
     if (rc) return rc;
     if (max_level > L) max_level = L;
     if (B == 0 || max_level == 0) return SN_OK;
-    const dim3 grid(div_up(B, 256), max_level), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (layout == SN_LAYOUT_BLC && D == 3 && dy_dx == nullptr && (L * C) % 4 == 0 && (C == 2 || C == 4 || C == 8) &&
+        (size_t)64 * (L * C + 4) * sizeof(float) <= 64 * 1024) {
+        // rows assembled in LDS, coalesced stores (levels >= max_level are written as zeros)
+        const size_t lds = (size_t)64 * (L * C + 4) * sizeof(float);
+        const dim3 gr(div_up(B, 64));
+#define CALL_ROWS(CC)                                                                                                               \
+        do {                                                                                                                        \
+            if (table_dtype == SN_F32) hipLaunchKernelGGL((k_grid_forward_rows<float, CC>), gr, dim3(256), lds, st, inputs,         \
+                                                          (const float *)embeddings, outputs, B, g, max_level, nullptr, 0u);        \
+            else hipLaunchKernelGGL((k_grid_forward_rows<__half, CC>), gr, dim3(256), lds, st, inputs, (const __half *)embeddings,   \
+                                    outputs, B, g, max_level, nullptr, 0u);                                                         \
+        } while (0)
+        if (C == 2) CALL_ROWS(2); else if (C == 4) CALL_ROWS(4); else CALL_ROWS(8);
+#undef CALL_ROWS
+        SN_LAUNCH_CHECK("k_grid_forward_rows");
+        return SN_OK;
+    }
+    const dim3 grid(div_up(B, 256), max_level), block(256);
 #define CALL_FWD(DD, CC)                                                                                          \
     if (table_dtype == SN_F32)                                                                                    \
         hipLaunchKernelGGL((k_grid_forward<float, DD, CC>), grid, block, 0, st, inputs, (const float *)embeddings, \
@@ -361,6 +460,34 @@ int sn_grid_encode_forward(const float *inputs, const void *embeddings, int tabl
     SN_GRID_DISPATCH_DC(D, C, CALL_FWD);
 #undef CALL_FWD
     SN_LAUNCH_CHECK("k_grid_forward");
+    return SN_OK;
+}
+
+int sn_grid_encode_forward_cat(const float *inputs, const void *embeddings, int table_dtype, const int32_t *offsets_host,
+                               const float *extra, uint32_t E, float *outputs, uint32_t B, uint32_t C, uint32_t L,
+                               float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, sn_stream_t stream) {
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(inputs && embeddings && outputs && extra && E >= 1, "grid_encode_forward_cat: NULL pointer / no extra columns");
+    SN_REQUIRE(table_dtype == SN_F32 || table_dtype == SN_F16, "grid_encode_forward_cat: embeddings must be float32 or float16");
+    SN_REQUIRE(C == 2 || C == 4 || C == 8, "grid_encode_forward_cat: level_dim must be 2, 4 or 8 (got %u)", C);
+    SN_REQUIRE(table_aligned(embeddings), "grid_encode_forward_cat: embeddings must be 16-byte aligned");
+    const size_t lds = (size_t)64 * (L * C + 4) * sizeof(float);
+    SN_REQUIRE(lds <= 64 * 1024, "grid_encode_forward_cat: %u levels x %u features do not fit the row tile", L, C);
+    GridLevels g;
+    int rc = build_grid_levels(&g, offsets_host, 3, C, L, S, H, gridtype, align_corners, interp);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gr(div_up(B, 64));
+#define CALL_ROWS(CC)                                                                                                               \
+    do {                                                                                                                            \
+        if (table_dtype == SN_F32) hipLaunchKernelGGL((k_grid_forward_rows<float, CC>), gr, dim3(256), lds, st, inputs,             \
+                                                      (const float *)embeddings, outputs, B, g, L, extra, E);                      \
+        else hipLaunchKernelGGL((k_grid_forward_rows<__half, CC>), gr, dim3(256), lds, st, inputs, (const __half *)embeddings,       \
+                                outputs, B, g, L, extra, E);                                                                        \
+    } while (0)
+    if (C == 2) CALL_ROWS(2); else if (C == 4) CALL_ROWS(4); else CALL_ROWS(8);
+#undef CALL_ROWS
+    SN_LAUNCH_CHECK("k_grid_forward_rows");
     return SN_OK;
 }
 

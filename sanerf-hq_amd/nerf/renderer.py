@@ -197,9 +197,12 @@ class NeRFRenderer(nn.Module):
             if return_feats > 0:
                 results["samvit"] = samvit.view(H, W, -1)
         if return_mask > 0:                                 # renderer.py:304-305, 376-385
-            masks = self.m_grid(xyzs, bound=self.bound)
             if opt.mask_mlp_type == "default":
-                point_masks = self._head_mlp(self.mask_mlp, torch.cat([masks, geo_feat.detach()], dim=-1))
+                if torch.is_grad_enabled() and self.m_grid.embeddings.requires_grad:
+                    mlp_in = torch.cat([self.m_grid(xyzs, bound=self.bound), geo_feat.detach()], dim=-1)
+                else:   # inference: features and geometry channels land in one [.., 143] buffer in a single pass
+                    mlp_in = self.m_grid.forward_cat(xyzs, geo_feat, bound=self.bound)
+                point_masks = self._head_mlp(self.mask_mlp, mlp_in)
             else:
                 raise RuntimeError("mask_mlp_type='lightweight_mask' is dimensionally inconsistent in the reference "
                                    "(renderer.py:381 feeds 63 features into a 35-input MLP, network.py:128)")

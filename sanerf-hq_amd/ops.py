@@ -199,6 +199,25 @@ class GridEncoder(nn.Module):
         return out.view(lead + [self.output_dim])
 
     @torch.no_grad()
+    def forward_cat(self, inputs, extra, bound=1):
+        """cat([self(inputs, bound), extra], -1) in one pass, inference only (the mask head's MLP input, renderer.py:380:
+        no [B, L*C] intermediate and no concatenation pass).  inputs [..., 3], extra [..., E] -> [..., L*C + E]."""
+        x = ((inputs + bound) / (2 * bound)).reshape(-1, self.input_dim).contiguous().float()
+        lead = list(inputs.shape[:-1])
+        ex = extra.reshape(-1, extra.shape[-1]).contiguous().float()
+        B, E = x.shape[0], ex.shape[1]
+        if ex.shape[0] != B or self.input_dim != 3:
+            raise ValueError(f"forward_cat: inputs {tuple(inputs.shape)} / extra {tuple(extra.shape)} do not match (3-D inputs only)")
+        table = self.embeddings.detach().contiguous()
+        out = torch.empty(B, self.output_dim + E, device=x.device, dtype=torch.float32)
+        S = float(np.float32(np.log2(self.per_level_scale)))
+        _lib.check(_lib.lib().sn_grid_encode_forward_cat(
+            _lib.dev(x, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table), _lib.host_i32(_host_offsets(self.offsets)),
+            _lib.dev(ex, "extra"), E, _lib.dev(out, "outputs"), B, self.level_dim, self.num_levels, S, int(self.base_resolution),
+            self.gridtype_id, int(self.align_corners), self.interp_id, _lib.stream()), "grid_encode_forward_cat")
+        return out.view(lead + [self.output_dim + E])
+
+    @torch.no_grad()
     def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
         """In-place TV-regulariser gradient on .embeddings.grad (grid.py:170-191)."""
         if self.embeddings.grad is None:

@@ -388,6 +388,25 @@ def test_proposal_loss_kernel_matches_the_torch_expression(gpu, T_, Tr):
     assert float(l3) == float(l1), "deterministic"
 
 
+@pytest.mark.parametrize("C_,E,B", [(8, 15, 100003), (2, 3, 777), (4, 1, 64)])
+def test_grid_forward_cat_equals_encode_then_cat(gpu, C_, E, B):
+    """GridEncoder.forward_cat (sn_grid_encode_forward_cat, the mask head's MLP input) == cat([encoder(x), extra]) bit
+    for bit, including a last partial 64-row block and row widths that are not multiples of 4 floats."""
+    from sanerf_hq_amd.ops import GridEncoder
+    torch.manual_seed(C_ * 10 + E)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=C_, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).to(gpu)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = (torch.rand(B, 3, device=gpu) * 4.4 - 2.2)          # some samples outside [-2, 2]: zero rows (gridencoder.cu:113-130)
+    extra = torch.randn(B, E, device=gpu)
+    with torch.no_grad():
+        want = torch.cat([enc(x, bound=2), extra], dim=-1)
+    got = enc.forward_cat(x, extra, bound=2)
+    assert got.shape == (B, 16 * C_ + E) and torch.equal(got, want)
+    got3 = enc.forward_cat(x.view(-1, 1, 3), extra.view(-1, 1, E), bound=2)
+    assert got3.shape == (B, 1, 16 * C_ + E) and torch.equal(got3.view(B, -1), want)
+
+
 def test_weights_and_composite(gpu, orc):
     from sanerf_hq_amd import raymarching as rm
     rng = np.random.default_rng(70)
