@@ -135,8 +135,13 @@ WEIGHTS_BACKWARD_MAX_T = 256      # sn_rm_weights_from_sigma_backward keeps a ra
 def weights_from_sigma(real_bins, sigmas, last_sample_opaque: bool = True):
     """real_bins [N,T+1], sigmas [N,T] -> weights [N,T]; under autograd the gradient reaches `sigmas` (T <= 256)."""
     if torch.is_grad_enabled() and sigmas.requires_grad:
-        if sigmas.shape[-1] > WEIGHTS_BACKWARD_MAX_T:
-            raise ValueError(f"weights_from_sigma: autograd supports at most {WEIGHTS_BACKWARD_MAX_T} samples per ray")
+        if sigmas.shape[-1] > WEIGHTS_BACKWARD_MAX_T:       # longer rays than the backward kernel holds: torch's own chain
+            ds = (real_bins[..., 1:] - real_bins[..., :-1]).detach() * sigmas
+            if last_sample_opaque:
+                ds = torch.cat([ds[..., :-1], torch.full_like(ds[..., -1:], torch.inf)], dim=-1)
+            trans = torch.cumsum(ds[..., :-1], dim=-1)
+            trans = torch.exp(-torch.cat([torch.zeros_like(ds[..., :1]), trans], dim=-1))
+            return ((1 - torch.exp(-ds)) * trans).nan_to_num(0)
         return _weights_from_sigma.apply(real_bins, sigmas, bool(last_sample_opaque))
     return _weights_from_sigma.forward(_NoCtx(), real_bins, sigmas, bool(last_sample_opaque))
 

@@ -275,7 +275,7 @@ def test_sample_pdf_large_random(gpu, orc):
     assert np.array_equal(got_i.cpu().numpy(), want_i) and np.array_equal(got_b.cpu().numpy(), want_b)
 
 
-@pytest.mark.parametrize("T_,opaque", [(1, True), (33, True), (64, False), (128, True), (200, False), (256, True)])
+@pytest.mark.parametrize("T_,opaque", [(1, True), (33, True), (64, False), (128, True), (200, False), (256, True), (300, True)])
 def test_weights_from_sigma_autograd(gpu, orc, T_, opaque):
     """The autograd form of weights_from_sigma against torch's own derivative of renderer.py:308-325 evaluated in fp64
     (delta*sigma -> alpha, exclusive cumsum -> transmittance, product, nan_to_num)."""
@@ -287,7 +287,10 @@ def test_weights_from_sigma_autograd(gpu, orc, T_, opaque):
     go = rng.standard_normal((N, T_)).astype(np.float32)
     s1 = T(sg, gpu).requires_grad_(True)
     w = rm.weights_from_sigma(T(rb, gpu), s1, opaque)
-    assert np.array_equal(w.detach().cpu().numpy(), orc.weights_from_sigma(rb, sg, opaque))
+    if T_ <= rm.raymarching.WEIGHTS_BACKWARD_MAX_T:
+        assert np.array_equal(w.detach().cpu().numpy(), orc.weights_from_sigma(rb, sg, opaque))
+    else:   # longer rays fall back to torch's chain (fp32 cumsum on the device): close, not bit-equal
+        np.testing.assert_allclose(w.detach().cpu().numpy(), orc.weights_from_sigma(rb, sg, opaque), rtol=2e-4, atol=1e-7)
     w.backward(T(go, gpu))
     s2 = T(sg, gpu).double().requires_grad_(True)
     rbd = T(rb, gpu).double()
@@ -300,7 +303,7 @@ def test_weights_from_sigma_autograd(gpu, orc, T_, opaque):
     ((alphas * trans).nan_to_num(0) * T(go, gpu).double()).sum().backward()
     ref = s2.grad.float()
     err = float((s1.grad - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
-    assert err < 2e-5, err
+    assert err < (2e-5 if T_ <= rm.raymarching.WEIGHTS_BACKWARD_MAX_T else 1e-3), err
     if opaque:
         assert float(s1.grad[:, -1].abs().max()) == 0.0, "the opaque last sample is a constant"
 
