@@ -150,6 +150,12 @@ int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigma
 int sn_rm_proposal_loss(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
                         uint32_t Tr, float *loss_per_ray, float *grad_weights, sn_stream_t stream);
 
+/* Distortion loss (nerf/renderer.py:17-27 -> torch_efficient_distloss.eff_distloss, third party, not vendored: the
+ * published value is mean over rays of (1/3) sum_i w_i^2 d_i + sum_ij w_i w_j |m_i - m_j|) on bins [N,T+1], weights [N,T]:
+ * loss_per_ray [N] (the reference's value is its mean) and grad_weights [N,T] = d loss_per_ray / d w, in one pass. */
+int sn_rm_distort_loss(const float *bins, const float *weights, uint32_t N, uint32_t T, float *loss_per_ray, float *grad_weights,
+                       sn_stream_t stream);
+
 /* One stage's sample geometry (renderer.py:277-285): bins [N,T+1] in [0,1] -> real_bins [N,T+1] (distances along the
  * ray through the Mip-360 spacing of nears/fars [N]), rays_t [N,T] (mid-points), xyzs [N,T,3] (positions, contracted
  * into [-2,2]^3 like sn_rm_contract if `contract`).  Nothing here is differentiated by the reference. */

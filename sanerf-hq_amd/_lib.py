@@ -78,6 +78,7 @@ _SIGNATURES = {
     "sn_rm_sample_pdf": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp]),
     "sn_rm_weights_from_sigma": (_int, [_vp, _vp, _u32, _u32, _int, _vp, _vp]),
     "sn_rm_weights_from_sigma_backward": (_int, [_vp, _vp, _vp, _u32, _u32, _int, _vp, _vp]),
+    "sn_rm_distort_loss": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_proposal_loss": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_sample_positions": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _vp, _vp, _vp, _vp]),
     "sn_rm_composite": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),

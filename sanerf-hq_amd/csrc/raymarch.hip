@@ -389,6 +389,39 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
     }
 }
 
+// Distortion loss of Mip-NeRF 360 on the final stage's normalised bins (nerf/renderer.py:17-27; the reference calls the
+// third-party torch_efficient_distloss.eff_distloss(w, m, interval), whose value is
+//   mean_rays[ (1/3) sum_i w_i^2 d_i + 2 sum_{i>j} w_i w_j (m_i - m_j) ]   with m = interval mid-points, d = lengths,
+// i.e. sum_ij w_i w_j |m_i - m_j| for sorted bins).  One wave per ray, lane k owns samples k, k+64, ...: the inner sum
+// S_k = sum_j w_j |m_k - m_j| is evaluated directly (T terms per sample, no prefix-sum cancellation), which gives the
+// value and the gradient at once:  loss_ray = (1/3) sum_k w_k^2 d_k + sum_k w_k S_k,  dloss_ray/dw_k = (2/3) w_k d_k + 2 S_k.
+__global__ __launch_bounds__(256) void k_distort_loss(const float *__restrict__ bins, const float *__restrict__ weights, uint32_t N,
+                                                      uint32_t T, float *__restrict__ loss_per_ray, float *__restrict__ grad_w) {
+    extern __shared__ float dl_lds[];                    // per wave: w[T] | m[T]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_raw = blockIdx.x * 4u + wave;
+    const uint32_t n = n_raw < N ? n_raw : N - 1u;
+    float *w = dl_lds + (size_t)wave * 2u * T, *m = w + T;
+    const float *b = bins + (size_t)n * (T + 1);
+    for (uint32_t i = lane; i < T; i += 64u) {
+        const float b0 = b[i], d = b[i + 1u] - b0;
+        w[i] = weights[(size_t)n * T + i];
+        m[i] = b0 + d / 2.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float part = 0.0f;
+    for (uint32_t k = lane; k < T; k += 64u) {
+        const float mk = m[k], wk = w[k], dk = b[k + 1u] - b[k];
+        float S = 0.0f;
+        for (uint32_t j = 0; j < T; ++j) S = __builtin_fmaf(w[j], fabsf(mk - m[j]), S);
+        part += wk * wk * dk / 3.0f + wk * S;
+        if (n_raw < N) grad_w[(size_t)n * T + k] = 2.0f * wk * dk / 3.0f + 2.0f * S;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) part += __shfl_xor(part, k);
+    if (lane == 0u && n_raw < N) loss_per_ray[n] = part;
+}
+
 // out[n,k] = sum_t w[n,t] * v[n,t,k], sequential fmaf over t (renderer.py:333-338,361,384)
 __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ weights, const float *__restrict__ values,
                                                    uint32_t N, uint32_t T, uint32_t K, float *__restrict__ out) {
@@ -518,6 +551,17 @@ int sn_rm_proposal_loss(const float *bins, const float *weights, const float *re
         hipLaunchKernelGGL(k_proposal_loss<true>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, grad_weights);
     }
     SN_LAUNCH_CHECK("k_proposal_loss");
+    return SN_OK;
+}
+
+int sn_rm_distort_loss(const float *bins, const float *weights, uint32_t N, uint32_t T, float *loss_per_ray, float *grad_weights,
+                       sn_stream_t stream) {
+    SN_REQUIRE(bins && weights && loss_per_ray && grad_weights, "distort_loss: NULL pointer");
+    SN_REQUIRE(T >= 1 && T <= 2048, "distort_loss: 1..2048 samples per ray (got %u)", T);
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_distort_loss, dim3(div_up(N, 4)), dim3(256), (size_t)4 * 2 * T * sizeof(float), (hipStream_t)stream, bins, weights, N, T,
+                       loss_per_ray, grad_weights);
+    SN_LAUNCH_CHECK("k_distort_loss");
     return SN_OK;
 }
 

@@ -56,6 +56,8 @@ def proposal_loss(all_bins, all_weights):
 def distort_loss(bins, weights):
     """Mip-NeRF-360 distortion loss, O(T) per ray (what the reference gets from the third-party
     `eff_distloss`, nerf/renderer.py:17-27): sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 d_i, mean over rays."""
+    if weights.is_cuda and weights.dim() == 2 and weights.shape[-1] <= rm.DISTORT_LOSS_MAX_T:
+        return rm.distort_loss(bins, weights)              # value and gradient from one kernel
     d = bins[..., 1:] - bins[..., :-1]
     m = bins[..., :-1] + d / 2
     wm = weights * m

@@ -209,6 +209,38 @@ def proposal_loss_stage(bins, weights, ref_bins, ref_weights):
     return _proposal_loss_stage.apply(bins, weights, ref_bins, ref_weights)
 
 
+class _distort_loss(Function):
+    """Mip-NeRF-360 distortion loss of nerf/renderer.py:17-27 (the reference delegates to the third-party
+    torch_efficient_distloss.eff_distloss): mean over rays of (1/3) sum w_i^2 d_i + sum_ij w_i w_j |m_i - m_j|;
+    value and d/dw from one kernel, the gradient is kept for backward (bins carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, bins, weights):
+        bins = bins.detach().contiguous().float()
+        w = weights.detach().contiguous().float()
+        N, T = w.shape
+        per_ray = torch.empty(N, device=w.device, dtype=torch.float32)
+        gw = torch.empty_like(w)
+        _lib.check(_lib.lib().sn_rm_distort_loss(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), N, T, _lib.dev(per_ray, "loss_per_ray"),
+                                                 _lib.dev(gw, "grad_weights"), _lib.stream()), "distort_loss")
+        ctx.save_for_backward(gw)
+        ctx.n = N
+        return per_ray.sum() / float(N)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (gw,) = ctx.saved_tensors
+        return None, gw * (grad_out / float(ctx.n))
+
+
+DISTORT_LOSS_MAX_T = 2048
+
+
+def distort_loss(bins, weights):
+    """bins [N,T+1], weights [N,T] -> scalar (renderer.py:17-27)."""
+    return _distort_loss.apply(bins, weights)
+
+
 class _composite(Function):
     """out[n,k] = sum_t w[n,t] * v[n,t,k]."""
 

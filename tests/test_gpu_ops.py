@@ -410,6 +410,34 @@ def test_grid_forward_cat_equals_encode_then_cat(gpu, C_, E, B):
     assert got3.shape == (B, 1, 16 * C_ + E) and torch.equal(got3.view(B, -1), want)
 
 
+@pytest.mark.parametrize("T_", [1, 32, 64, 100, 200])
+def test_distort_loss_kernel(gpu, T_):
+    """sn_rm_distort_loss against the O(T^2) definition sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 d_i in fp64 (value and
+    autograd gradient), and against the cumulative-sum form the CPU path uses (what eff_distloss computes)."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf import renderer as R
+    rng = np.random.default_rng(T_)
+    N = 301
+    b = np.sort(rng.uniform(0, 1, (N, T_ + 1)), axis=1).astype(np.float32)
+    w = (rng.uniform(0, 1, (N, T_)) ** 4).astype(np.float32)
+    w1 = T(w, gpu).requires_grad_(True)
+    l1 = rm.distort_loss(T(b, gpu), w1)
+    (l1 * 0.7).backward()
+    w2 = T(w, gpu).double().requires_grad_(True)
+    bd = T(b, gpu).double()
+    d = bd[:, 1:] - bd[:, :-1]
+    m = bd[:, :-1] + d / 2
+    l2 = ((w2[:, :, None] * w2[:, None, :] * (m[:, :, None] - m[:, None, :]).abs()).sum((1, 2)) + (w2 * w2 * d).sum(1) / 3).mean()
+    (l2 * 0.7).backward()
+    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l2)) + 1e-9
+    assert float((w1.grad - w2.grad.float()).abs().max()) <= 1e-5 * float(w2.grad.abs().max()) + 1e-12
+    w3 = torch.from_numpy(w).double().requires_grad_(True)
+    l3 = R.distort_loss(torch.from_numpy(b).double(), w3)      # CPU tensors: the cumulative-sum statement
+    (l3 * 0.7).backward()
+    assert abs(float(l3) - float(l2)) <= 1e-9 * abs(float(l2)) + 1e-12
+    assert float((w3.grad - w2.grad.cpu()).abs().max()) <= 1e-9 * float(w2.grad.abs().max()) + 1e-14
+
+
 def test_weights_and_composite(gpu, orc):
     from sanerf_hq_amd import raymarching as rm
     rng = np.random.default_rng(70)

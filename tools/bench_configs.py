@@ -116,6 +116,8 @@ def main():
         optim.zero_grad(set_to_none=True)
         o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=True)
         loss = torch.nn.functional.mse_loss(o["image"], gt) + opt.lambda_proposal * o["proposal_loss"]
+        if "distort_loss" in o:                                     # main.py:112: lambda_distort defaults to 0.02
+            loss = loss + opt.lambda_distort * o["distort_loss"]
         loss.backward()
         return loss
 
@@ -126,6 +128,9 @@ def main():
     t_st = timeit(rgb_step)
     out["RGB_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_st * 1e3, 3),
                                           "rays_per_s_step": round(N / t_st, 1)}
+    opt.lambda_distort = 0.02                                       # the reference's default loss: + distortion term
+    out["RGB_training_step_4096_rays"]["fwd_bwd_with_distort_loss_ms"] = round(timeit(rgb_fwd_bwd) * 1e3, 3)
+    opt.lambda_distort = 0.0
     try:   # torch's single-kernel Adam (same update rule; the reference constructs the default multi-tensor one)
         optim = torch.optim.Adam(model.get_params(1e-2), eps=1e-15, fused=True)
         out["RGB_training_step_4096_rays"]["fwd_bwd_fused_adam_ms"] = round(timeit(rgb_step) * 1e3, 3)
