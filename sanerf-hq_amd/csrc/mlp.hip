@@ -584,6 +584,89 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_partial(const float *__res
         }
 }
 
+// fold step of k_linear_wgrad_rows: v[0..CNT) per lane, lanes differing in bit D exchange halves; `base` = index of
+// v[0] in the output once the lane bits seen so far have chosen their halves.  D = 0: every lane of a group of equal
+// `base` holds the finished sums of its CNT outputs; the group's first lane stores them.
+template <int CNT, int D>
+__device__ __forceinline__ void wgrad_fold(float *v, uint32_t lane, uint32_t base, float *__restrict__ out) {
+    if constexpr (D == 0) {
+        // lanes that took the same halves at every halving stage are equal here; plain stages left all their lanes equal too
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) out[base + i] = v[i];      // same value from every lane of the group: benign
+    } else if constexpr (CNT % 2 == 0) {
+        constexpr int H = CNT / 2;
+        const bool up = (lane & (uint32_t)D) != 0u;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const float lo = v[i], hi = v[i + H];
+            const float r = __shfl_xor(up ? lo : hi, D);
+            v[i] = (up ? hi : lo) + r;
+        }
+        wgrad_fold<H, D / 2>(v, lane, base + (up ? (uint32_t)H : 0u), out);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) v[i] += __shfl_xor(v[i], D);
+        wgrad_fold<CNT, D / 2>(v, lane, base, out);
+    }
+}
+
+// The proposal MLPs' two layers (10 -> 16 -> 1) see 262 144 / 524 288 samples per step; the tile kernel above keeps
+// 12 or 4 of its 256 threads busy on such outputs (69 us for the larger one: 0.8 TB/s).  Here a lane owns whole rows:
+// it reads its row of x and of dy (consecutive lanes = consecutive rows = contiguous memory) and keeps the full N x K
+// outer-product sum in registers; a wave takes `rows_per_wave` rows, folds its 64 lanes with a butterfly and writes
+// one partial result; k_linear_wgrad_sum adds the waves in a fixed order.
+template <int K, int N>
+__global__ __launch_bounds__(256) void k_linear_wgrad_rows(const float *__restrict__ x, const float *__restrict__ dy, uint32_t M,
+                                                           uint32_t rows_per_wave, float *__restrict__ partial) {
+    const uint32_t lane = threadIdx.x & 63u, wg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t m0 = (uint64_t)wg * rows_per_wave;
+    if (m0 >= M) return;
+    float acc[N][K];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[n][k] = 0.0f;
+    auto load_row = [&](uint64_t m, float (&xv)[K], float (&dv)[N]) {
+        if constexpr (K % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < K; k += 2) { const float2 t = *reinterpret_cast<const float2 *>(x + m * K + k); xv[k] = t.x; xv[k + 1] = t.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) xv[k] = x[m * K + k];
+        }
+        if constexpr (N % 4 == 0) {
+#pragma unroll
+            for (int n = 0; n < N; n += 4) { const float4 t = *reinterpret_cast<const float4 *>(dy + m * N + n); dv[n] = t.x; dv[n + 1] = t.y; dv[n + 2] = t.z; dv[n + 3] = t.w; }
+        } else {
+#pragma unroll
+            for (int n = 0; n < N; ++n) dv[n] = dy[m * N + n];
+        }
+    };
+    // two rows per trip, both rows' loads issued before the first product (a row past the end is read at row M-1 and
+    // multiplied by zero: no branch between the loads)
+    for (uint32_t r = lane; r < rows_per_wave; r += 128u) {
+        const uint64_t ma = m0 + r, mb = ma + 64u;
+        const bool va = ma < M, vb = mb < M && r + 64u < rows_per_wave;
+        float xa[K], da[N], xb[K], db[N];
+        load_row(va ? ma : (uint64_t)M - 1u, xa, da);
+        load_row(vb ? mb : (uint64_t)M - 1u, xb, db);
+        const float sa = va ? 1.0f : 0.0f, sb = vb ? 1.0f : 0.0f;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float ya = da[n] * sa, yb = db[n] * sb;
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[n][k] = __builtin_fmaf(yb, xb[k], __builtin_fmaf(ya, xa[k], acc[n][k]));
+        }
+    }
+    // Fold the 64 lanes.  A plain butterfly is 6 dependent shuffles per output (960 for the 16 x 10 layer, latency-bound:
+    // 40 us); instead each stage also halves what a lane is responsible for -- the lane whose bit is clear keeps the
+    // first half of its values and receives the partner's first half, the other lane the second half -- so a stage costs
+    // CNT/2 independent shuffles: 80 + 40 + 20 + 10 + 5 (+ 5 plain ones once the count is odd) = 160.
+    float *out = partial + (size_t)wg * (N * K);
+    float *v = &acc[0][0];
+    wgrad_fold<N * K, 32>(v, lane, 0u, out);
+}
+
 // dw[i] = sum over slabs, in a fixed order: LPO lanes per output stride over the slabs, then a shuffle tree.  The small
 // layers have <= 4096 outputs and up to 1024 slabs: with 16 lanes per output each lane walked 64 dependent-latency
 // loads (20 us per layer, seven layers per RGB-mode step); 64 lanes per output walk 16.
@@ -790,6 +873,19 @@ extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint
         return SN_OK;
     }
     const uint32_t tiles = sn::div_up(M, sn::WG_ROWS);
+    if (((K == 10 && N == 16) || (K == 16 && N == 1)) && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0) {
+        // the proposal MLPs' layers: one lane per row, whole output in registers (at most min(tiles, 1024) partial results)
+        uint32_t rpw = sn::div_up(M, sn::WG_MAX_SLABS);
+        rpw = rpw < sn::WG_ROWS ? sn::WG_ROWS : ((rpw + 63u) & ~63u);
+        const uint32_t nwave = sn::div_up(M, rpw);
+        float *part = reinterpret_cast<float *>(workspace);
+        if (K == 10) hipLaunchKernelGGL((sn::k_linear_wgrad_rows<10, 16>), dim3(sn::div_up(nwave, 4)), dim3(256), 0, st, x, dy, M, rpw, part);
+        else hipLaunchKernelGGL((sn::k_linear_wgrad_rows<16, 1>), dim3(sn::div_up(nwave, 4)), dim3(256), 0, st, x, dy, M, rpw, part);
+        SN_LAUNCH_CHECK("k_linear_wgrad_rows");
+        hipLaunchKernelGGL(sn::k_linear_wgrad_sum<64>, dim3(sn::div_up(N * K, 4)), dim3(256), 0, st, part, nwave, N * K, dw);
+        SN_LAUNCH_CHECK("k_linear_wgrad_sum");
+        return SN_OK;
+    }
     const uint32_t nslab = tiles < sn::WG_MAX_SLABS ? tiles : sn::WG_MAX_SLABS;
     hipLaunchKernelGGL(sn::k_linear_wgrad_partial, dim3(nslab), dim3(256), 0, st, x, dy, M, K, N, reinterpret_cast<float *>(workspace));
     SN_LAUNCH_CHECK("k_linear_wgrad_partial");

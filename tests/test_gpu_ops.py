@@ -567,7 +567,7 @@ def test_wide_mlp_large_batch_is_race_free(gpu):
         assert torch.equal(rm.mlp_forward(x, mlp, ln), first)
 
 
-@pytest.mark.parametrize("M,K,N", [(131072, 32, 64), (5000, 10, 16), (70001, 16, 1), (4096, 31, 32), (1, 64, 64)])
+@pytest.mark.parametrize("M,K,N", [(131072, 32, 64), (5000, 10, 16), (70001, 16, 1), (4096, 31, 32), (1, 64, 64), (524288, 10, 16), (262147, 16, 1), (130, 10, 16), (63, 16, 1)])
 def test_linear_wgrad_matches_matmul(gpu, M, K, N):
     """sn_linear_wgrad: dw = dy^T x for the <= 64-wide layers of the radiance / proposal MLPs."""
     import ctypes as C

@@ -27,7 +27,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.lib()
     out = {}
-    for M, K, N in ((131072, 256, 256), (131072, 143, 256), (131072, 256, 2), (131072, 419, 256), (524288, 32, 64)):
+    for M, K, N in ((131072, 256, 256), (131072, 143, 256), (131072, 256, 2), (131072, 419, 256), (524288, 32, 64), (524288, 10, 16), (524288, 16, 1), (131072, 64, 64)):
         x, dy = torch.randn(M, K, device=dev), torch.randn(M, N, device=dev)
         ws = torch.empty(int(lib.sn_linear_wgrad_workspace_bytes(M, K, N)), dtype=torch.uint8, device=dev)
         dw = torch.empty(N, K, device=dev)
