@@ -716,7 +716,9 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_sum4(const float4 *__restr
 //         real one (tile column jj of block cb <-> real column 4*jj + cb%4 of a 128-wide group), undone on store.
 //   FLAT: N <= 32 (the 2-output last layer): one row block, the four waves split the columns instead.
 
-template <int CBW, bool VEC, bool FLAT>
+//   MSPLIT: N, K <= 64 (the radiance MLP's layers): one wave holds the whole 64 x 64 output, so the four waves of a
+//         workgroup split the slab's ROWS instead and each writes its own partial result (4 per workgroup).
+template <int CBW, bool VEC, bool FLAT, bool MSPLIT = false>
 __global__ __launch_bounds__(256, 1) void k_linear_wgrad_mfma(const float *__restrict__ x, const float *__restrict__ dy, uint32_t M,
                                                               uint32_t K, uint32_t N, uint32_t rows_per_slab, float *__restrict__ partial) {
     constexpr int RBW = FLAT ? 1 : 2;
@@ -725,10 +727,13 @@ __global__ __launch_bounds__(256, 1) void k_linear_wgrad_mfma(const float *__res
     constexpr int WGM_PF = FLAT ? 32 : (CBW <= 4 ? 16 : 8);
     static_assert(!VEC || (CBW % 4 == 0 && !FLAT), "vector loads cover four column blocks / two row blocks at a time");
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, lo = lane & 31u, hi = lane >> 5;
-    const uint32_t r0 = FLAT ? 0u : 64u * wave;                                        // first output row of this wave
-    const uint32_t c0 = (FLAT ? (blockIdx.y * 4u + wave) : blockIdx.y) * (CBW * 32u);  // first column of this wave
-    const uint32_t m_begin = blockIdx.x * rows_per_slab;
-    const uint32_t m_end = m_begin + rows_per_slab < M ? m_begin + rows_per_slab : M;
+    static_assert(!MSPLIT || (!FLAT && !VEC && CBW == 2), "row-split form: 64 x 64 outputs, scalar loads");
+    const uint32_t r0 = (FLAT || MSPLIT) ? 0u : 64u * wave;                            // first output row of this wave
+    const uint32_t c0 = MSPLIT ? 0u : (FLAT ? (blockIdx.y * 4u + wave) : blockIdx.y) * (CBW * 32u);  // first column of this wave
+    const uint32_t slab = MSPLIT ? blockIdx.x * 4u + wave : blockIdx.x;                // rows_per_slab is per wave when MSPLIT
+    const uint64_t mb64 = (uint64_t)slab * rows_per_slab;
+    const uint32_t m_begin = mb64 < M ? (uint32_t)mb64 : M;
+    const uint32_t m_end = mb64 + rows_per_slab < M ? m_begin + rows_per_slab : M;
     struct Step { float a[RBW]; float b[CBW]; };
     // Output rows >= N / columns >= K are never stored, so their operands may be anything finite or not: addresses
     // are clamped into the arrays and nothing is selected after the load (a select per loaded value made the
@@ -801,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void k_linear_wgrad_mfma(const float *__res
         fma_step(cur);
     }
     // accumulator register r of lane l holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
-    float *out = partial + (size_t)blockIdx.x * N * K;
+    float *out = partial + (size_t)slab * N * K;
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
@@ -839,7 +844,7 @@ extern "C" size_t sn_linear_wgrad_workspace_bytes(uint32_t M, uint32_t K, uint32
     if (K == 0 || N == 0 || N > sn::WGM_MAX_N) return 0;
     if (K > 64 || N > 64) return (size_t)sn::div_up(M ? M : 1u, sn::wgm_rows_per_slab(M)) * N * K * sizeof(float);
     const uint32_t tiles = sn::div_up(M ? M : 1u, sn::WG_ROWS);
-    return (size_t)(tiles < sn::WG_MAX_SLABS ? tiles : sn::WG_MAX_SLABS) * N * K * sizeof(float);
+    return (size_t)((tiles < sn::WG_MAX_SLABS ? tiles : sn::WG_MAX_SLABS) + 3u) * N * K * sizeof(float);   // + 3: whole workgroups of 4 wave-slabs
 }
 
 extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uint32_t N, float *dw,
@@ -883,6 +888,18 @@ extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint
         else hipLaunchKernelGGL((sn::k_linear_wgrad_rows<16, 1>), dim3(sn::div_up(nwave, 4)), dim3(256), 0, st, x, dy, M, rpw, part);
         SN_LAUNCH_CHECK("k_linear_wgrad_rows");
         hipLaunchKernelGGL(sn::k_linear_wgrad_sum<64>, dim3(sn::div_up(N * K, 4)), dim3(256), 0, st, part, nwave, N * K, dw);
+        SN_LAUNCH_CHECK("k_linear_wgrad_sum");
+        return SN_OK;
+    }
+    if (M >= 16384u && !getenv("SN_WGRAD_NO_MSPLIT")) {
+        // <= 64 x 64 over many rows (the radiance MLP's layers): matrix cores, each wave its own slab of rows
+        uint32_t rpw = sn::div_up(M, sn::WG_MAX_SLABS);
+        rpw = rpw < sn::WG_ROWS ? sn::WG_ROWS : ((rpw + 1u) & ~1u);
+        const uint32_t nblk = sn::div_up(sn::div_up(M, rpw), 4u), nparts = nblk * 4u;
+        float *part = reinterpret_cast<float *>(workspace);
+        hipLaunchKernelGGL((sn::k_linear_wgrad_mfma<2, false, false, true>), dim3(nblk), dim3(256), 0, st, x, dy, M, K, N, rpw, part);
+        SN_LAUNCH_CHECK("k_linear_wgrad_mfma");
+        hipLaunchKernelGGL(sn::k_linear_wgrad_sum<64>, dim3(sn::div_up(N * K, 4)), dim3(256), 0, st, part, nparts, N * K, dw);
         SN_LAUNCH_CHECK("k_linear_wgrad_sum");
         return SN_OK;
     }
