@@ -116,7 +116,7 @@ class PipelinedGather:
         slot = self.k % len(self.images)
         if self.works[slot] is not None:
             self.works[slot].wait()                 # the buffer's previous frame is complete
-        if self.world == 1:
+        if not dist.is_initialized():
             self.images[slot].copy_(local)
         else:
             self.works[slot] = dist.all_gather_into_tensor(self.images[slot], local.contiguous(), group=self.group, async_op=True)
