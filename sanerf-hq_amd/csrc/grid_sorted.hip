@@ -208,6 +208,15 @@ static int key_bits(uint32_t sentinel) {
     return bits;
 }
 
+// temporary storage of the (key, pair index) sort in its DoubleBuffer form: the four slabs of the workspace are the
+// ping-pong buffers, so this is only the sort's control state (digit histograms, look-back flags, block counter)
+static size_t sort_temp_bytes(uint32_t n) {
+    size_t temp = 0;
+    hipcub::DoubleBuffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp, dk, dv, (int)n, 0, 32) != hipSuccess) return 0;
+    return temp;
+}
+
 }  // namespace sn
 
 using namespace sn;
@@ -218,9 +227,8 @@ size_t sn_grid_backward_sorted_workspace_bytes(uint32_t B, uint32_t D, uint32_t 
     if (D < 2 || D > 3 || C == 0) return 0;
     const uint64_t n = (uint64_t)B * max_level * (1u << D);
     if (n == 0 || n >= (1ull << 31)) return 0;
-    size_t temp = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                           (uint32_t *)nullptr, (int)n, 0, 32) != hipSuccess) return 0;
+    const size_t temp = sort_temp_bytes((uint32_t)n);
+    if (temp == 0) return 0;
     return 4 * align256((size_t)n * sizeof(uint32_t)) + align256((size_t)n * C * sizeof(float)) + align256(temp) + 256;
 }
 
@@ -249,7 +257,7 @@ int sn_grid_encode_backward_sorted(const float *grad, const float *inputs, const
     float *contrib = reinterpret_cast<float *>(w + 4 * slab);
     const size_t cslab = align256((size_t)n * C * sizeof(float));
     void *temp = w + 4 * slab + cslab;
-    size_t temp_bytes = workspace_bytes - 4 * slab - cslab;
+    size_t temp_bytes = sort_temp_bytes(n);                   // exactly what the sort asks for (the cached workspace may be far larger)
     const uint32_t sentinel = (uint32_t)offsets_host[L];     // one past the last row
     hipStream_t st = (hipStream_t)stream;
     const dim3 gk(div_up((uint64_t)B << D, 256), max_level), blk(256);
@@ -266,8 +274,14 @@ int sn_grid_encode_backward_sorted(const float *grad, const float *inputs, const
 #undef SN_KEYS
     if (!ok) { set_error("grid_encode_backward_sorted: C=%u not instantiated for D=%u", C, D); return SN_ERR_UNSUPPORTED; }
     SN_LAUNCH_CHECK("k_bwd_keys");
-    SN_HIP_OK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k0, k1, v0, v1, (int)n, 0, key_bits(sentinel), st));
-#define SN_REDUCE(CC) hipLaunchKernelGGL((k_bwd_reduce<CC>), gr, blk, 0, st, k1, v1, n, sentinel, contrib, grad_embeddings)
+    // The sort's control storage is cleared by us: the same workspace serves grids with different pair counts (different
+    // layouts of that storage), and a replayed HIP graph of the training step faulted inside the onesweep kernel
+    // (scatter through stale state) until this memset was added.  A few hundred KiB.
+    SN_HIP_OK(hipMemsetAsync(temp, 0, temp_bytes, st));
+    hipcub::DoubleBuffer<uint32_t> dkeys(k0, k1), dvals(v0, v1);
+    SN_HIP_OK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, dkeys, dvals, (int)n, 0, key_bits(sentinel), st));
+    const uint32_t *ks = dkeys.Current(), *vs = dvals.Current();        // whichever slab the last pass wrote
+#define SN_REDUCE(CC) hipLaunchKernelGGL((k_bwd_reduce<CC>), gr, blk, 0, st, ks, vs, n, sentinel, contrib, grad_embeddings)
     switch (C) { case 1: SN_REDUCE(1); break; case 2: SN_REDUCE(2); break; case 4: SN_REDUCE(4); break;
                  case 8: SN_REDUCE(8); break; case 16: SN_REDUCE(16); break; case 32: SN_REDUCE(32); break; default: ok = false; }
 #undef SN_REDUCE

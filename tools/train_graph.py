@@ -44,6 +44,10 @@ optim.zero_grad(set_to_none=True)
 with torch.cuda.graph(g):
     step()
 print("captured", flush=True)
+# Known fragility (ROCm 7.2, rocPRIM onesweep inside a replayed graph): before the library cleared the sort's control
+# storage itself, the first replay faulted inside the radix-sort kernel ("write access to a read-only page") whenever the
+# step's allocation pattern changed; with the memset this tool replays cleanly, but a minimal two-grid reproduction still
+# faulted under pytest (not as a plain script) -- treat graph replay of sort-containing steps as experimental.
 # Each replay is followed by a synchronisation (as a loop that reads the loss every step would): queueing several
 # replays of this graph back to back wedged the stream on ROCm 7.2 (it contains hipCUB radix sorts, whose decoupled
 # look-back kernels spin on flags) -- observed once, not investigated further.
