@@ -46,6 +46,9 @@ python $root/tools/mlp_bench.py > $out/ubench_head_mlp.txt 2>&1
 python $root/tools/wgrad_bench.py 2>/dev/null | tail -1 > $out/ubench_wgrad.json
 python $root/tools/prop_sp_ab.py 2>/dev/null | tail -1 > $out/small_batch_kernels_ab.json
 SN_AB_STEPS=128 python $root/tools/prop_sp_ab.py 2>/dev/null | tail -1 > $out/small_batch_kernels_ab_flat128.json
+# robustness evidence: every fused path repeated on identical inputs (bit-equal?), random configurations against the oracle
+python $root/tools/stress_determinism.py 30 2>&1 | grep -v amdgpu.ids > $out/stress_determinism.txt
+python $root/tools/fuzz_parity.py 60 31 2>&1 | grep -v amdgpu.ids | tail -12 > $out/fuzz_parity_tail.txt
 # un-profiled numbers
 cd $root
 python tools/bench_configs.py 2>/dev/null | tail -1 > $out/bench_configs.json
