@@ -148,6 +148,9 @@ struct Corner { float v[C]; };
 #ifndef SN_BLEND_PKW
 #define SN_BLEND_PKW 1       // packed corner-weight products in the final stage's blends, fp32 tables (same-box: 7.25 -> 7.19 ms; fp16 tables 6.75 -> 6.90, so not there)
 #endif
+#ifndef SN_PROP_GROUP
+#define SN_PROP_GROUP 3      // proposal stage, fp32 tables: levels gathered in groups of 3 + 2 (all 5 at once spills at 128 VGPRs): [128,64,32] 4.70 -> 4.55 ms same-box; fp16 tables fit and lose 2 % with the split
+#endif
 #ifndef SN_XSWAP_DENSE
 #define SN_XSWAP_DENSE 0
 #endif
@@ -314,23 +317,24 @@ __device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corne
 template <typename T, int L, int C, int GROUP, int K, bool PAIR, typename Emit>
 __device__ __forceinline__ bool encode_grouped(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3], Emit emit,
                                                const PairTab *pt = nullptr) {
-    static_assert(L % GROUP == 0 || GROUP >= L, "GROUP must divide L");
+    // (a last, shorter group is allowed: L = 5 levels in groups of 3 + 2)
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < 3; ++d) oob |= (x01[d] < 0.0f || x01[d] > 1.0f);
     constexpr int G = GROUP >= L ? L : GROUP;
-    static_for<0, L / G>([&](auto grp) {
+    static_for<0, (L + G - 1) / G>([&](auto grp) {
         constexpr int l0 = decltype(grp)::value * G;
-        float pos[G][3];
-        Corner<T, C> cv[G][8];
-        static_for<0, G>([&](auto kk) {
+        constexpr int GN = (L - l0) < G ? (L - l0) : G;        // levels in this group
+        float pos[GN][3];
+        Corner<T, C> cv[GN][8];
+        static_for<0, GN>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int KIND = K < 0 ? -1 : ((l0 + k) < K ? 0 : 1);
             issue_level<T, C, KIND, (PAIR && K > 0 && K <= 8 && SN_PAIR_ALIGNED)>(table, g, l0 + k, x01, pos[k], cv[k], pt);
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
+        for (int k = 0; k < GN; ++k) {
             float acc[C];
             blend_level<T, C>(pos[k], cv[k], acc);
             emit(l0 + k, acc);
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
         float feat[L * C];
-        encode_levels<TT, L, C, K, true>(table, a.g, x01, feat, &a.pairs);
+        encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : L)>(table, a.g, x01, feat, &a.pairs);
         float h[HID], raw[1];
         const uint32_t oz = opaque_zero();
         dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
