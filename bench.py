@@ -2,115 +2,188 @@
 """Headline benchmark: rays/s of the full forward render (BASELINE.json `metric`).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): 800x800 rays per GPU, hash grid L=16 T=2^19 F=2, 2x64
-sigma/colour MLP, synthetic camera + random-init (hash-generated) weights, rays resident in HBM.
-  --schedule flat128 (default): num_steps=[128]  = "128 samples/ray through the L=16 grid", configs[1] literally
-  --schedule ref              : num_steps=[128,64,32] with both proposal grids = the reference's own default
-One "step" = one whole-image render: sn_rm_render_rays over this rank's row band (+ at N>1 the
-RCCL all-gather that assembles the image on every rank; the gather of frame k overlaps the render of
-frame k+1, all of them complete inside the timed region).  Weak scaling: the image grows to
-800 x (800*N) rows, each rank renders an 800-row band.
+`--gpus N` is honoured either way: under `torch.distributed.run` (WORLD_SIZE set; must equal N) or
+stand-alone, in which case this script re-launches itself as N ranks (one per GPU, RCCL) and fails
+if fewer than N devices are visible.
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — dominant kernel (final stage) timed with HIP events inside the timed region,
-                 algorithmic gather bytes per ray / measured time vs 8 TB/s
-  cpu_baseline — the CPU oracle (a port, oracle/) on a bounded sample of the same rays, N=1 only
+Workload, random-init (hash-generated) weights, synthetic orbit camera, rays resident in HBM:
+  N = 1 (default)  BASELINE configs[1]: 800x800 rays, hashgrid L=16 T=2^19 F=2, 32-64-64-16 + 31-32-32-3 MLPs,
+                   --schedule flat128 = num_steps [128] (the literal "128 samples/ray through the L=16 grid"),
+                   --schedule ref     = [128,64,32] with both proposal grids (the reference's default).
+  N > 1 (default)  BASELINE configs[3], STRONG scaling: one fixed 1600x1600 image, contiguous row bands
+                   (dist.shard_rows), ONE RCCL all-gather of rgb|depth|weights_sum per frame; value = 2.56e6 rays
+                   / step time.  The same image rendered by one GPU is measured in the same run
+                   (`single_gpu_same_image`), which is the base of the speed-up.  `--scaling weak` keeps the
+                   round-1 behaviour (an 800 x 800*N image).  `--scaling strong --gpus 1` renders config 4 on one GPU.
+One "step" = one whole-image render of this rank's band (+ at N>1 the all-gather; the gather of frame k
+overlaps the render of frame k+1, everything in flight is drained inside the timed region).
+
+Prints ONE JSON line (rank 0): the contract fields plus
+  roofline     — dominant kernel (final stage), HIP-event time measured inside the timed region, against the
+                 ceilings that bind: the gather address rate of the texture addressers at the
+                 shader clock measured in the kernel, the fabric-side traffic from the committed PMC passes;
+                 the SURVEY 8(d) algorithmic figure is kept, labelled as cache-absorbed
+  cpu_baseline — the CPU oracle (a port, oracle/) on a bounded sample of the same rays, N = 1 only
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table
-MFMA_F32_PEAK = 157.3e12   # FLOP/s dense f32-input MFMA
-
-
-def algorithmic_bytes_per_ray(steps, s_bytes):
-    """SURVEY.md §8d: sum_stages T_k * L_k * 2^D * F_k * s + 24 (o,d in) + 20 (rgb, depth, wsum out)."""
-    L = [5] * (len(steps) - 1) + [16]
-    return sum(t * l * 8 * 2 * s_bytes for t, l in zip(steps, L)) + 44
+HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md chip table
+PEAK_CLOCK_HZ = 2.4e9        # ibid.
+N_CU = 256
+GATHER_CYCLES_PER_CU = 17.5  # one wave-wide <=16-byte gather instruction per 17.5 cycles per CU (4 lanes/clk address rate);
+                             # measured: tools/ubench/gathers.hip -> profiles/r01/ubench_gathers.txt
 
 
-def flops_per_ray(steps):
-    macs = sum(t * 176 for t in steps[:-1]) + steps[-1] * 7168 + 2112
-    return 2 * macs
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--schedule", choices=["flat128", "ref"], default="flat128")
-    ap.add_argument("--hw", type=int, default=800)
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="auto: N=1 -> configs[1] (800x800); N>1 -> strong scaling on the fixed 1600x1600 image of configs[3]")
+    ap.add_argument("--hw", type=int, default=0, help="image side (default 800; 1600 for strong scaling)")
     ap.add_argument("--tables", choices=["f32", "f16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="world size 1 only: still go through RCCL (init, all-gather pipeline, barriers)")
     ap.add_argument("--primary-only", action="store_true", help="skip the extra configurations reported under `also`")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run (one per GPU)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} requested but only {ndev} device(s) are visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def algorithmic_bytes_per_ray(steps, s_bytes):
+    """SURVEY.md 8(d): sum_stages T_k * L_k * 2^D * F_k * s + 24 (o,d in) + 20 (rgb, depth, wsum out)."""
+    L = [5] * (len(steps) - 1) + [16]
+    return sum(t * l * 8 * 2 * s_bytes for t, l in zip(steps, L)) + 44
+
+
+def flops_per_ray(steps):
+    return 2 * (sum(t * 176 for t in steps[:-1]) + steps[-1] * 7168 + 2112)
+
+
+def gather_instructions_per_wave_sample(tables):
+    """Final stage (render.hip): 5 dense levels as aligned pair rows (fp32: 4 loads) / quad rows (fp16: 2 loads),
+    11 hashed levels x 8 corners."""
+    return 5 * (4 if tables == "f32" else 2) + 11 * 8
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources: ties a committed PMC profile to the code it was taken from (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "sanerf-hq_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     force_dist = args.force_dist and world == 1      # exercise the RCCL code path on a one-GPU box
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-    if world > 1 or force_dist:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
     multi = world > 1 or force_dist
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    rccl_ranks = None
+    if multi:
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                        # every rank really joined the RCCL communicator
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world:
+            sys.exit(f"bench.py: {rccl_ranks} ranks joined the communicator, expected {world}")
 
-    from helpers import product_model, synthetic_params
     from sanerf_hq_amd import _lib, raymarching as rm, synth
-    from sanerf_hq_amd.dist import PipelinedGather, shard_rows
+    from sanerf_hq_amd.dist import PipelinedGather, band_align, shard_rows
 
-    W = args.hw
-    H = args.hw * world                      # weak scaling: one hw x hw band per rank
-    b, e = shard_rows(H, world, rank)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "single")
+    hw = args.hw or (1600 if scaling == "strong" else 800)
+    W = hw
+    H = hw * world if scaling == "weak" else hw
+    align = band_align(H, world)
+    b, e = shard_rows(H, world, rank, align)
     pose = synth.orbit_pose(1.0, 20.0, 30.0)
-    intr = synth.pinhole_intrinsics(args.hw, W)   # same focal length at every N
-    rays_o, rays_d = rm.generate_rays(pose, (intr[0], intr[1], W / 2.0, H / 2.0), H, W, device=dev, row_begin=b, row_end=e)
-    n_local = rays_o.shape[0]
+    fx, fy, _, _ = synth.pinhole_intrinsics(hw, W)   # same focal length at every N
+    intr = (fx, fy, W / 2.0, H / 2.0)
     lib = _lib.lib()
     total_rays = H * W
     models = {}
 
-    def measure(schedule, tables, n_steps, n_warm, rays=None):
-        """K timed whole-image renders (+ all-gather at N>1) of one configuration; returns the bench numbers.
-        rays = (rays_o, rays_d, width): another image than the bench line's (N = 1 only)."""
-        r_o, r_d, r_w = rays if rays is not None else (rays_o, rays_d, W)
-        n_total = r_o.shape[0] if rays is not None else total_rays
+    # ---- ray generation (a1; SURVEY 8(d): reported as its own term, not inside `value`) ----
+    rays_o, rays_d = rm.generate_rays(pose, intr, H, W, device=dev, row_begin=b, row_end=e)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(10):
+        rm.generate_rays(pose, intr, H, W, device=dev, row_begin=b, row_end=e)
+    ev[1].record()
+    torch.cuda.synchronize()
+    raygen_ms = ev[0].elapsed_time(ev[1]) / 10
+    n_local = rays_o.shape[0]
+
+    def measure(schedule, tables, n_steps, n_warm, rays=None, gather=multi):
+        """K timed whole-image renders (+ all-gather when `gather`) of one configuration.
+        rays = (rays_o, rays_d, width, n_total): another image than the bench line's (no gather)."""
+        r_o, r_d, r_w, n_total = rays if rays is not None else (rays_o, rays_d, W, total_rays)
         steps = [128] if schedule == "flat128" else [128, 64, 32]
         if schedule not in models:
-            params = synthetic_params(steps, seed=0)
-            models[schedule] = (params, product_model(params, steps, False, dev))
+            params = synth.synthetic_params(steps, seed=0)
+            models[schedule] = (params, synth.product_model(params, steps, False, dev))
         params, model = models[schedule]
         plan = rm.RenderPlan(model, steps, torch.float16 if tables == "f16" else torch.float32)
         out = {}
         # N > 1: the all-gather of frame k (RCCL, its own stream, over xGMI) overlaps the render of frame k+1; two
         # rotating image buffers, everything in flight is drained inside the timed region
-        pipe = PipelinedGather(H, W, 5, dev, depth=2) if multi else None
+        pipe = PipelinedGather(H, W, 5, dev, depth=2, align=align) if gather else None
 
         def step():
             rm.render_rays(plan, r_o, r_d, tile_w=r_w, out=out)
-            if multi:
+            if pipe is not None:
                 band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
                 pipe.submit(band)
 
@@ -119,93 +192,127 @@ def main():
         if pipe is not None:
             pipe.drain()
         torch.cuda.synchronize()
-        if multi:
+        if gather and multi:
             dist.barrier()
         lib.sn_rm_profile_enable(1)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n_steps):
+        marks[0].record()
+        for i in range(n_steps):
             step()
+            marks[i + 1].record()
         if pipe is not None:
             pipe.drain()
         torch.cuda.synchronize()
-        if multi:
+        if gather and multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         ms = (C.c_float * 8)()
         cnt = (C.c_int32 * 8)()
         _lib.check(lib.sn_rm_profile_read(ms, cnt, 8), "profile_read")
+        mhz, probe_ms = C.c_float(0), C.c_float(0)
+        _lib.check(lib.sn_rm_profile_shader_clock(C.byref(mhz), C.byref(probe_ms)), "profile_shader_clock")
         lib.sn_rm_profile_enable(0)
-        if multi:
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps))
+        if gather and multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        s_bytes = 2 if tables == "f16" else 4
-        per = lambda i: (ms[i] / cnt[i]) if cnt[i] else None
+        per = lambda i: (ms[i] / cnt[i]) if cnt[i] else None     # noqa: E731
         return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=n_total / (elapsed / n_steps),
-                    ms_per_step=elapsed / n_steps * 1e3, s_bytes=s_bytes, final_ms=per(4), final_launches=int(cnt[4]),
-                    pack_ms=per(0), prop_ms=[per(1), per(2)])
+                    ms_per_step=elapsed / n_steps * 1e3, median_ms=per_step[len(per_step) // 2], tables=tables,
+                    s_bytes=2 if tables == "f16" else 4, final_ms=per(4), final_launches=int(cnt[4]), pack_ms=per(0),
+                    prop_ms=[per(1), per(2)], shader_mhz=float(mhz.value), probe_ms=float(probe_ms.value),
+                    image=pipe.drain() if pipe is not None else None)
 
     m = measure(args.schedule, args.tables, args.steps, args.warmup)
     steps, params, out = m["steps"], m["params"], m["out"]
     value, ms_per_step, s_bytes, final_ms = m["value"], m["ms_per_step"], m["s_bytes"], m["final_ms"]
 
+    # ---- N > 1: the gathered image must be the single-process image; and the same image on ONE GPU for the ratio ----
+    single = gathered_check = None
+    if world > 1:
+        ro_f, rd_f = rm.generate_rays(pose, intr, H, W, device=dev)
+        if rank == 0:
+            r1 = measure(args.schedule, args.tables, max(3, args.steps // 4), 1, rays=(ro_f, rd_f, W, total_rays), gather=False)
+            single = {"rays_per_s": round(r1["value"], 1), "ms_per_step": round(r1["ms_per_step"], 4),
+                      "note": "rank 0 alone renders the whole image right after the timed region (other ranks idle at a barrier)"}
+            full = torch.cat([r1["out"]["image"], r1["out"]["depth"].unsqueeze(-1), r1["out"]["weights_sum"].unsqueeze(-1)], dim=-1)
+            gathered_check = {"max_abs_diff_vs_single_gpu_image": float((m["image"] - full).abs().max().item()),
+                              "rows_per_rank": [list(shard_rows(H, world, r, align)) for r in range(world)]}
+        dist.barrier()
+        del ro_f, rd_f
+
     # ---- roofline of the dominant kernel (final stage) on this rank ----
+    gpw = gather_instructions_per_wave_sample(args.tables)
+    waves = -(-n_local // 64)
+    gather_instr = waves * steps[-1] * gpw
+    clock_hz = m["shader_mhz"] * 1e6 if m["shader_mhz"] > 0 else None
+    floor_ms = lambda hz: gather_instr * GATHER_CYCLES_PER_CU / N_CU / hz * 1e3      # noqa: E731
+    ta_floor = floor_ms(clock_hz) if clock_hz else None
     bytes_final = n_local * (steps[-1] * 16 * 8 * 2 * s_bytes + 44)
     flops_final = n_local * 2 * (steps[-1] * 7168 + 2112)
-    achieved = bytes_final / (final_ms * 1e-3)
-    # HBM-side bytes per launch of the same kernel: from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/latest_traffic.json, regenerated with tools/gpu_pmc_quick.sh); null when no profile matches.
+    # fabric-side bytes per launch of the same kernel: committed rocprofv3 --pmc passes of this same command
+    # (profiles/latest_traffic.json, tools/gpu_profile_all.sh); used only when taken from these very kernel sources
     traffic = traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    fp = source_fingerprint()
     if os.path.exists(tpath):
         tj = json.load(open(tpath)).get(f"{args.schedule}_{args.tables}")
-        if tj and tj.get("rays") == n_local:
+        if tj and tj.get("rays") == n_local and tj.get("source_fingerprint") == fp:
             traffic, traffic_detail = tj["hbm_bytes_per_launch"], tj
     roofline = {
-        "kernel": "k_final_stage", "bound": "hbm",
-        "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_detail": traffic_detail,
+        "kernel": "k_final_stage", "bound": "ta_address_rate",
+        "achieved": round(gather_instr / (final_ms * 1e-3) / 1e9, 3), "unit": "G wave-gathers/s",
+        "peak": round(N_CU * clock_hz / GATHER_CYCLES_PER_CU / 1e9, 3) if clock_hz else None,
+        "frac": round(ta_floor / final_ms, 4) if ta_floor else None,
         "avg_kernel_ms": round(final_ms, 4), "launches": m["final_launches"],
-        "algorithmic_bytes_per_launch": int(bytes_final),
-        "note": "achieved = algorithmic gather bytes (SURVEY 8d: every corner fetch counted once, no cache credit) / HIP-event kernel time; "
-                "it can exceed the HBM peak because L1/L2 absorb the re-reads of neighbouring rays (see traffic)",
+        "floor_ms": round(ta_floor, 4) if ta_floor else None,
+        "floor_ms_at_peak_clock": round(floor_ms(PEAK_CLOCK_HZ), 4),
+        "shader_clock_mhz": round(m["shader_mhz"], 1), "clock_probe_ms": round(m["probe_ms"], 3),
+        "wave_gather_instructions_per_launch": int(gather_instr),
+        "note": f"texture-addresser ceiling: every wave-wide gather (<=16 B/lane) occupies a CU's address path for {GATHER_CYCLES_PER_CU} cycles "
+                f"(tools/ubench/gathers.hip); {gpw} gather instructions per wave-sample; priced at the shader clock measured inside the kernel "
+                "(s_memtime / s_memrealtime over workgroup 0's lifetime)",
+        "traffic": traffic,
+        "fabric": ({"bytes_per_launch": traffic, "achieved_GBps": round(traffic / (final_ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK / 1e9,
+                    "frac": round(traffic / (final_ms * 1e-3) / HBM_PEAK, 4), "detail": traffic_detail} if traffic else
+                   {"bytes_per_launch": None, "note": f"no PMC profile of these kernel sources (fingerprint {fp}) in profiles/latest_traffic.json"}),
+        "algorithmic": {"bytes_per_launch": int(bytes_final), "GBps": round(bytes_final / (final_ms * 1e-3) / 1e9, 1),
+                        "algorithmic_frac": round(bytes_final / (final_ms * 1e-3) / HBM_PEAK, 4),
+                        "note": "SURVEY 8(d) figure: every corner fetch counted once, no cache credit. Cache-absorbed (L1/L2/Infinity Cache serve "
+                                "neighbouring rays), NOT a bound: it can exceed 1"},
         "mlp_on_matrix_cores": {"achieved_tflops": round(flops_final / (final_ms * 1e-3) / 1e12, 2),
                                 "note": "algorithmic fp32-equivalent MLP FLOPs; executed as 3 fp16 MFMA products per fp32 product"},
-        "gather_address_rate": {   # the ceiling that binds after the caches (tools/ubench/gathers.hip)
-            "wave_instructions_per_launch": int(-(-n_local // 64) * steps[-1] * (5 * 4 + 11 * 8)),
-            "cycles_per_instruction_per_cu": 17.5,
-            "floor_ms": round(-(-n_local // 64) * steps[-1] * (5 * 4 + 11 * 8) * 17.5 / 256 / 2.4e9 * 1e3, 3),
-            "note": "one wave-wide gather per 17.5 cycles per CU (4 lanes/clk address rate, measured); 5 dense levels x 4 paired loads + 11 hashed levels x 8; "
-                    "priced at the 2.4 GHz peak clock -- under this kernel the shader clock is ~1.97 GHz (GRBM_GUI_ACTIVE, profiles/r01/pmc_flat128.txt), i.e. floor x 1.22"},
         "other_kernels_ms": {"pack": round(m["pack_ms"], 4) if m["pack_ms"] else None,
                              "prop0": round(m["prop_ms"][0], 4) if m["prop_ms"][0] else None,
-                             "prop1": round(m["prop_ms"][1], 4) if m["prop_ms"][1] else None},
-        "whole_path": {"algorithmic_bytes_per_ray": algorithmic_bytes_per_ray(steps, s_bytes),
-                       "achieved_GBps": round(value / world * algorithmic_bytes_per_ray(steps, s_bytes) / 1e9, 2),
-                       "frac": round(value / world * algorithmic_bytes_per_ray(steps, s_bytes) / HBM_PEAK, 4),
-                       "flops_per_ray": flops_per_ray(steps)},
+                             "prop1": round(m["prop_ms"][1], 4) if m["prop_ms"][1] else None,
+                             "generate_rays": round(raygen_ms, 4)},
+        "whole_path": {"algorithmic_bytes_per_ray": algorithmic_bytes_per_ray(steps, s_bytes), "flops_per_ray": flops_per_ray(steps),
+                       "rays_per_s_incl_ray_generation": round(total_rays / ((ms_per_step + raygen_ms) * 1e-3), 1)},
+        "source_fingerprint": fp,
     }
 
     # ---- other configurations of the same path, measured in the same process (N = 1 only, short) ----
     also = None
-    if world == 1 and not args.primary_only:
+    if world == 1 and not multi and not args.primary_only and scaling == "single":
         also = {}
-        for sch, tb in (("ref", "f32"), ("flat128", "f16"), ("ref", "f16")):
+        for sch, tb in (("flat128", "f32"), ("ref", "f32"), ("flat128", "f16"), ("ref", "f16")):
             if (sch, tb) == (args.schedule, args.tables):
                 continue
             r = measure(sch, tb, max(3, args.steps // 2), 2)
             also[f"{sch}_{tb}"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
-                                   "num_steps": r["steps"], "tables": tb,
+                                   "median_ms_per_step": round(r["median_ms"], 4), "num_steps": r["steps"], "tables": tb,
                                    "kernel_ms": {"final": round(r["final_ms"], 4),
                                                  "prop0": round(r["prop_ms"][0], 4) if r["prop_ms"][0] else None,
                                                  "prop1": round(r["prop_ms"][1], 4) if r["prop_ms"][1] else None}}
-        # BASELINE configs C4 at one GPU: 1600 x 1600 rays of the same view (same field of view: rays twice as dense, so
-        # neighbouring lanes share more table lines -- higher rays/s than the 800 x 800 bench line)
+        # BASELINE configs[3] at one GPU = the base of the N > 1 strong-scaling lines: 1600 x 1600 rays of the same view
+        # (same field of view: rays twice as dense, neighbouring lanes share more table lines -> higher rays/s)
         H4 = 1600
         ro4, rd4 = rm.generate_rays(pose, synth.pinhole_intrinsics(H4, H4), H4, H4, device=dev)
         for sch in ("flat128", "ref"):
-            r = measure(sch, "f32", 3, 1, rays=(ro4, rd4, H4))
+            r = measure(sch, "f32", 3, 1, rays=(ro4, rd4, H4, H4 * H4))
             also[f"c4_1600x1600_{sch}_f32"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
                                                "num_steps": r["steps"], "tables": "f32", "rays": H4 * H4}
         del ro4, rd4
@@ -214,6 +321,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle as orc
         from helpers import oracle_cfg
         cfg = oracle_cfg(orc, params, steps, table_f16=(args.tables == "f16"))
@@ -237,19 +345,27 @@ def main():
                         "max_abs_rgb_diff_vs_gpu": err}
 
     if rank == 0:
+        cfg_name = {"single": "BASELINE configs[1]", "strong": "BASELINE configs[3]", "weak": "BASELINE configs[1] per GPU"}[scaling]
         line = {
             "metric": "rays/s full render (800x800, hashgrid L=16 + 2x64 MLP)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 tables, positions, interpolation, compositing; the 32-64-64-16 MLP multiplies fp16 hi/lo splits of fp32 operands on the matrix cores with fp32 accumulation (2^-22 per product, RGB within 1e-5 of the fp32 oracle)",
-            "config": {"workload": f"BASELINE configs[1]: {W}x{args.hw} rays per GPU ({W}x{H} image), hashgrid L=16 T=2^19 F=2, "
+            "median_ms_per_step": round(m["median_ms"], 4),
+            "higher_is_better": True, "scaling": "weak" if scaling == "weak" else "strong", "vs_baseline": None,
+            "dtype": args.tables, "data": "synthetic",
+            "dtype_note": f"{args.tables} hash tables; positions, interpolation, compositing in fp32; the 32-64-64-16 MLP multiplies fp16 hi/lo "
+                          "splits of fp32 operands on the matrix cores with fp32 accumulation (2^-22 per product, RGB within 1e-5 of the fp32 oracle)",
+            "rccl_ranks": rccl_ranks,
+            "config": {"workload": f"{cfg_name}: {W}x{H} image, {n_local} rays on this GPU, hashgrid L=16 T=2^19 F=2, "
                                    f"32-64-64-16 + 31-32-32-3 MLPs, num_steps={steps} ({args.schedule}), tables {args.tables}, "
                                    "arithmetic fp32, random-init weights, orbit camera",
                        "rays_per_gpu": n_local, "image": [H, W], "schedule": args.schedule,
-                       "parallelism": f"ray-tile row bands x{world}" + (" + RCCL all-gather of rgb|depth|wsum" if world > 1 else "")},
+                       "parallelism": f"ray-tile row bands x{world}" + (" + one RCCL all-gather of rgb|depth|wsum per frame" if multi else "")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "also": also,
         }
+        if single is not None:
+            line["single_gpu_same_image"] = single
+            line["speedup_vs_single_gpu_same_image"] = round(value / single["rays_per_s"], 3)
+            line["gathered_image_check"] = gathered_check
         print(json.dumps(line))
     if multi:
         dist.destroy_process_group()

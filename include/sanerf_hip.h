@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 3
+#define SN_ABI_VERSION 4
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -278,6 +278,10 @@ int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uin
  * synchronises, returns summed device milliseconds and launch counts per class, and resets. */
 void sn_rm_profile_enable(int on);
 int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_classes);
+/* Shader clock the last profiled final-stage launch ran at, MHz: workgroup 0 reads s_memtime (shader cycles) and
+ * s_memrealtime (constant wall-clock rate) at entry and exit; shader_mhz = their ratio x the wall-clock rate.  probe_ms
+ * (optional) = the wall time the probe spanned.  0 when no final stage ran since sn_rm_profile_enable(1).  Synchronises. */
+int sn_rm_profile_shader_clock(float *shader_mhz, float *probe_ms);
 /* Diagnostics: occupancy-API workgroups/CU of the fused kernels (prop, final f16x3, final f32-MFMA) and their dynamic LDS bytes. */
 int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n);
 

@@ -55,7 +55,7 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 3   # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 4   # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),
@@ -92,6 +92,7 @@ _SIGNATURES = {
     "sn_rm_render_rays": (_int, [C.POINTER(RenderCfg), C.POINTER(RenderIO), _vp]),
     "sn_rm_profile_enable": (None, [_int]),
     "sn_rm_profile_read": (_int, [_vp, _vp, _int]),
+    "sn_rm_profile_shader_clock": (_int, [_vp, _vp]),
     "sn_rm_debug_occupancy": (_int, [_vp, _vp, _int]),
 }
 

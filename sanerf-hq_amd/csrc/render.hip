@@ -788,6 +788,19 @@ struct FinalArgs {
     PairTab pairs;               // dense levels of the main grid as aligned x-pairs (K > 0 instantiations)
 };
 
+// shader-clock probe of the measurement hook: s_memtime ticks at the shader clock, s_memrealtime at the constant
+// wall-clock rate (hipDeviceAttributeWallClockRate); their ratio over one workgroup's lifetime is the clock the
+// kernel actually ran at (DVFS: well below the 2.4 GHz peak under this kernel), which prices the cycle-count ceilings
+// (device globals rather than a kernel argument: the final stage has no scalar registers to spare)
+__device__ int g_clk_on = 0;
+__device__ unsigned long long g_clk_buf[4];
+__device__ __forceinline__ void clock_probe(int slot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g_clk_on) {
+        g_clk_buf[2 * slot] = __builtin_readcyclecounter();
+        g_clk_buf[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // A-operand packing for the 32->64->64->16 MLP on v_mfma_f32_32x32x2_f32.
 //   D[m][j] += sum_k A[m][k] * B[k][j],  A = weights (m = output neuron), B = activations
 //   (j = sample).  Lane l supplies A[m = l&31][k = l>>5] and B[k = l>>5][j = l&31]; the
@@ -1118,6 +1131,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
     }
     __syncthreads();
+    clock_probe(0);
 
     uint32_t n;
     const uint32_t wg = tile_id(a.rc);
@@ -1259,6 +1273,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         }
     }
 
+    clock_probe(1);
     // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
     static_assert(VH <= IN && NCOL <= IN && IN * 64 <= 2 * 64 * SLAB_STRIDE, "view MLP activations reuse the feature column / slab");
     if constexpr (MFMA) {
@@ -1719,10 +1734,33 @@ extern "C" {
 
 void sn_rm_profile_enable(int on) {
     g_prof_on = on != 0;
+    {   // arm / disarm the final stage's clock probe (see clock_probe)
+        const int flag = g_prof_on ? 1 : 0;
+        const unsigned long long zero[4] = {0, 0, 0, 0};
+        if (g_prof_on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clk_buf), zero, sizeof(zero));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clk_on), &flag, sizeof(flag));
+    }
     if (!g_prof_on) {
         for (auto &sp : g_prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         g_prof.clear();
     }
+}
+
+int sn_rm_profile_shader_clock(float *shader_mhz, float *probe_ms) {
+    SN_REQUIRE(shader_mhz, "profile_shader_clock: NULL output");
+    *shader_mhz = 0.0f;
+    if (probe_ms) *probe_ms = 0.0f;
+    unsigned long long h[4];
+    SN_HIP_OK(hipDeviceSynchronize());
+    SN_HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_buf), sizeof(h)));
+    int dev = 0, wall_khz = 0;
+    SN_HIP_OK(hipGetDevice(&dev));
+    SN_HIP_OK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev));
+    if (h[3] <= h[1] || h[2] <= h[0] || wall_khz <= 0) return SN_OK;       // no final-stage launch since enable
+    const double wall_s = (double)(h[3] - h[1]) / ((double)wall_khz * 1e3);
+    *shader_mhz = (float)((double)(h[2] - h[0]) / wall_s / 1e6);
+    if (probe_ms) *probe_ms = (float)(wall_s * 1e3);
+    return SN_OK;
 }
 
 int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_classes) {

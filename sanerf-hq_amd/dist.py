@@ -31,6 +31,17 @@ def shard_rows(H: int, world_size: int, rank: int, align: int = TILE_ROWS) -> Tu
     return min(t0 * align, H), min(t1 * align, H)
 
 
+def band_align(H: int, world_size: int) -> int:
+    """Row alignment of the bands of an H-row image: whole 16-row workgroup tiles when that gives every rank the same
+    number of rows, else whole 8-row wave tiles (1600 rows on 8 GPUs: 200 rows each -- the last workgroup row of a band
+    is then half idle, but every rank launches the same grid and the all-gather needs no padding), else 16 (unequal
+    bands, padded gather)."""
+    for a in (TILE_ROWS, 8):
+        if H % (a * world_size) == 0:
+            return a
+    return TILE_ROWS
+
+
 def all_shards(H: int, world_size: int, align: int = TILE_ROWS) -> List[Tuple[int, int]]:
     return [shard_rows(H, world_size, r, align) for r in range(world_size)]
 
@@ -66,22 +77,30 @@ def render_image_sharded(render_rows: Callable[[int, int], torch.Tensor], H: int
     Returns the full [H*W, K] image on every rank (or the local band if gather=False)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    b, e = shard_rows(H, world, rank)
+    align = band_align(H, world)
+    b, e = shard_rows(H, world, rank, align)
     local = render_rows(b, e) if e > b else None
     if local is None:
         raise RuntimeError(f"rank {rank} received an empty band: image height {H} has fewer than {world} row tiles")
-    return gather_image(local, H, W, group) if gather else local
+    return gather_image(local, H, W, group, align) if gather else local
 
 
 def render_model_sharded(model, pose, intrinsics, H: int, W: int, group: Optional[dist.ProcessGroup] = None,
-                         gather: bool = True) -> torch.Tensor:
-    """Whole-image render of a NeRFNetwork replica: [H*W, 5] = rgb | depth | weights_sum."""
-    from .raymarching import generate_rays
+                         gather: bool = True, ray_fn: Optional[Callable] = None) -> torch.Tensor:
+    """Whole-image render of a NeRFNetwork replica: [H*W, 5] = rgb | depth | weights_sum on every rank.
+    Each rank generates the rays of its own band on its own device (nothing but the final image crosses xGMI).
+    ray_fn(pose, intrinsics, H, W, device, row_begin, row_end) -> (rays_o, rays_d): defaults to the HIP
+    generate_rays; the gloo tests pass a CPU twin."""
+    if ray_fn is None:
+        from .raymarching import generate_rays
+
+        def ray_fn(pose, intrinsics, H, W, device, row_begin, row_end):
+            return generate_rays(pose, intrinsics, H, W, device=device, row_begin=row_begin, row_end=row_end)
 
     device = next(model.parameters()).device
 
     def rows(b, e):
-        rays_o, rays_d = generate_rays(pose, intrinsics, H, W, device=device, row_begin=b, row_end=e)
+        rays_o, rays_d = ray_fn(pose, intrinsics, H, W, device, b, e)
         out = model.render(rays_o, rays_d, staged=False, perturb=False, tile_w=W)
         return torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
 
@@ -98,13 +117,13 @@ class PipelinedGather:
     (H a multiple of 16*world); otherwise use `gather_image`."""
 
     def __init__(self, H: int, W: int, K: int, device, depth: int = 2, group: Optional[dist.ProcessGroup] = None,
-                 dtype=torch.float32):
+                 dtype=torch.float32, align: Optional[int] = None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
-        bands = all_shards(H, self.world)
+        bands = all_shards(H, self.world, band_align(H, self.world) if align is None else align)
         rows = bands[0][1] - bands[0][0]
         if any(e - b != rows for b, e in bands):
-            raise ValueError(f"PipelinedGather needs equal bands: image height {H} is not a multiple of {TILE_ROWS * self.world}")
+            raise ValueError(f"PipelinedGather needs equal bands: image height {H} is not a multiple of 8 * {self.world}")
         self.local_numel = rows * W
         self.images = [torch.empty(H * W, K, device=device, dtype=dtype) for _ in range(depth)]
         self.works = [None] * depth

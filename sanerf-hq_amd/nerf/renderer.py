@@ -84,6 +84,8 @@ class NeRFRenderer(nn.Module):
         self._plan = None
         self._plan_key = None
         self.render_table_dtype = torch.float32             # torch.float16: render from half-precision table copies
+        self.render_tables_static = False                   # True: skip the per-call refresh of those copies (frozen field)
+        self.unstaged_cam_near_far = False                  # True: honour cam_near_far when staged=False (the reference ignores it)
 
     def forward(self, x, d, **kwargs):
         raise NotImplementedError()
@@ -102,7 +104,11 @@ class NeRFRenderer(nn.Module):
     # ---------------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, staged=False, cam_near_far=None, **kwargs):
         if not staged:
-            return self.run(rays_o, rays_d, cam_near_far=cam_near_far, **kwargs)
+            # the reference drops cam_near_far here (renderer.py:187-188: `self.run(rays_o, rays_d, **kwargs)`), so every
+            # un-staged call -- all of its training steps -- marches the full aabb interval; same here unless opted in
+            if getattr(self, "unstaged_cam_near_far", False):
+                return self.run(rays_o, rays_d, cam_near_far=cam_near_far, **kwargs)
+            return self.run(rays_o, rays_d, **kwargs)
         # staged inference (renderer.py:185-219): chunks of max_ray_batch, results scattered into place
         N = rays_o.shape[0]
         results: Dict[str, torch.Tensor] = {}
@@ -133,17 +139,41 @@ class NeRFRenderer(nn.Module):
             return False
         return any(p.requires_grad for p in self._core_parameters())
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        # a checkpoint load rewrites tables / aabb in place (same data_ptr): never reuse a plan across it
+        self._plan = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def invalidate_render_plan(self):
+        """Drop the cached fused-render plan (call after writing parameters through `.data`, e.g. an EMA copy_to)."""
+        self._plan = None
+
+    def _plan_tensors(self, with_feat: bool):
+        encs = [self.grid] + list(self.prop_encoders) + ([self.s_grid] if with_feat else [])
+        mlps = [self.grid_mlp, self.view_mlp] + list(self.prop_mlp)
+        return [e.embeddings for e in encs] + [lin.weight for m in mlps for lin in m.net]
+
     def _get_plan(self, with_feat: bool = False):
-        key = (self.grid.embeddings.data_ptr(), self.grid.embeddings.device, tuple(self.opt.num_steps),
-               self.render_table_dtype, self.training, self.s_grid.embeddings.data_ptr() if with_feat else None)
+        """The cached RenderPlan.  The plan holds device pointers into the module's own fp32 tensors (in-place updates
+        by an optimiser step / load_state_dict are seen as they are), so it is rebuilt only when a tensor moved
+        (data_ptr / device / dtype) or the schedule changed.  What the plan COPIES is refreshed on every call: the aabb
+        (host values, memoised on the buffer's version counter) and, with render_table_dtype=float16, the
+        half-precision table copies (one conversion pass per render, ~20 us for the main grid; writes through `.data`
+        do not bump version counters, so nothing cheaper is safe -- set `render_tables_static = True` for a frozen
+        field to skip it)."""
+        tensors = self._plan_tensors(with_feat)
+        key = (tuple((t.data_ptr(), t.dtype, t.device) for t in tensors), tuple(self.opt.num_steps), self.render_table_dtype,
+               with_feat, float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0))
         if self._plan is None or self._plan_key != key:
             self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype,
                                        feat_encoder=self.s_grid if with_feat else None,
                                        early_stop_eps=float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0))
-            ab = (self.aabb_train if self.training else self.aabb_infer).detach().cpu().tolist()
-            for i in range(6):
-                self._plan.cfg.aabb[i] = ab[i]
             self._plan_key = key
+        elif not getattr(self, "render_tables_static", False):
+            self._plan.refresh_tables()
+        ab = rm._host_values(self.aabb_train if self.training else self.aabb_infer)
+        for i in range(6):
+            self._plan.cfg.aabb[i] = ab[i]
         return self._plan
 
     def _sam_fusable(self) -> bool:

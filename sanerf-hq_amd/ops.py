@@ -145,6 +145,18 @@ class _grid_encode(Function):
 grid_encode = _grid_encode.apply
 
 
+def grid_level_offsets(input_dim: int, num_levels: int, per_level_scale: float, base_resolution: int,
+                       log2_hashmap_size: int) -> np.ndarray:
+    """First row of every level (+ the total), int32 [L+1]: rows per level = min(2^log2T, res^D) rounded up to a
+    multiple of 8 with res = ceil(base * scale^level) in float64 (grid.py:121-136)."""
+    sizes = []
+    for level in range(num_levels):
+        res = int(np.ceil(base_resolution * per_level_scale ** level))
+        rows = min(2 ** log2_hashmap_size, res ** input_dim)
+        sizes.append(int(np.ceil(rows / 8) * 8))
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+
+
 class GridEncoder(nn.Module):
     """Same constructor, attributes and state_dict keys as gridencoder/grid.py:102-204."""
 
@@ -167,14 +179,8 @@ class GridEncoder(nn.Module):
         self.interp_id = _interp_to_id[interpolation]
         self.align_corners = align_corners
 
-        # rows per level: min(2^log2T, res^D) rounded up to a multiple of 8 (grid.py:121-136)
         self.max_params = 2 ** log2_hashmap_size
-        sizes = []
-        for level in range(num_levels):
-            res = int(np.ceil(base_resolution * per_level_scale ** level))
-            rows = min(self.max_params, res ** input_dim)
-            sizes.append(int(np.ceil(rows / 8) * 8))
-        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        starts = grid_level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size)
         self.register_buffer("offsets", torch.from_numpy(starts))
         self.n_params = int(starts[-1]) * level_dim
         self.embeddings = nn.Parameter(torch.empty(int(starts[-1]), level_dim))

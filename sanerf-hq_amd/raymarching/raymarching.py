@@ -378,10 +378,14 @@ class RenderPlan:
         for k, t in enumerate(num_steps):
             cfg.num_steps[k] = int(t)
 
+        self.copies: list = []       # (source parameter, converted copy) pairs: see refresh_tables()
+
         def table_of(enc):
-            t = enc.embeddings.detach()
-            t = t.to(table_dtype) if t.dtype != table_dtype else t
-            t = t.contiguous()
+            src = enc.embeddings.detach()
+            t = src
+            if src.dtype != table_dtype or not src.is_contiguous():
+                t = src.to(table_dtype).contiguous()
+                self.copies.append((enc.embeddings, t))
             self.keep.append(t)
             return t
 
@@ -412,6 +416,13 @@ class RenderPlan:
         self.geo = model.geom_feat_dim
         self.ncol = model.geom_feat_dim + model.view_encoder.output_dim
         self._ws: Optional[torch.Tensor] = None
+
+    @torch.no_grad()
+    def refresh_tables(self) -> None:
+        """Re-convert the table copies (render_table_dtype != the parameters' dtype) from the live parameters, in place:
+        the plan's device pointers stay valid.  A plan over fp32 tables holds no copies and this is a no-op."""
+        for src, copy in self.copies:
+            copy.copy_(src.detach())
 
     def workspace(self, N: int, tile_w: int, device) -> torch.Tensor:
         need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(self.cfg), N, tile_w))

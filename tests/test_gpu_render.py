@@ -128,9 +128,16 @@ def test_model_render_api_and_staging(gpu, orc):
         # oracle agreement on the whole image
         want = orc.render(oracle_cfg(orc, params, [128, 64, 32]), ro, rd)
         np.testing.assert_allclose(full["image"].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
-        # cam_near_far clamps the march (renderer.py:233-235)
+        # cam_near_far clamps the march (renderer.py:233-235) -- on the staged path; the reference's un-staged render()
+        # drops the argument (renderer.py:187-188), and so does this one unless `unstaged_cam_near_far` is set
         cnf = torch.tensor([[0.5, 3.0]], device=gpu)
-        a = model.render(ro_t, rd_t, cam_near_far=cnf)
+        dropped = model.render(ro_t, rd_t, cam_near_far=cnf)
+        assert torch.equal(dropped["image"], full["image"]) and torch.equal(dropped["depth"], full["depth"])
+        a = model.render(ro_t, rd_t, staged=True, cam_near_far=cnf)
+        model.unstaged_cam_near_far = True
+        a2 = model.render(ro_t, rd_t, cam_near_far=cnf)
+        model.unstaged_cam_near_far = False
+        assert torch.equal(a["image"], a2["image"])
         wa = orc.render(oracle_cfg(orc, params, [128, 64, 32]), ro, rd, cam_near_far=np.array([[0.5, 3.0]], np.float32))
         np.testing.assert_allclose(a["image"].cpu().numpy(), wa["image"], rtol=0, atol=2e-5)
         np.testing.assert_allclose(a["depth"].cpu().numpy(), wa["depth"], rtol=1e-5, atol=1e-5)
@@ -282,6 +289,95 @@ def test_row_band_shards_assemble_the_full_image(gpu, orc):
                 o = model.render(ro, rd, staged=False, perturb=False, tile_w=W)
                 parts.append(torch.cat([o["image"], o["depth"].unsqueeze(-1), o["weights_sum"].unsqueeze(-1)], -1))
             assert torch.equal(torch.cat(parts, 0), full), f"world={world}"
+
+
+@pytest.mark.parametrize("steps", [[128], [128, 64, 32]])
+def test_config4_1600x1600_in_eight_bands(gpu, orc, steps):
+    """BASELINE configs[3] at full size: the 1600x1600 image rendered as the 8 row bands an 8-GPU run gives its ranks
+    (200 rows each, 8-row aligned: dist.band_align) equals the single-launch image bit for bit, and 512 pseudo-random
+    pixels agree with the CPU oracle (RGB 2e-5, depth 1e-5 relative)."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.dist import all_shards, band_align
+    params = synthetic_params(steps, seed=0)                              # the bench's own field
+    model = product_model(params, steps, False, gpu)
+    H = W = 1600
+    pose, intr = synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W)
+    plan = rm.RenderPlan(model, steps)
+    ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
+    full = rm.render_rays(plan, ro, rd, tile_w=W, out={})
+    img, dep, ws = full["image"], full["depth"], full["weights_sum"]
+    assert torch.isfinite(img).all() and torch.isfinite(dep).all()
+    np.testing.assert_allclose(ws.cpu().numpy(), 1.0, atol=3e-6)
+    align = band_align(H, 8)
+    bands = all_shards(H, 8, align)
+    assert align == 8 and all(e - b == 200 for b, e in bands)
+    for b, e in bands:
+        rob, rdb = rm.generate_rays(pose, intr, H, W, device=gpu, row_begin=b, row_end=e)
+        assert torch.equal(rob, ro[b * W:e * W]) and torch.equal(rdb, rd[b * W:e * W])
+        o = rm.render_rays(plan, rob, rdb, tile_w=W, out={})
+        assert torch.equal(o["image"], img[b * W:e * W]), f"band {b}:{e} image"
+        assert torch.equal(o["depth"], dep[b * W:e * W]) and torch.equal(o["weights_sum"], ws[b * W:e * W])
+    idx = (synth.hash_u01(512, 9) * (H * W)).astype(np.int64)
+    want = orc.render(oracle_cfg(orc, params, steps), ro[idx].cpu().numpy(), rd[idx].cpu().numpy())
+    np.testing.assert_allclose(img[idx].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dep[idx].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
+
+
+def test_cached_plan_follows_in_place_parameter_updates(gpu, orc):
+    """NeRFRenderer caches its RenderPlan.  In-place writes (optimizer.step, load_state_dict, writes through `.data`
+    like an EMA copy_to) keep every data_ptr, so the cache key cannot see them: with fp16 render tables the plan holds
+    COPIES, which must be refreshed; the aabb buffers are baked into the config and must be re-read."""
+    steps = [64, 32]
+    params = synthetic_params(steps, seed=11)
+    model = product_model(params, steps, False, gpu)
+    _, _, ro, rd = camera_rays(orc, 24, 24)
+    ro_t, rd_t = T(ro, gpu), T(rd, gpu)
+    for dtype in (torch.float32, torch.float16):
+        model.render_table_dtype = dtype
+        with torch.no_grad():
+            a = model.render(ro_t, rd_t)["image"].clone()
+            plan = model._plan
+            model.grid.embeddings.data.mul_(0.5)                          # `.data`: no version bump
+            model.prop_encoders[0].embeddings.mul_(0.9)
+            b = model.render(ro_t, rd_t)["image"].clone()
+            assert model._plan is plan, "in-place updates must not force a plan rebuild"
+            assert not torch.equal(a, b), f"{dtype}: stale tables rendered"
+            fresh = product_model({k: v.cpu().numpy() for k, v in model.state_dict().items() if not k.endswith("offsets") and not k.startswith("aabb")},
+                                  steps, False, gpu)
+            fresh.render_table_dtype = dtype
+            assert torch.equal(fresh.render(ro_t, rd_t)["image"], b), f"{dtype}: cached plan != fresh plan"
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            sd["aabb_infer"] = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=gpu)
+            model.load_state_dict(sd)
+            c = model.render(ro_t, rd_t)
+            want = orc.render(oracle_cfg(orc, {k: v.cpu().numpy() for k, v in sd.items()}, steps, table_f16=(dtype == torch.float16),
+                                         aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), ro, rd)
+            np.testing.assert_allclose(c["image"].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+            sd["aabb_infer"] = torch.tensor([-128.0] * 3 + [128.0] * 3, device=gpu)
+            model.load_state_dict(sd)
+
+
+def test_shader_clock_probe(gpu, orc):
+    """bench.py's roofline prices its cycle-count ceiling at the clock measured inside the final stage."""
+    import ctypes as C
+    from sanerf_hq_amd import _lib, raymarching as rm
+    params = synthetic_params([128], seed=3)
+    model = product_model(params, [128], False, gpu)
+    _, _, ro, rd = camera_rays(orc, 256, 256)
+    plan = rm.RenderPlan(model, [128])
+    lib = _lib.lib()
+    lib.sn_rm_profile_enable(1)
+    a = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=256, out={})
+    mhz, ms = C.c_float(0), C.c_float(0)
+    _lib.check(lib.sn_rm_profile_shader_clock(C.byref(mhz), C.byref(ms)), "clock")
+    msv = (C.c_float * 8)(); cnt = (C.c_int32 * 8)()
+    _lib.check(lib.sn_rm_profile_read(msv, cnt, 8), "read")
+    lib.sn_rm_profile_enable(0)
+    assert cnt[4] == 1 and msv[4] > 0
+    assert 500.0 < mhz.value < 2500.0, f"shader clock {mhz.value} MHz"
+    assert 0.0 < ms.value <= msv[4] * 1.05
+    b = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=256, out={})      # probe off again: same image
+    assert torch.equal(a["image"], b["image"])
 
 
 def test_edge_cases(gpu, orc):
