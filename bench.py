@@ -110,6 +110,11 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_spawn(args)
+    # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints a version banner
+    # there) is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -366,7 +371,7 @@ def main():
             line["single_gpu_same_image"] = single
             line["speedup_vs_single_gpu_same_image"] = round(value / single["rays_per_s"], 3)
             line["gathered_image_check"] = gathered_check
-        print(json.dumps(line))
+        print(json.dumps(line), file=json_out, flush=True)
     if multi:
         dist.destroy_process_group()
 

@@ -282,6 +282,10 @@ int sn_rm_profile_read(float *ms_per_class, int32_t *launches_per_class, int n_c
  * s_memrealtime (constant wall-clock rate) at entry and exit; shader_mhz = their ratio x the wall-clock rate.  probe_ms
  * (optional) = the wall time the probe spanned.  0 when no final stage ran since sn_rm_profile_enable(1).  Synchronises. */
 int sn_rm_profile_shader_clock(float *shader_mhz, float *probe_ms);
+/* Test hook: the library's device numerics primitives element-wise, y[i] = f(a[i][, b[i]]).  op 0: exp (the shared
+ * deterministic recipe, oracle orc_expf); 1: a / b as compiled (IEEE-rounded); 2 / 3: the Mip-360 spacing function and its
+ * inverse (renderer.py:249-252). */
+int sn_debug_eval(int op, const float *a, const float *b, uint32_t n, float *y, sn_stream_t stream);
 /* Diagnostics: occupancy-API workgroups/CU of the fused kernels (prop, final f16x3, final f32-MFMA) and their dynamic LDS bytes. */
 int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n);
 

@@ -50,15 +50,15 @@ static inline uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); r
 /* The build's fp32 exp.  torch.exp / CUDA expf are not bit-reproducible across
  * platforms, so the CPU oracle and the HIP kernels share this recipe instead:
  *   k = rint(x*log2e); r = x - k*ln2 (two-step, fmaf); p = Horner degree 6 (fmaf);
- *   result = (p * 2^(k/2)) * 2^(k - k/2).  <= 1 ulp from the correctly rounded value
- *   on the tested range; exact special cases exp(-inf)=0, exp(+inf)=inf, NaN->NaN.
+ *   result = ldexpf(p, k) on the argument clamped to [-104, 89].  <= 1 ulp from the correctly rounded
+ *   value on the tested range; exact special cases exp(-inf)=0, exp(+inf)=inf, NaN->NaN.
  * Stands in for: torch.exp in activation.py:9 (trunc_exp) and renderer.py:316,321. */
 float orc_expf(float x) {
     if (x != x) return x;
-    if (x > 88.72283935546875f) return INFINITY;
-    if (x < -103.97208404541015625f) return 0.0f;
-    const float k = rintf(x * 1.44269502162933349609375f);
-    float r = fmaf(k, -0.693145751953125f, x);
+    /* clamped argument: 89 -> k = 128, ldexpf overflows to +inf; -104 -> k = -150, ldexpf rounds to 0 */
+    const float xc = x < -104.0f ? -104.0f : (x > 89.0f ? 89.0f : x);
+    const float k = rintf(xc * 1.44269502162933349609375f);
+    float r = fmaf(k, -0.693145751953125f, xc);
     r = fmaf(k, -1.42860676533018704503775e-06f, r);
     float p = 1.98756915e-4f;
     p = fmaf(p, r, 1.39819995e-3f);
@@ -69,12 +69,7 @@ float orc_expf(float x) {
     const float r2 = r * r;
     p = fmaf(p, r2, r);
     p = p + 1.0f;
-    const int ki = (int)k;
-    const int k1 = ki / 2;
-    const int k2 = ki - k1;
-    const float s1 = bits_to_float((uint32_t)(k1 + 127) << 23);
-    const float s2 = bits_to_float((uint32_t)(k2 + 127) << 23);
-    return (p * s1) * s2;
+    return ldexpf(p, (int)k);      /* one rounding (subnormal results included) */
 }
 
 float orc_half_to_float(uint16_t h) {

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "sn_rm_profile_read": (_int, [_vp, _vp, _int]),
     "sn_rm_profile_shader_clock": (_int, [_vp, _vp]),
     "sn_rm_debug_occupancy": (_int, [_vp, _vp, _int]),
+    "sn_debug_eval": (_int, [_int, _vp, _vp, _u32, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -121,7 +122,12 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for these operators.")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if os.environ.get("SN_LIB"):        # A/B against an older build of the same ABI version: newer entry points are simply absent
+                    continue
+                raise ImportError(f"{LIB_PATH} does not export {name}: rebuild it")
             fn.restype, fn.argtypes = res, args
         if l.sn_abi_version() != ABI_VERSION:   # the ctypes structs above mirror include/sanerf_hip.h of exactly this version
             raise ImportError(f"{LIB_PATH} has ABI version {l.sn_abi_version()}, this package expects {ABI_VERSION}: rebuild it")

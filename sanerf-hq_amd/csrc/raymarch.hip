@@ -57,6 +57,23 @@ __global__ __launch_bounds__(256) void k_contract(const float *__restrict__ x, u
     z[(size_t)n * 3] = a; z[(size_t)n * 3 + 1] = b; z[(size_t)n * 3 + 2] = c;
 }
 
+// device numerics primitives exposed element-wise for the parity tests (sn_debug_eval)
+__global__ __launch_bounds__(256) void k_debug_eval(int op, const float *__restrict__ a, const float *__restrict__ b, uint32_t n,
+                                                    float *__restrict__ y) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], w = b ? b[i] : 0.0f;
+    float r;
+    switch (op) {
+        case 0: r = expf_det(x); break;
+        case 1: r = x / w; break;                       // IEEE-rounded division as compiled (-fhip-fp32-correctly-rounded-divide-sqrt)
+        case 2: r = spacing_fn(x); break;
+        case 3: r = spacing_inv(x); break;
+        default: r = 0.0f;
+    }
+    y[i] = r;
+}
+
 __device__ __forceinline__ float nan_to_num(float v) {
     if (v != v) return 0.0f;
     if (v == __builtin_inff()) return FLT_MAX;
@@ -481,6 +498,15 @@ int sn_rm_contract(const float *x, uint32_t N, float *z, sn_stream_t stream) {
     if (N == 0) return SN_OK;
     hipLaunchKernelGGL(k_contract, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, x, N, z);
     SN_LAUNCH_CHECK("k_contract");
+    return SN_OK;
+}
+
+int sn_debug_eval(int op, const float *a, const float *b, uint32_t n, float *y, sn_stream_t stream) {
+    SN_REQUIRE(a && y && op >= 0 && op <= 3, "debug_eval: bad arguments");
+    SN_REQUIRE(b || op != 1, "debug_eval: op %d needs two operands", op);
+    if (n == 0) return SN_OK;
+    hipLaunchKernelGGL(k_debug_eval, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n, y);
+    SN_LAUNCH_CHECK("k_debug_eval");
     return SN_OK;
 }
 

@@ -151,6 +151,9 @@ struct Corner { float v[C]; };
 #ifndef SN_PROP_GROUP
 #define SN_PROP_GROUP 3      // proposal stage, fp32 tables: levels gathered in groups of 3 + 2 (all 5 at once spills at 128 VGPRs): [128,64,32] 4.70 -> 4.55 ms same-box; fp16 tables fit and lose 2 % with the split
 #endif
+#ifndef SN_FINAL_LV
+#define SN_FINAL_LV 1        // final stage, K > 0: host-precomputed level constants + wave-uniform interior fast path (FinalLv); A/B switch
+#endif
 #ifndef SN_XSWAP_DENSE
 #define SN_XSWAP_DENSE 0
 #endif
@@ -380,6 +383,118 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
     });
 }
 
+// ---- final stage, specialised instantiations (K > 0: dense prefix + hashed tail): per-level constants from the host ----
+// The generic code above derives every per-level quantity from GridLevels inside the march: u32 -> f32 conversions of the
+// resolutions, 64-bit base pointers per level (more than the scalar file holds: ~150 v_readlane / v_writelane spill
+// instructions per sample), border selects and clamps on every level.  The final stage issues one instruction per
+// 4 cycles per SIMD whatever its type and is bound by exactly that, so this variant removes
+// instructions, bit-identically:
+//   * resolutions / limits arrive as floats and byte quantities in the kernel argument (FinalLv);
+//   * hashed levels of a GridEncoder table are equal-sized and contiguous (grid.py:121-136: a level is hashed iff it hit
+//     the 2^log2_hashmap_size cap), so ONE base pointer + a per-level byte offset OR-ed into the masked x term serves all
+//     of them; the two prime multiplies become full-rate 24-bit multiplies (only the bits under the mask matter);
+//   * FAST (wave-uniform, decided per sample): every lane's coordinate is at least one coarsest-hashed-level cell away
+//     from the border of [0,1]^3 -> on hashed levels neither the position clamp nor the clamp of the +1 neighbour
+//     (gridencoder.cu:148,182) can trigger, and out-of-range zeroing cannot apply.  Otherwise the general form runs.
+struct FinalLv {
+    float res_f[16];                 // level resolution (gridencoder.cu:133) as float
+    float top_f[16];                 // res - 1
+    uint32_t d_sy[8], d_sz[8];       // dense levels inside the pair / quad-row table (PairTab): y and z strides in bytes,
+    uint32_t d_ylim[8], d_zlim[8];   //   (res - 1) * stride, the clamp of the +1 neighbour,
+    uint32_t d_off[8];               //   byte offset of the level
+    uint32_t h_off[16];              // hashed levels: byte offset from the first hashed level (a multiple of size * row bytes)
+    uint32_t h_mask;                 // (size - 1) * row bytes, the same for every hashed level
+    float in_lo, in_hi;              // FAST <=> in_lo <= x01[d] <= in_hi for all lanes and dimensions
+    const char *pair_base, *hash_base;
+};
+
+template <typename T, bool DENSE, bool FAST, bool XSWAP, int l>
+__device__ __forceinline__ void issue_level_lv(const FinalLv &lv, const float (&x01)[3], float (&pos)[3], Corner<T, 2> (&cv)[8]) {
+    constexpr uint32_t RB = 2u * (uint32_t)sizeof(T);              // bytes per table row (C = 2)
+    const float rf = lv.res_f[l];
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = __builtin_fmaf(x01[d], rf, -0.5f);
+        if constexpr (DENSE || !FAST) p = __builtin_amdgcn_fmed3f(p, 0.0f, lv.top_f[l]);   // = min(max(p, 0), res-1), gridencoder.cu:148
+        cell[d] = (uint32_t)p;
+        pos[d] = __builtin_amdgcn_fractf(p);
+    }
+    if constexpr (DENSE) {
+        const uint32_t sy = lv.d_sy[l], sz = lv.d_sz[l];
+        const uint32_t X0 = __umul24(cell[0], 16u) + lv.d_off[l];
+        const uint32_t Y0 = __umul24(cell[1], sy), Z0 = __umul24(cell[2], sz);
+        const uint32_t Y1 = umin(Y0 + sy, lv.d_ylim[l]), Z1 = umin(Z0 + sz, lv.d_zlim[l]);
+        if constexpr (sizeof(T) == 2) {          // quad rows: (x,y), (x+1,y), (x,y+1), (x+1,y+1)
+#pragma unroll
+            for (int zi = 0; zi < 2; ++zi) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(lv.pair_base + (X0 + Y0 + (zi ? Z1 : Z0)));
+                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __half2 h = *reinterpret_cast<const __half2 *>(&w[q]);
+                    cv[4 * zi + q].v[0] = __low2float(h); cv[4 * zi + q].v[1] = __high2float(h);
+                }
+            }
+        } else {                                 // pair rows: (x, x+1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t off = X0 + ((i & 1) ? Y1 : Y0) + ((i & 2) ? Z1 : Z0);
+                const float4 t = *reinterpret_cast<const float4 *>(lv.pair_base + off);
+                cv[2 * i].v[0] = t.x; cv[2 * i].v[1] = t.y; cv[2 * i + 1].v[0] = t.z; cv[2 * i + 1].v[1] = t.w;
+            }
+        }
+    } else {
+        constexpr uint32_t MY = (2654435761u * RB) & 0xFFFFFFu, MZ = (805459861u * RB) & 0xFFFFFFu;   // gridencoder.cu:49, low 24 bits
+        const uint32_t mask = lv.h_mask, ho = lv.h_off[l];
+        const uint32_t X0 = cell[0] * RB, Y0 = __umul24(cell[1], MY), Z0 = __umul24(cell[2], MZ);
+        uint32_t X1 = X0 + RB, Y1 = Y0 + MY, Z1 = Z0 + MZ;
+        if constexpr (!FAST) {                   // the +1 neighbour is clamped to res-1 (gridencoder.cu:182)
+            const uint32_t top = (uint32_t)lv.top_f[l];
+            X1 = cell[0] < top ? X1 : X0; Y1 = cell[1] < top ? Y1 : Y0; Z1 = cell[2] < top ? Z1 : Z0;
+        }
+        const uint32_t X0m = (X0 & mask) | ho, X1m = (X1 & mask) | ho, Y0m = Y0 & mask, Y1m = Y1 & mask, Z0m = Z0 & mask, Z1m = Z1 & mask;
+        uint32_t offs[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) offs[i] = ((i & 1u) ? X1m : X0m) ^ ((i & 2u) ? Y1m : Y0m) ^ ((i & 4u) ? Z1m : Z0m);
+        if constexpr (XSWAP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) half_wave_swap(offs[2 * q], offs[2 * q + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const char *row = lv.hash_base + offs[i];
+            if constexpr (sizeof(T) == 4) {
+                const float2 t = *reinterpret_cast<const float2 *>(row);
+                cv[i].v[0] = t.x; cv[i].v[1] = t.y;
+            } else if constexpr (XSWAP) {
+                cv[i].v[0] = __uint_as_float(*reinterpret_cast<const uint32_t *>(row)); cv[i].v[1] = 0.0f;
+            } else {
+                const __half2 t = *reinterpret_cast<const __half2 *>(row);
+                cv[i].v[0] = __low2float(t); cv[i].v[1] = __high2float(t);
+            }
+        }
+    }
+}
+
+template <typename T, int G, int K, int GRP, bool FAST>
+__device__ __forceinline__ void issue_group_lv(const FinalLv &lv, const float (&x01)[3], GroupRegs<T, 2, G> &r) {
+    r.oob = false;
+    static_for<0, G>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int l = GRP * G + k;
+        constexpr bool DENSE = l < K;
+        issue_level_lv<T, DENSE, FAST, xswap_level<T, DENSE ? 0 : 1, l>(), l>(lv, x01, r.pos[k], r.cv[k]);
+    });
+}
+
+// FAST test of one sample (see FinalLv): wave-uniform
+__device__ __forceinline__ bool all_interior(const FinalLv &lv, const float (&x01)[3]) {
+    const bool in = (x01[0] >= lv.in_lo && x01[0] <= lv.in_hi) && (x01[1] >= lv.in_lo && x01[1] <= lv.in_hi) &&
+                    (x01[2] >= lv.in_lo && x01[2] <= lv.in_hi);
+    return __all(in) != 0;
+}
+
 // all levels of one grid at one position into registers; D = 3.  gridencoder.cu:94-201 per level.
 template <typename T, int L, int C, int K, bool PAIRX, int GROUP = L>
 __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const GridLevels &g, const float (&x01)[3],
@@ -402,7 +517,7 @@ __device__ __forceinline__ void dense_uniform(const float *__restrict__ W, const
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < IN; ++k) acc = __builtin_fmaf(W[o * IN + k], x[k], acc);
-        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        if (ACT == 1) acc = __builtin_fmaxf(acc, 0.0f);       // ReLU as one v_max_f32 (= acc > 0 ? acc : 0 up to the sign of a zero; NaN -> 0 either way)
         y[o] = acc;
     }
 }
@@ -453,7 +568,7 @@ __device__ __forceinline__ void dense_ldsw_t(const float *__restrict__ Wl, const
         }
     }
 #pragma unroll
-    for (int o = 0; o < OUT; ++o) y[o] = (ACT == 1) ? (acc[o] > 0.0f ? acc[o] : 0.0f) : acc[o];
+    for (int o = 0; o < OUT; ++o) y[o] = (ACT == 1) ? __builtin_fmaxf(acc[o], 0.0f) : acc[o];
 }
 
 // Tiny-MLP weights in the [out][in_padded] layout (view MLP, evaluated once per ray)
@@ -481,7 +596,7 @@ __device__ __forceinline__ void dense_ldsw(const float *__restrict__ Wl, const f
             if (4 * k4 + 2 < IN) acc = __builtin_fmaf(w.z, x[4 * k4 + 2], acc);
             if (4 * k4 + 3 < IN) acc = __builtin_fmaf(w.w, x[4 * k4 + 3], acc);
         }
-        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        if (ACT == 1) acc = __builtin_fmaxf(acc, 0.0f);       // ReLU as one v_max_f32 (= acc > 0 ? acc : 0 up to the sign of a zero; NaN -> 0 either way)
         y[o] = acc;
     }
 }
@@ -506,7 +621,7 @@ __device__ __forceinline__ void dense_ldsw_col(const float *__restrict__ Wl, con
             if (4 * k4 + 2 < IN) acc = __builtin_fmaf(w.z, x[4 * k4 + 2], acc);
             if (4 * k4 + 3 < IN) acc = __builtin_fmaf(w.w, x[4 * k4 + 3], acc);
         }
-        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        if (ACT == 1) acc = __builtin_fmaxf(acc, 0.0f);       // ReLU as one v_max_f32 (= acc > 0 ? acc : 0 up to the sign of a zero; NaN -> 0 either way)
         yout[o * stride] = acc;
     }
 }
@@ -786,6 +901,7 @@ struct FinalArgs {
     float *w_out;                // scratch [T][Npad] for the feature stage, or NULL
     float stop_cum;              // > 0: a wave leaves the march once every lane's optical depth exceeds this (-ln eps)
     PairTab pairs;               // dense levels of the main grid as aligned x-pairs (K > 0 instantiations)
+    FinalLv lv;                  // per-level constants of the K > 0 instantiations
 };
 
 // shader-clock probe of the measurement hook: s_memtime ticks at the shader clock, s_memrealtime at the constant
@@ -1062,7 +1178,7 @@ __device__ __forceinline__ void dense_lds(const float *__restrict__ W, const flo
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < IN; ++k) acc = __builtin_fmaf(W[o * IN + k], x[k], acc);
-        if (ACT == 1) acc = acc > 0.0f ? acc : 0.0f;
+        if (ACT == 1) acc = __builtin_fmaxf(acc, 0.0f);       // ReLU as one v_max_f32 (= acc > 0 ? acc : 0 up to the sign of a zero; NaN -> 0 either way)
         yout[o * stride] = acc;
     }
 }
@@ -1175,7 +1291,13 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     float tmid_n = (rb_next_n + rb_prev) / 2.0f;
     float p_n[3], x01_n[3];
     sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-    if constexpr (MODE == MLP_F16X3) {
+    constexpr bool LV = SN_FINAL_LV && MODE == MLP_F16X3 && K >= PG && K <= 8;   // FinalLv path; the prefetched group 0 is all dense
+    bool fast_n = false;
+    if constexpr (LV) {
+        fast_n = all_interior(a.lv, x01_n);
+        issue_group_lv<TT, PG, K, 0, false>(a.lv, x01_n, g0);
+        __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (MODE == MLP_F16X3) {
         issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1196,19 +1318,36 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
             };
             blend_group<TT, 2, PG, K, 0>(g0, emit);
             __builtin_amdgcn_sched_barrier(0);
-            static_for<1, L / PG>([&](auto gg) {
-                constexpr int GRP = decltype(gg)::value;
-                GroupRegs<TT, 2, PG> gr;
-                issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr, a.pairs);
-                __builtin_amdgcn_sched_barrier(0);
-                blend_group<TT, 2, PG, K, GRP>(gr, emit);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            {
+            auto zero_oob = [&]() {
                 const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
                 if (__builtin_expect(__any(oob), 0)) {      // gridencoder.cu:105-130: zeros outside [0,1]
                     if (oob) for (int l = 0; l < L; ++l) { row_hi[l] = 0u; row_lo[l] = 0u; }
                 }
+            };
+            if constexpr (LV) {
+                auto rest = [&](auto fast_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+                    static_for<1, L / PG>([&](auto gg) {
+                        constexpr int GRP = decltype(gg)::value;
+                        GroupRegs<TT, 2, PG> gr;
+                        issue_group_lv<TT, PG, K, GRP, FAST>(a.lv, x01, gr);
+                        __builtin_amdgcn_sched_barrier(0);
+                        blend_group<TT, 2, PG, K, GRP>(gr, emit);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                };
+                if (__builtin_expect(fast_n, 1)) rest(std::true_type{});          // fast_n: decided for this sample one iteration ago
+                else { rest(std::false_type{}); zero_oob(); }
+            } else {
+                static_for<1, L / PG>([&](auto gg) {
+                    constexpr int GRP = decltype(gg)::value;
+                    GroupRegs<TT, 2, PG> gr;
+                    issue_group<TT, 2, PG, K, GRP>(table, a.g, x01, gr, a.pairs);
+                    __builtin_amdgcn_sched_barrier(0);
+                    blend_group<TT, 2, PG, K, GRP>(gr, emit);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                zero_oob();
             }
             {   // geometry of the next sample (the last iteration re-issues its own sample: in bounds, unused)
                 const uint32_t jn = j + 2u <= T ? j + 2u : T;
@@ -1217,7 +1356,12 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 const float rbp = j + 2u <= T ? rb_next : rb_prev;
                 tmid_n = (rb_next_n + rbp) / 2.0f;
                 sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-                issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
+                if constexpr (LV) {
+                    fast_n = all_interior(a.lv, x01_n);
+                    issue_group_lv<TT, PG, K, 0, false>(a.lv, x01_n, g0);
+                } else {
+                    issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_wave_barrier();
@@ -1655,6 +1799,33 @@ static uint32_t pair_layout(const GridLevels &g, int K, uint32_t (&off)[8]) {
     return total;
 }
 
+// FinalLv of a grid whose levels are "K dense (packed as pair / quad rows in pt), then hashed, equal-sized and contiguous".
+// Returns false when the grid does not have that shape (the generic instantiation then runs).
+static bool build_final_lv(const GridLevels &g, int K, const PairTab &pt, const void *table, uint32_t row_bytes, FinalLv &lv) {
+    memset(&lv, 0, sizeof(lv));
+    if (g.L > 16 || (uint32_t)K >= g.L || g.C != 2 || K < 1 || K > 8 || pt.base == nullptr) return false;
+    const uint32_t size = g.size[K];
+    if ((size & (size - 1)) != 0 || (uint64_t)size * row_bytes > (1u << 24)) return false;      // 24-bit multiplies cover the mask
+    for (uint32_t l = (uint32_t)K; l < g.L; ++l) {
+        if (g.size[l] != size || (l + 1 < g.L && g.off[l + 1] != g.off[l] + size) || g.res[l] >= (1u << 24)) return false;
+        lv.h_off[l] = (g.off[l] - g.off[K]) * row_bytes;
+    }
+    lv.h_mask = (size - 1u) * row_bytes;
+    lv.hash_base = reinterpret_cast<const char *>(table) + (size_t)g.off[K] * row_bytes;
+    lv.pair_base = reinterpret_cast<const char *>(pt.base);
+    for (uint32_t l = 0; l < g.L; ++l) { lv.res_f[l] = (float)g.res[l]; lv.top_f[l] = (float)(g.res[l] - 1u); }
+    for (uint32_t l = 0; l < (uint32_t)K; ++l) {
+        const uint32_t res = g.res[l];
+        lv.d_sy[l] = res * 16u; lv.d_sz[l] = res * res * 16u;
+        lv.d_ylim[l] = (res - 1u) * lv.d_sy[l]; lv.d_zlim[l] = (res - 1u) * lv.d_sz[l];
+        lv.d_off[l] = pt.off[l] * 16u;
+    }
+    // one and a half cells of the coarsest hashed level: fl(x * res_l - 0.5) stays inside [0.99, res_l - 1.99] on every hashed level
+    lv.in_lo = 1.5f / (float)g.res[K];
+    lv.in_hi = 1.0f - 1.5f / (float)g.res[K];
+    return true;
+}
+
 enum { PK_PACK = 0, PK_PROP0, PK_PROP1, PK_PROP2, PK_FINAL, PK_FEAT, PK_CLASSES };
 struct ProfSpan { hipEvent_t a, b; int cls; };
 static bool g_prof_on = false;
@@ -2014,6 +2185,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * 15 : nullptr;
         fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
         fa.pairs = pairs;
+        const bool lv_ok = build_final_lv(gl_main, dense_prefix(gl_main), pairs, cfg->grid.embeddings,
+                                          2u * (cfg->grid.table_dtype == SN_F16 ? 2u : 4u), fa.lv);
         fa.w_out = cfg->with_feat ? w_scr[S - 1] : nullptr;
         // early termination is honoured only when nothing per-sample leaves the kernel (those tensors would be left
         // unwritten past the stop)
@@ -2042,7 +2215,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         const bool aux = fa.w_out != nullptr || fa.stop_cum > 0.0f;
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
-        const int Kmain = dense_prefix(gl_main);
+        const int Kmain = (SN_FINAL_LV && !lv_ok) ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
         // few rays in linear order: lanes share rays (k_final_stage_sp); fewer samples per lane while CUs would idle
         const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && n <= final_sp_max_rays() &&
                               fa.T <= 64u * FSP_MAX_SPL;

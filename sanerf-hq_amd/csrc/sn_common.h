@@ -60,9 +60,10 @@ uint32_t level_resolution(uint32_t level, float S, uint32_t H);
 
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float expf_det(float x) {
-    // branch-free: the polynomial runs on the clamped argument and the three special cases are selected at the end
-    // (early returns compile to exec-mask branches that serialise the three exps of a march step)
-    const float xc = fminf(fmaxf(x, -104.0f), 89.0f);
+    // branch-free: the polynomial runs on the clamped argument; scaling is ONE v_ldexp_f32, which also produces the
+    // overflow (+inf from 89 -> k = 128) and underflow (0 from -104 -> k = -150) cases; NaN is selected at the end.
+    // Same recipe as the oracle's orc_expf (oracle/oracle.c).
+    const float xc = __builtin_amdgcn_fmed3f(x, -104.0f, 89.0f);
     const float k = __builtin_rintf(xc * 1.44269502162933349609375f);
     float r = __builtin_fmaf(k, -0.693145751953125f, xc);
     r = __builtin_fmaf(k, -1.42860676533018704503775e-06f, r);
@@ -75,14 +76,7 @@ __device__ __forceinline__ float expf_det(float x) {
     const float r2 = r * r;
     p = __builtin_fmaf(p, r2, r);
     p = p + 1.0f;
-    const int ki = (int)k;
-    const int k1 = ki / 2;
-    const int k2 = ki - k1;
-    const float s1 = __int_as_float((k1 + 127) << 23);
-    const float s2 = __int_as_float((k2 + 127) << 23);
-    float y = (p * s1) * s2;
-    y = x < -103.97208404541015625f ? 0.0f : y;
-    y = x > 88.72283935546875f ? __builtin_inff() : y;
+    const float y = __builtin_amdgcn_ldexpf(p, (int)k);
     return x != x ? x : y;
 }
 
@@ -247,11 +241,15 @@ __device__ __forceinline__ void corner_offsets(const uint32_t (&cell)[3], uint32
     // or the base term itself at the border -- an add and a select instead of a second quarter-rate v_mul_lo_u32
     uint32_t Y0, Z0;
     if constexpr (KIND == 0) { Y0 = __umul24(y0, my); Z0 = __umul24(z0, mz); }   // full rate; operands bounded by levels_fast()
-    else { Y0 = y0 * my; Z0 = z0 * mz; }
+    else if constexpr (KIND == 1) {
+        // only the bits under the mask survive and levels_fast() bounds mask < 2^24: the low 24 bits of (y * P * stride)
+        // depend on the low 24 bits of the factors only -> full-rate v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
+        Y0 = __umul24(y0, my & 0xffffffu); Z0 = __umul24(z0, mz & 0xffffffu);
+    } else { Y0 = y0 * my; Z0 = z0 * mz; }
     const uint32_t X0 = x0 * STRIDE_BYTES;
     const uint32_t X1 = x0 < top ? X0 + STRIDE_BYTES : X0;
-    const uint32_t Y1 = y0 < top ? Y0 + my : Y0;
-    const uint32_t Z1 = z0 < top ? Z0 + mz : Z0;
+    const uint32_t Y1 = y0 < top ? Y0 + (KIND == 1 ? (my & 0xffffffu) : my) : Y0;
+    const uint32_t Z1 = z0 < top ? Z0 + (KIND == 1 ? (mz & 0xffffffu) : mz) : Z0;
     if constexpr (KIND == 1) {
         // (X ^ Y ^ Z) & m == (X & m) ^ (Y & m) ^ (Z & m): masking the 6 partial terms replaces 8 per-corner ANDs
         const uint32_t X0m = X0 & mask, X1m = X1 & mask, Y0m = Y0 & mask, Y1m = Y1 & mask, Z0m = Z0 & mask, Z1m = Z1 & mask;
@@ -272,7 +270,7 @@ __device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t re
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float p = __builtin_fmaf(x01[d], (float)res, -0.5f);
-        p = fminf(fmaxf(p, 0.0f), (float)(res - 1u));
+        p = __builtin_amdgcn_fmed3f(p, 0.0f, (float)(res - 1u));      // = min(max(p, 0), res-1) in one instruction (NaN -> 0 like fmaxf)
         cell[d] = (uint32_t)p;                     // p >= 0: truncation == floor (one v_cvt_u32_f32)
         pos[d] = __builtin_amdgcn_fractf(p);       // p - floor(p), exact for p >= 0 (one v_fract_f32)
     }
@@ -282,7 +280,7 @@ __device__ __forceinline__ void locate_linear(const float (&x01)[3], uint32_t re
 static inline bool levels_fast(const GridLevels &g) {
     for (uint32_t l = 0; l < g.L; ++l) {
         const uint32_t mode = g.mode[l], mk = (mode >> 1) & 3u, nd = (mode >> 4) & 15u;
-        if (mode & 1u) { if (mk != 1u) return false; }
+        if (mode & 1u) { if (mk != 1u || (uint64_t)g.size[l] * g.C * 4u > (1u << 24) || g.res[l] >= (1u << 24)) return false; }   // 24-bit hash multiplies
         else if (mk != 0u || nd != 3u) return false;
         else if ((uint64_t)g.res[l] * g.res[l] * 16u >= (1u << 24)) return false;   // dense strides go through 24-bit multiplies
     }

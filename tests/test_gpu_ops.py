@@ -635,3 +635,27 @@ def test_small_linear_autograd_equals_nn_linear(gpu):
     gw = wide.weight.grad.clone(); wide.zero_grad()
     wide(xw).square().sum().backward()
     assert float((gw - wide.weight.grad).abs().max()) <= 1e-4 * float(wide.weight.grad.abs().max())
+
+
+def test_device_exp_matches_the_oracle_bit_for_bit(gpu, orc):
+    """The deterministic exp shared by csrc/ and oracle/ (numerics contract): bit-identical over the
+    whole argument range incl. the overflow / underflow ends, subnormal results, infinities and NaN."""
+    import ctypes as C
+    from sanerf_hq_amd import _lib
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.uniform(-110.0, 95.0, 400000), rng.uniform(-1.0, 1.0, 100000), rng.uniform(-104.5, -86.0, 200000),      # subnormal results
+        rng.uniform(88.0, 89.5, 50000), np.linspace(-104.2, -103.8, 20001), np.linspace(88.70, 88.75, 20001),
+        [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-30, -1e-30, 88.72283935546875, -103.97208404541015625, 89.0, -104.0, 1e30, -1e30],
+    ]).astype(np.float32)
+    xt = torch.from_numpy(x).to(gpu)
+    yt = torch.empty_like(xt)
+    _lib.check(_lib.lib().sn_debug_eval(0, xt.data_ptr(), None, x.size, yt.data_ptr(), _lib.stream()), "debug_eval")
+    got = yt.cpu().numpy()
+    want = orc.expf(x)
+    assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32)), \
+        f"{int((got.view(np.uint32) != want.astype(np.float32).view(np.uint32)).sum())} of {x.size} values differ"
+    ok = np.isfinite(want) & (want > 1e-37)
+    ref = np.exp(x[ok].astype(np.float64))
+    assert np.max(np.abs(got[ok] - ref) / ref) < 2.5e-7            # <= ~2 ulp of the correctly rounded value
+    assert got[x == np.float32(-np.inf)][0] == 0.0 and np.isinf(got[x == np.float32(np.inf)][0]) and np.isnan(got[np.isnan(x)]).all()

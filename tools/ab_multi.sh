@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/ab_multi.sh "<bench args>" lib1.so lib2.so ...   ("HEAD" = the in-tree library)
+# Same-box comparison of several builds: two interleaved rounds, per-kernel times from the bench line.
+args=$1; shift
+for i in 1 2; do
+  for lib in "$@"; do
+    l=$lib; [ "$lib" = "HEAD" ] && l=""
+    SN_LIB=$l python bench.py --no-cpu-baseline --primary-only $args 2>/dev/null | grep "^{" | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; o=r['other_kernels_ms']
+print('%-28s %-8s %7.2f Mrays/s %7.3f ms | final %.3f prop0 %s prop1 %s | clk %s MHz' % ('$lib'.split('/')[-1], d['config']['schedule'], d['value']/1e6, d['ms_per_step'], r['avg_kernel_ms'], o['prop0'], o['prop1'], r['shader_clock_mhz']))"
+  done
+done
