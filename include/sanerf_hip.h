@@ -212,6 +212,12 @@ typedef struct sn_render_cfg {
      * pixels) stops marching once the transmittance of all its rays is below this value; 0 = off (default).  Every
      * output changes by at most ~eps * |feature|.  Ignored when per-sample outputs or the feature stage are on. */
     float        early_stop_eps;
+    /* Arithmetic of the 32-64-64-16 MLP on the matrix cores.  0 (default): fp16 hi/lo-split products with fp32 accumulation
+     * (2^-22 per product) -- requires every weight and activation of that MLP to stay below 65504 in magnitude, which the
+     * CALLER guarantees (the Python mirror derives a bound from max|table| and the weights' row norms and sets 1 when it
+     * cannot).  1: exact fp32 v_mfma_f32_32x32x2_f32 (no range limit, ~2.2x slower final stage).  The environment
+     * variable SN_RENDER_MLP (f16x3 / mfma32 / valu) overrides this field. */
+    int32_t      mlp_exact_fp32;
 } sn_render_cfg;
 
 typedef struct sn_render_io {
@@ -260,6 +266,10 @@ int sn_rm_grid_composite(const float *xyzs, const float *weights, uint32_t N, ui
  * inside the fp16 range, |v| < 65504).  workspace: >= sn_mlp_wide_workspace_bytes(), 16-byte aligned (holds the
  * re-ordered weights, rebuilt on every call: the call is stateless).  ln_weight/ln_bias NULL = no LayerNorm. */
 size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp);
+/* Range check of the split-fp16 arithmetic: sn_mlp_wide_forward raises a sticky device-side flag when an output row is not
+ * finite (what an activation beyond the fp16 range produces).  Reads and clears it: *flag = 1 if any call since the last
+ * read overflowed.  Synchronises the device. */
+int sn_mlp_wide_overflow(int32_t *flag);
 int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
                         const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
                         sn_stream_t stream);

@@ -40,7 +40,7 @@ class RenderCfg(C.Structure):
                 ("grid", GridDesc), ("grid_mlp", MlpDesc), ("view_mlp", MlpDesc),
                 ("sh_degree", C.c_uint32), ("aabb", C.c_float * 6), ("min_near", C.c_float), ("bound", C.c_float),
                 ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float),
-                ("feat_grid", GridDesc), ("with_feat", C.c_int32), ("early_stop_eps", C.c_float)]
+                ("feat_grid", GridDesc), ("with_feat", C.c_int32), ("early_stop_eps", C.c_float), ("mlp_exact_fp32", C.c_int32)]
 
 
 class RenderIO(C.Structure):
@@ -86,6 +86,7 @@ _SIGNATURES = {
     "sn_rm_grid_composite": (_int, [_vp, _vp, _u32, _u32, _f32, C.POINTER(GridDesc), _u32, _vp, _vp]),
     "sn_mlp_wide_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "sn_mlp_wide_forward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _f32, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
+    "sn_mlp_wide_overflow": (_int, [_vp]),
     "sn_linear_wgrad_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32]),
     "sn_linear_wgrad": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_render_workspace_bytes": (C.c_size_t, [C.POINTER(RenderCfg), _u32, _u32]),

@@ -76,6 +76,9 @@ __device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
+__device__ int g_wide_overflow = 0;      // sticky: a k_mlp_wide launch produced a non-finite output row (see the epilogue)
+
+
 // one thread per (layer, k-step, output tile, lane): 8 weights -> (hi, lo) uint4
 __global__ void k_pack_mlp_wide(PackArgs a) {
     const uint32_t layer = blockIdx.y;
@@ -339,6 +342,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 
     // ---- epilogue: optional LayerNorm over the row, then 16-byte stores (4 consecutive neurons per register quad) ----
     const WideLayer LL = a.layer[a.nl - 1u];
+    {   // range check of the split-fp16 arithmetic: an activation beyond 65504 turned into inf in a hi half and reaches
+        // the last layer as inf / NaN.  0 * x is NaN exactly for those.  Sticky flag, read by sn_mlp_wide_overflow().
+        float chk = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(acc[mt][r], 0.0f, chk);
+        if (ok && chk != chk) g_wide_overflow = 1;
+    }
     float mean = 0.0f, rstd = 1.0f;
     if (a.ln_w) {
         float s = 0.0f;
@@ -449,6 +461,17 @@ static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) 
 }  // namespace sn
 
 using namespace sn;
+
+extern "C" int sn_mlp_wide_overflow(int32_t *flag) {
+    SN_REQUIRE(flag, "mlp_wide_overflow: NULL output");
+    int v = 0;
+    const int zero = 0;
+    SN_HIP_OK(hipDeviceSynchronize());
+    SN_HIP_OK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wide_overflow), sizeof(v)));
+    SN_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_wide_overflow), &zero, sizeof(zero)));
+    *flag = v;
+    return SN_OK;
+}
 
 extern "C" size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp) {
     WideLayer layers[SN_MAX_LAYERS];

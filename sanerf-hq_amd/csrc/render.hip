@@ -2049,10 +2049,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     // SN_RENDER_MLP = f16x3 (default: fp16 hi/lo split on the matrix cores, fp32 accumulate),
     //                 mfma32 / mfma (exact fp32 v_mfma_f32_32x32x2_f32), valu (vector-ALU fallback)
     const char *mode = getenv("SN_RENDER_MLP");
-    int mlp_mode = MLP_F16X3;
+    int mlp_mode = cfg->mlp_exact_fp32 ? MLP_F32 : MLP_F16X3;
     if (mode && strcmp(mode, "valu") == 0) mlp_mode = MLP_VALU;
     else if (mode && (strcmp(mode, "mfma32") == 0 || strcmp(mode, "mfma") == 0)) mlp_mode = MLP_F32;
-    else if (mode && mode[0] && strcmp(mode, "f16x3") != 0) { set_error("render_rays: unknown SN_RENDER_MLP=%s", mode); return SN_ERR_INVALID; }
+    else if (mode && strcmp(mode, "f16x3") == 0) mlp_mode = MLP_F16X3;
+    else if (mode && mode[0]) { set_error("render_rays: unknown SN_RENDER_MLP=%s", mode); return SN_ERR_INVALID; }
     const bool use_mfma = mlp_mode != MLP_VALU;
 
     SN_REQUIRE(io->workspace != nullptr, "render_rays: workspace is NULL");

@@ -170,7 +170,7 @@ class NeRFRenderer(nn.Module):
                                        early_stop_eps=float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0))
             self._plan_key = key
         elif not getattr(self, "render_tables_static", False):
-            self._plan.refresh_tables()
+            self._plan.refresh_tables()        # also re-checks the fp16 range guard when parameters changed
         ab = rm._host_values(self.aabb_train if self.training else self.aabb_infer)
         for i in range(6):
             self._plan.cfg.aabb[i] = ab[i]

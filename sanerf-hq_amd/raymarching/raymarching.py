@@ -17,6 +17,8 @@ This module is that operator surface, implemented over libsanerf_hip.so:
 from __future__ import annotations
 
 import ctypes as C
+import os
+import warnings
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -313,9 +315,22 @@ def grid_composite(weights: torch.Tensor, xyzs: torch.Tensor, encoder, bound: fl
     return out
 
 
-def mlp_forward(x: torch.Tensor, mlp, layer_norm: Optional[torch.nn.LayerNorm] = None) -> torch.Tensor:
+FP16_SPLIT_LIMIT = 65504.0 * 0.5      # split-fp16 operands must stay below the fp16 range; half of it as the guard band
+
+
+def mlp_wide_overflow() -> bool:
+    """True if a matrix-core head MLP call since the last query produced a non-finite output row, i.e. an activation
+    left the fp16 range of its split-fp16 arithmetic.  Reads and clears the device flag; synchronises."""
+    flag = C.c_int32(0)
+    _lib.check(_lib.lib().sn_mlp_wide_overflow(C.byref(flag)), "sn_mlp_wide_overflow")
+    return bool(flag.value)
+
+
+def mlp_forward(x: torch.Tensor, mlp, layer_norm: Optional[torch.nn.LayerNorm] = None, check_range: Optional[bool] = None) -> torch.Tensor:
     """SkipConnMLP / MLP forward [+ LayerNorm] in one matrix-core kernel (network.py:9-66, 115; the feature heads
-    of renderer.py:359-385).  x [N, dim_in] -> [N, dim_out].  Inference only (no autograd graph); hidden width 256."""
+    of renderer.py:359-385).  x [N, dim_in] -> [N, dim_out].  Inference only (no autograd graph); hidden width 256.
+    check_range (default: environment SN_CHECK_RANGE=1): query the overflow flag after the call (one synchronisation) and
+    raise if an activation left the fp16 range -- the inputs are run-time data, so no static bound exists for this kernel."""
     L = _lib.lib()
     x = x.detach().contiguous().float()
     layers = list(mlp.net)
@@ -339,6 +354,10 @@ def mlp_forward(x: torch.Tensor, mlp, layer_norm: Optional[torch.nn.LayerNorm] =
     _lib.check(L.sn_mlp_wide_forward(C.byref(desc), _lib.dev(lw, "ln.weight"), _lib.dev(lb, "ln.bias"), eps,
                                      _lib.dev(x, "x"), x.shape[0], _lib.dev(out, "out"), ws.data_ptr(), ws.numel(),
                                      _lib.stream()), "sn_mlp_wide_forward")
+    if check_range if check_range is not None else os.environ.get("SN_CHECK_RANGE") == "1":
+        if mlp_wide_overflow():
+            raise RuntimeError("mlp_forward: an activation left the fp16 range of the split-fp16 matrix-core arithmetic "
+                               "(|v| >= 65504): outputs are not finite; run this head through the torch module instead")
     return out
 
 
@@ -412,10 +431,43 @@ class RenderPlan:
             self.feat_dim = feat_encoder.output_dim
         cfg.early_stop_eps = float(early_stop_eps)      # opt-in transmittance early-out of the last stage (0 = reference behaviour)
         self.cfg = cfg
+        self._range_model = model
+        self._range_versions = None
+        self.activation_bound = 0.0
+        self.check_range()
         self.num_steps = [int(t) for t in num_steps]
         self.geo = model.geom_feat_dim
         self.ncol = model.geom_feat_dim + model.view_encoder.output_dim
         self._ws: Optional[torch.Tensor] = None
+
+    @torch.no_grad()
+    def check_range(self) -> None:
+        """Static range guard of the split-fp16 MLP of the final stage.  Hash-grid features are convex combinations of
+        table values, so |feature| <= max|table|; a ReLU layer's outputs are bounded by the largest row L1 norm of its
+        weight times the bound of its inputs.  If features, hidden activations or weights could reach the fp16 range the
+        plan switches the kernel to the exact fp32 matrix-core path (cfg.mlp_exact_fp32, ~2.2x slower final stage) instead
+        of risking inf / NaN.  Re-evaluated when a parameter's version counter moved (one small reduction + sync)."""
+        m = self._range_model
+        tensors = [m.grid.embeddings] + [lin.weight for lin in m.grid_mlp.net]
+        versions = tuple((t.data_ptr(), t._version) for t in tensors)
+        if versions == self._range_versions:
+            return
+        self._range_versions = versions
+        bound = float(m.grid.embeddings.detach().abs().max())
+        worst = bound
+        wmax = 0.0
+        for lin in list(m.grid_mlp.net)[:-1]:                          # the last layer's outputs stay fp32 accumulators
+            w = lin.weight.detach().float()
+            bound = float(w.abs().sum(dim=1).max()) * bound
+            worst = max(worst, bound)
+        for lin in m.grid_mlp.net:
+            wmax = max(wmax, float(lin.weight.detach().abs().max()))
+        self.activation_bound = max(worst, wmax)
+        exact = not (self.activation_bound < FP16_SPLIT_LIMIT)          # also catches NaN
+        if exact and not self.cfg.mlp_exact_fp32:
+            warnings.warn(f"fused render: activations of the 32-64-64-16 MLP are only bounded by {self.activation_bound:.3g} "
+                          f"(>= {FP16_SPLIT_LIMIT:.0f}): using the exact fp32 matrix-core path instead of split-fp16")
+        self.cfg.mlp_exact_fp32 = int(exact)
 
     @torch.no_grad()
     def refresh_tables(self) -> None:
@@ -423,6 +475,7 @@ class RenderPlan:
         the plan's device pointers stay valid.  A plan over fp32 tables holds no copies and this is a no-op."""
         for src, copy in self.copies:
             copy.copy_(src.detach())
+        self.check_range()
 
     def workspace(self, N: int, tile_w: int, device) -> torch.Tensor:
         need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(self.cfg), N, tile_w))

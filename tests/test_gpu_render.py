@@ -666,3 +666,56 @@ def test_uncontracted_scene_and_transparent_background(gpu, orc):
     np.testing.assert_allclose(got["weights_sum"].cpu().numpy(), want["weights_sum"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(got["depth"].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
+
+
+def test_split_fp16_range_guard(gpu, orc, monkeypatch):
+    """The default MLP arithmetic splits fp32 operands into fp16 hi/lo halves: |activation| must stay below 65504.  The
+    plan bounds the activations from max|table| and the weights' row norms and falls back to the exact fp32 matrix-core
+    path when the bound is not safe; forcing split-fp16 on such a field is what the guard protects from."""
+    import warnings
+    from sanerf_hq_amd import raymarching as rm
+    steps = [32]
+    params = synthetic_params(steps, seed=21, gain=4.0)
+    params["grid_mlp.net.0.weight"] = params["grid_mlp.net.0.weight"] * np.float32(2.0 ** 17)  # hidden activations ~1e5..1e6
+    params["grid_mlp.net.2.weight"] = params["grid_mlp.net.2.weight"] * np.float32(2.0 ** -17)
+    model = product_model(params, steps, False, gpu)
+    _, _, ro, rd = camera_rays(orc, 32, 32)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        plan = rm.RenderPlan(model, steps)
+    assert plan.cfg.mlp_exact_fp32 == 1 and plan.activation_bound > rm.FP16_SPLIT_LIMIT
+    assert any("exact fp32" in str(w.message) for w in caught)
+    out = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32, out={})
+    want = orc.render(oracle_cfg(orc, params, steps), ro, rd)
+    assert torch.isfinite(out["image"]).all()
+    np.testing.assert_allclose(out["image"].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+    monkeypatch.setenv("SN_RENDER_MLP", "f16x3")                       # override the guard: fp16 halves overflow
+    bad = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32, out={})
+    assert not torch.isfinite(bad["image"]).all() or float((bad["image"] - out["image"]).abs().max()) > 1e-2
+    monkeypatch.delenv("SN_RENDER_MLP")
+    # an ordinary field keeps the fast path
+    ok_model = product_model(synthetic_params(steps, seed=21), steps, False, gpu)
+    assert rm.RenderPlan(ok_model, steps).cfg.mlp_exact_fp32 == 0
+    # in-place weight update seen through the module-level plan cache
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ok_model.render(T(ro, gpu), T(rd, gpu))
+        assert ok_model._plan.cfg.mlp_exact_fp32 == 0
+        ok_model.grid_mlp.net[0].weight.mul_(2.0 ** 17)
+        ok_model.render(T(ro, gpu), T(rd, gpu))
+        assert ok_model._plan.cfg.mlp_exact_fp32 == 1
+
+
+def test_wide_mlp_overflow_is_reported(gpu):
+    """Head MLPs (run-time inputs, no static bound): a non-finite output row raises the sticky device flag."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(0)
+    mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+    x = torch.randn(500, 143, device=gpu)
+    rm.mlp_wide_overflow()                                               # clear
+    y = rm.mlp_forward(x, mlp, check_range=True)
+    assert torch.isfinite(y).all() and not rm.mlp_wide_overflow()
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        rm.mlp_forward(x * 1e6, mlp, check_range=True)                   # hidden activations ~1e6 >> 65504
+    assert not rm.mlp_wide_overflow(), "flag is cleared by the read"
