@@ -123,6 +123,12 @@ int sn_freq_encode_backward(const float *grad, const float *outputs, uint32_t B,
 int sn_rm_generate_rays(const float *pose_host, float fx, float fy, float cx, float cy,
                         uint32_t H, uint32_t W, uint32_t row_begin, uint32_t row_end,
                         float *rays_o, float *rays_d, sn_stream_t stream);
+/* nerf/utils.py:209-287 for a drawn pixel subset (a training step's rays): ray n looks through flat pixel index inds[n]
+ * (int64, row-major in an image of width W) of camera poses[n].  poses: DEVICE, n_poses x 16 floats row-major cam2world,
+ * n_poses = 1 (one camera for all rays) or N (one camera per ray: provider.py:908-913 `random_image_batch`);
+ * intrinsics: DEVICE, n_intrinsics x (fx, fy, cx, cy), 1 or N.  No host round trip. */
+int sn_rm_rays_from_pixels(const float *poses, uint32_t n_poses, const float *intrinsics, uint32_t n_intrinsics, const int64_t *inds,
+                           uint32_t W, uint32_t N, float *rays_o, float *rays_d, sn_stream_t stream);
 /* nerf/renderer.py:122-139.  aabb: 6 floats, HOST.  nears/fars [N]. */
 int sn_rm_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb_host,
                              float min_near, uint32_t N, float *nears, float *fars, sn_stream_t stream);

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "sn_freq_encode_forward": (_int, [_vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "sn_freq_encode_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "sn_rm_generate_rays": (_int, [_vp, _f32, _f32, _f32, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "sn_rm_rays_from_pixels": (_int, [_vp, _u32, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_near_far_from_aabb": (_int, [_vp, _vp, _vp, _f32, _u32, _vp, _vp, _vp]),
     "sn_rm_contract": (_int, [_vp, _u32, _vp, _vp]),
     "sn_rm_sample_pdf": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp]),

@@ -37,6 +37,33 @@ __global__ __launch_bounds__(256) void k_generate_rays(Pose pose, float fx, floa
     }
 }
 
+// nerf/utils.py:209-287 for a drawn subset of pixels: ray n looks through flat pixel index inds[n] (row-major, H x W) of
+// camera poses[n] (or the one shared camera), intrinsics likewise -- the per-ray cameras of provider.py:908-913
+// (`random_image_batch`: `poses = self.poses[index]` with one image index per ray).  Same arithmetic as k_generate_rays.
+__global__ __launch_bounds__(256) void k_rays_from_pixels(const float *__restrict__ poses, uint32_t pose_stride,
+                                                          const float *__restrict__ intr, uint32_t intr_stride,
+                                                          const int64_t *__restrict__ inds, uint32_t W, uint32_t N,
+                                                          float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *m = poses + (size_t)n * pose_stride;        // 4x4 row-major cam2world
+    const float *k4 = intr + (size_t)n * intr_stride;        // fx, fy, cx, cy
+    const int64_t ind = inds[n];
+    const uint32_t row = (uint32_t)(ind / W), col = (uint32_t)(ind - (int64_t)row * W);
+    const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+    const float xs = (i - k4[2]) / k4[0];
+    const float ys = -(j - k4[3]) / k4[1];
+    const float zs = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float acc = xs * m[k * 4 + 0];
+        acc = __builtin_fmaf(ys, m[k * 4 + 1], acc);
+        acc = __builtin_fmaf(zs, m[k * 4 + 2], acc);
+        rays_d[(size_t)n * 3 + k] = acc;
+        rays_o[(size_t)n * 3 + k] = m[k * 4 + 3];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                   Aabb ab, float min_near, uint32_t N,
                                                   float *__restrict__ nears, float *__restrict__ fars) {
@@ -479,6 +506,19 @@ int sn_rm_generate_rays(const float *pose_host, float fx, float fy, float cx, fl
     if (count == 0) return SN_OK;
     hipLaunchKernelGGL(k_generate_rays, dim3(div_up(count, 256)), dim3(256), 0, (hipStream_t)stream, p, fx, fy, cx, cy, W, first, count, rays_o, rays_d);
     SN_LAUNCH_CHECK("k_generate_rays");
+    return SN_OK;
+}
+
+int sn_rm_rays_from_pixels(const float *poses, uint32_t n_poses, const float *intrinsics, uint32_t n_intrinsics, const int64_t *inds,
+                           uint32_t W, uint32_t N, float *rays_o, float *rays_d, sn_stream_t stream) {
+    SN_REQUIRE(poses && intrinsics && inds && rays_o && rays_d, "rays_from_pixels: NULL pointer");
+    SN_REQUIRE((n_poses == 1 || n_poses == N) && (n_intrinsics == 1 || n_intrinsics == N),
+               "rays_from_pixels: %u poses / %u intrinsics for %u rays (each must be 1 or N)", n_poses, n_intrinsics, N);
+    SN_REQUIRE(W >= 1, "rays_from_pixels: W must be >= 1");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_rays_from_pixels, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, poses, n_poses == 1 ? 0u : 16u,
+                       intrinsics, n_intrinsics == 1 ? 0u : 4u, inds, W, N, rays_o, rays_d);
+    SN_LAUNCH_CHECK("k_rays_from_pixels");
     return SN_OK;
 }
 

@@ -1,8 +1,9 @@
 """Ray generation with the reference's `get_rays` contract (nerf/utils.py:182-304).
 
-Full-image rays come from the HIP kernel (`raymarching.generate_rays`); pixel subsets (`coords`, random pixels,
-random patches, and the error-map / incoherent-mask draws of utils.py:214-259) are selected on the device with
-torch ops and gathered from it -- no host round trip in a training step.
+Full-image rays come from the HIP kernel `raymarching.generate_rays`; pixel subsets (`coords`, random pixels, random
+patches, and the error-map / incoherent-mask draws of utils.py:214-259) are drawn on the device with torch ops and
+turned into rays by `raymarching.rays_from_pixels`, with one camera per ray if asked -- no host round trip and no
+H x W intermediate in a training step.
 """
 from __future__ import annotations
 
@@ -14,17 +15,21 @@ from ..raymarching import generate_rays
 
 def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, coords=None, device="cuda", incoherent_mask=None,
              include_incoherent_region=False, incoherent_mask_size=128, random_sample=False):
-    """poses [1,4,4] cam2world, intrinsics [4] ndarray or [1,4] tensor -> dict(rays_o, rays_d[, i, j], inds_coarse)."""
+    """poses [1 or N,4,4] cam2world, intrinsics [4] ndarray or [1 or N,4] tensor -> dict(rays_o, rays_d[, i, j], inds_coarse).
+
+    N <= 0: every pixel of one camera (HIP generate_rays).  N > 0: the reference's four ways of drawing N pixels
+    (utils.py:209-263: given `coords`, random patches, error-map / incoherent-mask multinomial, uniform) on the device,
+    and rays of exactly those pixels from `rays_from_pixels` -- with one camera per ray when `poses` has N entries
+    (provider.py:908-913, `random_image_batch`).  The full H x W image is never generated for a subset."""
+    from ..raymarching import rays_from_pixels
     if torch.is_tensor(poses):
         device = poses.device if poses.is_cuda else device
+    pose = (poses if torch.is_tensor(poses) else torch.as_tensor(np.asarray(poses, dtype=np.float32))).reshape(-1, 4, 4)
+    n_cam = pose.shape[0]
     if isinstance(intrinsics, np.ndarray):
-        intr = [float(v) for v in intrinsics.reshape(-1)[:4]]
+        intr_t = torch.as_tensor(intrinsics.reshape(-1)[:4].astype(np.float32)).reshape(1, 4)
     else:
-        intr = [float(v) for v in intrinsics.reshape(-1, 4)[0].tolist()]
-    pose = poses.reshape(-1, 4, 4)
-    if pose.shape[0] != 1:
-        raise NotImplementedError("get_rays: one camera per call (the reference's loaders use batch size 1)")
-    rays_o, rays_d = generate_rays(pose[0], intr, H, W, device=device)
+        intr_t = intrinsics.reshape(-1, 4).float()
     results = {}
     if N > 0:
         if coords is not None:
@@ -59,10 +64,17 @@ def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, coords=None, device="c
             results["inds_coarse"] = inds_coarse                                   # the caller updates its error map with these
         else:
             inds = torch.randint(0, H * W, size=[N], device=device)
-        rays_o, rays_d = rays_o[inds], rays_d[inds]
+        n_rays = inds.shape[0]
+        if n_cam not in (1, n_rays) or intr_t.shape[0] not in (1, n_rays):
+            raise RuntimeError(f"get_rays: {n_cam} poses / {intr_t.shape[0]} intrinsics for {n_rays} rays (each must be 1 or one per ray)")
+        rays_o, rays_d = rays_from_pixels(pose.to(device), intr_t.to(device), inds, W)
         results["i"] = inds % W
         results["j"] = torch.div(inds, W, rounding_mode="floor")
     else:
+        if n_cam != 1:
+            raise RuntimeError("get_rays: a full image needs exactly one camera")
+        intr = [float(v) for v in intr_t.reshape(-1)[:4].tolist()]
+        rays_o, rays_d = generate_rays(pose[0], intr, H, W, device=device)
         inds = torch.arange(H * W, device=device)
     results["rays_o"] = rays_o
     results["rays_d"] = rays_d

@@ -47,6 +47,23 @@ def generate_rays(pose, intrinsics, H: int, W: int, device="cuda", row_begin: in
     return rays_o, rays_d
 
 
+def rays_from_pixels(poses: torch.Tensor, intrinsics: torch.Tensor, inds: torch.Tensor, W: int):
+    """Rays through the flat pixel indices `inds` [N] (row-major, width W): poses [1 or N, 4, 4] and intrinsics
+    [1 or N, 4] on the device, one camera for all rays or one per ray (nerf/utils.py:209-287 with the per-ray cameras of
+    provider.py:908-913).  Everything stays on the device."""
+    inds = inds.reshape(-1).contiguous().long()
+    N = inds.shape[0]
+    poses = poses.reshape(-1, 16).contiguous().float()
+    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    rays_o = torch.empty(N, 3, device=inds.device, dtype=torch.float32)
+    rays_d = torch.empty(N, 3, device=inds.device, dtype=torch.float32)
+    _lib.check(_lib.lib().sn_rm_rays_from_pixels(_lib.dev(poses, "poses"), poses.shape[0], _lib.dev(intrinsics, "intrinsics"),
+                                                 intrinsics.shape[0], _lib.dev(inds, "inds", torch.int64), int(W), N,
+                                                 _lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.stream()),
+               "rays_from_pixels")
+    return rays_o, rays_d
+
+
 def _host_values(t) -> list:
     """Host copy of a small device tensor, memoised on the tensor object (keyed by its in-place version counter): a
     device->host read per call would put a synchronisation into every training step and forbids graph capture."""

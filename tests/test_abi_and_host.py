@@ -211,3 +211,60 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     assert heads.s_grid.embeddings.requires_grad and heads.mask_mlp[0].net[0].weight.requires_grad
     bare = NeRFNetwork(make_opt())
     assert load_checkpoint(bare, base.state_dict()) == ([], [], {})          # bare state_dict branch (trainer.py:1793-1796)
+
+
+def test_checkpoint_layout_equals_the_reference(tmp_path):
+    """tests/golden/checkpoint_layout.json was captured from the REFERENCE's NeRFNetwork (tools/gen_ckpt_fixture.py): ordered
+    state_dict keys / shapes / dtypes, Adam param-group structure of get_params, top-level checkpoint keys and the stats
+    dictionary of trainer.py:151-157, 1685-1718 -- for every training mode of main.py."""
+    import json
+    from sanerf_hq_amd.nerf import NeRFNetwork, load_checkpoint, save_checkpoint
+    lay = json.load(open(os.path.join(ROOT, "tests", "golden", "checkpoint_layout.json")))
+    for mode, kw in (("rgb", {}), ("sam", dict(with_sam=True)), ("mask", dict(with_mask=True)), ("sam+mask", dict(with_sam=True, with_mask=True))):
+        ref = lay["modes"][mode]
+        model = NeRFNetwork(make_opt(**kw))
+        sd = model.state_dict()
+        ours = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+        assert ours == ref["state_dict"], f"{mode}: state_dict differs from the reference's (order, shapes or dtypes)"
+        for k, v in ref["small_buffers"].items():
+            assert sd[k].tolist() == v, f"{mode}: buffer {k}"
+        groups = model.get_params(1e-2)
+        optim = torch.optim.Adam([dict(params=list(g["params"]), lr=g["lr"]) for g in groups], betas=(0.9, 0.99), eps=1e-15)
+        assert [len(g["params"]) for g in optim.state_dict()["param_groups"]] == ref["param_groups"]
+        if mode != "mask":
+            continue
+        # a checkpoint as the reference writes it (full=True) loads into the product and round-trips through the writer
+        sched = torch.optim.lr_scheduler.LambdaLR(optim, lambda it: 1.0)
+        path = os.path.join(tmp_path, "ngp_ep0003.pth")
+        state = save_checkpoint(model, path, epoch=3, global_step=77, optimizer=optim, lr_scheduler=sched)
+        assert set(lay["top_level_keys_default"]) <= set(state) and set(state) <= set(lay["top_level_keys_full"])
+        assert list(state["stats"]) == list(lay["stats"]) and state["stats"] == lay["stats"]
+        fresh = NeRFNetwork(make_opt(**kw))
+        missing, unexpected, loaded = load_checkpoint(fresh, path, map_location="cpu")
+        assert missing == [] and unexpected == [] and loaded["epoch"] == 3 and loaded["global_step"] == 77
+        assert torch.equal(fresh.mask_mlp[0].net[0].weight, model.mask_mlp[0].net[0].weight)
+        # an RGB-mode reference checkpoint into the mask model: only the new heads are missing (main.py:243-256)
+        rgb_sd = {k: torch.zeros(shape, dtype=getattr(torch, dt)) for k, shape, dt in lay["modes"]["rgb"]["state_dict"]}
+        missing, unexpected, _ = load_checkpoint(fresh, {"model": rgb_sd, "epoch": 1, "global_step": 1, "stats": lay["stats"]})
+        assert unexpected == [] and sorted(missing) == sorted(k for k, _, _ in ref["state_dict"] if k.startswith(("m_grid", "mask_mlp")))
+
+
+def test_sam_feature_cache_container(tmp_path):
+    """<workspace>/sam_cache/<img_name>.npy, float32 [256,64,64] (trainer.py:1069-1079), read back as [1,256,64,64] (:924-926)."""
+    from sanerf_hq_amd.nerf import SamFeatureCache, feature_map
+    cache = SamFeatureCache(str(tmp_path))
+    f = torch.randn(1, 256, 64, 64)
+    path = cache.store("frame_00012", f)
+    assert path == os.path.join(str(tmp_path), "sam_cache", "frame_00012.npy") and "frame_00012" in cache and "nope" not in cache
+    raw = np.load(path)
+    assert raw.dtype == np.float32 and raw.shape == (256, 64, 64)              # what the reference's np.save wrote / np.load expects
+    back = cache.load("frame_00012")
+    assert back.shape == (1, 256, 64, 64) and torch.equal(back, f)
+    np.save(os.path.join(cache.path, "bad.npy"), np.zeros((64, 64), np.float64))
+    with pytest.raises(ValueError, match="float32"):
+        cache.load("bad")
+    # rendered per-ray features -> the map the reference compares with the cached target (trainer.py:536-542)
+    samvit = torch.randn(32 * 32, 256)
+    m = feature_map(samvit, 32, 32, size=(64, 64))
+    want = torch.nn.functional.interpolate(samvit.reshape(1, 32, 32, 256).permute(0, 3, 1, 2), (64, 64), mode="bilinear")
+    assert m.shape == (1, 256, 64, 64) and torch.equal(m, want)

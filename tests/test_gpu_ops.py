@@ -659,3 +659,34 @@ def test_device_exp_matches_the_oracle_bit_for_bit(gpu, orc):
     ref = np.exp(x[ok].astype(np.float64))
     assert np.max(np.abs(got[ok] - ref) / ref) < 2.5e-7            # <= ~2 ulp of the correctly rounded value
     assert got[x == np.float32(-np.inf)][0] == 0.0 and np.isinf(got[x == np.float32(np.inf)][0]) and np.isnan(got[np.isnan(x)]).all()
+
+
+def test_get_rays_one_camera_per_ray_matches_the_reference(gpu):
+    """provider.py:908-913 (`random_image_batch`): one image index per ray -> poses [N,4,4], intrinsics [N,4].  Fixture =
+    the reference's own get_rays output (tools/gen_rays_fixture.py)."""
+    from helpers import golden
+    from sanerf_hq_amd.nerf import get_rays
+    from sanerf_hq_amd import raymarching as rm
+    g = golden("rays_multi")
+    H, W = [int(v) for v in g["HW"]]
+    cams, intr = torch.from_numpy(g["cams"]).to(gpu), torch.from_numpy(g["intr"]).to(gpu)
+    index = torch.from_numpy(g["index"]).to(gpu)
+    coords = torch.from_numpy(g["coords"]).to(gpu)
+    res = get_rays(cams[index], intr[index], H, W, coords.shape[0], coords=coords, incoherent_mask_size=32)
+    assert np.array_equal(res["rays_o"].cpu().numpy(), g["rays_o"])
+    np.testing.assert_allclose(res["rays_d"].cpu().numpy(), g["rays_d"], rtol=0, atol=3e-7)
+    assert np.array_equal(res["i"].cpu().numpy(), g["i"]) and np.array_equal(res["j"].cpu().numpy(), g["j"])
+    assert np.array_equal(res["inds_coarse"].cpu().numpy(), g["inds_coarse"])
+    # every ray equals the ray of the same pixel in its own camera's full image (bit for bit: same kernel arithmetic)
+    for k in range(cams.shape[0]):
+        sel = (index == k).nonzero().reshape(-1)
+        if sel.numel() == 0:
+            continue
+        ro, rd = rm.generate_rays(cams[k], intr[k].tolist(), H, W, device=gpu)
+        flat = coords[sel, 0] * W + coords[sel, 1]
+        assert torch.equal(res["rays_d"][sel], rd[flat]) and torch.equal(res["rays_o"][sel], ro[flat])
+    # uniform draw with per-ray cameras, the training call of provider.py:972-977
+    draw = get_rays(cams[index], intr[index], H, W, index.numel(), random_sample=True)
+    assert draw["rays_d"].shape == (index.numel(), 3) and int(draw["i"].max()) < W and int(draw["j"].max()) < H
+    with pytest.raises(RuntimeError, match="poses"):
+        get_rays(cams[:3], intr[:1], H, W, 10, random_sample=True)
