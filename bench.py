@@ -171,16 +171,20 @@ def main():
     raygen_ms = ev[0].elapsed_time(ev[1]) / 10
     n_local = rays_o.shape[0]
 
-    def measure(schedule, tables, n_steps, n_warm, rays=None, gather=multi):
+    def measure(schedule, tables, n_steps, n_warm, rays=None, gather=multi, compact=False, aabb=None):
         """K timed whole-image renders (+ all-gather when `gather`) of one configuration.
-        rays = (rays_o, rays_d, width, n_total): another image than the bench line's (no gather)."""
+        rays = (rays_o, rays_d, width, n_total): another image than the bench line's (no gather).
+        compact / aabb: the opt-in live-sample compaction (cfg.compact_live) and a replacement aabb (`also` entries only)."""
         r_o, r_d, r_w, n_total = rays if rays is not None else (rays_o, rays_d, W, total_rays)
         steps = [128] if schedule == "flat128" else [128, 64, 32]
         if schedule not in models:
             params = synth.synthetic_params(steps, seed=0)
             models[schedule] = (params, synth.product_model(params, steps, False, dev))
         params, model = models[schedule]
-        plan = rm.RenderPlan(model, steps, torch.float16 if tables == "f16" else torch.float32)
+        plan = rm.RenderPlan(model, steps, torch.float16 if tables == "f16" else torch.float32, compact_live=compact)
+        if aabb is not None:
+            for i in range(6):
+                plan.cfg.aabb[i] = aabb[i]
         out = {}
         # N > 1: the all-gather of frame k (RCCL, its own stream, over xGMI) overlaps the render of frame k+1; two
         # rotating image buffers, everything in flight is drained inside the timed region
@@ -321,6 +325,17 @@ def main():
             also[f"c4_1600x1600_{sch}_f32"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
                                                "num_steps": r["steps"], "tables": "f32", "rays": H4 * H4}
         del ro4, rd4
+        # opt-in live-sample compaction (not reference behaviour, off in every line above): a scene whose aabb
+        # two thirds of the rays miss (renderer.py:133-135), default kernels vs k_final_stage_cmp; images are bit-equal
+        box = [-0.25, -0.25, -0.25, 0.25, 0.25, 0.25]
+        for sch in ("flat128", "ref"):
+            r0 = measure(sch, "f32", 3, 1, aabb=box)
+            img0 = r0["out"]["image"].clone()
+            r1 = measure(sch, "f32", 3, 1, aabb=box, compact=True)
+            also[f"compact_live_small_aabb_{sch}_f32"] = {
+                "ms_default_kernels": round(r0["ms_per_step"], 4), "ms_compact_live": round(r1["ms_per_step"], 4),
+                "rays_missing_the_aabb": round(float((r1["out"]["weights_sum"] == 0).float().mean()), 4),
+                "image_bit_equal": bool(torch.equal(img0, r1["out"]["image"])), "num_steps": r1["steps"]}
         out = m["out"]
 
     cpu_baseline = None

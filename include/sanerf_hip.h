@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 4
+#define SN_ABI_VERSION 5
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -224,6 +224,16 @@ typedef struct sn_render_cfg {
      * cannot).  1: exact fp32 v_mfma_f32_32x32x2_f32 (no range limit, ~2.2x slower final stage).  The environment
      * variable SN_RENDER_MLP (f16x3 / mfma32 / valu) overrides this field. */
     int32_t      mlp_exact_fp32;
+    /* opt-in, NOT reference behaviour: the last stage runs with per-ray termination and wave-level compaction of live
+     * samples (k_final_stage_cmp).  A ray stops taking samples once its transmittance is below early_stop_eps (if > 0),
+     * rays that miss the aabb (renderer.py:133-135: near = far = 1e9) and lanes beyond the image edge take none, and each
+     * wave deals its 64 evaluation slots (gather lanes, rows of the MFMA tile) out to the rays still live, found with a
+     * ballot + prefix count per iteration.  With nothing to skip the outputs are bit-identical to the default kernel; a
+     * terminated ray changes every output by at most ~eps * |feature|; a missed ray gets weights_sum = depth = 0 and the
+     * background colour (the reference marches such rays through inf / NaN distances; with its default options every
+     * weight comes out 0 as well).  Ignored (default kernel runs) when per-sample outputs or the feature stage are on,
+     * for tables the FinalLv fast path does not cover, and in the exact-fp32 / VALU MLP modes. */
+    int32_t      compact_live;
 } sn_render_cfg;
 
 typedef struct sn_render_io {

@@ -40,7 +40,8 @@ class RenderCfg(C.Structure):
                 ("grid", GridDesc), ("grid_mlp", MlpDesc), ("view_mlp", MlpDesc),
                 ("sh_degree", C.c_uint32), ("aabb", C.c_float * 6), ("min_near", C.c_float), ("bound", C.c_float),
                 ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float),
-                ("feat_grid", GridDesc), ("with_feat", C.c_int32), ("early_stop_eps", C.c_float), ("mlp_exact_fp32", C.c_int32)]
+                ("feat_grid", GridDesc), ("with_feat", C.c_int32), ("early_stop_eps", C.c_float), ("mlp_exact_fp32", C.c_int32),
+                ("compact_live", C.c_int32)]
 
 
 class RenderIO(C.Structure):
@@ -55,7 +56,7 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 4   # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 5   # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),

@@ -658,7 +658,15 @@ struct PropArgs {
     float *dbg_bins, *dbg_w, *dbg_sigma;  // [N,T+1], [N,T], [N,T] or NULL
     int32_t *dbg_inds;                    // [N,Tn+1] or NULL
     PairTab pairs;                        // dense levels as aligned x-pairs
+    int skip_miss;                        // the last stage runs k_final_stage_cmp: waves whose rays all miss the aabb leave at once
 };
+
+// renderer.py:133-135: near = far = 1e9 marks a ray that misses the aabb
+__device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &rs) {
+    float nr, fr;
+    near_far_one(rs.o, rs.d, rc.aabb, rc.min_near, nr, fr);
+    return nr == 1e9f && fr == 1e9f;
+}
 
 template <typename TT, int L, int C, int HID, int K>
 __global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
@@ -675,6 +683,9 @@ __global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
     const uint32_t Npad = a.rc.Npad;
     RaySetup rs;
     setup_ray(a.rc, n, rs);
+    // opt-in compaction (cfg->compact_live): k_final_stage_cmp gives rays that miss the aabb (and lanes beyond the image
+    // edge) no samples and never reads their bins, so a wave made of such rays only has nothing to produce (no barrier follows)
+    if (a.skip_miss && __all(!ok || ray_misses(a.rc, rs))) return;
     const uint32_t T = a.T;
     const float b0step = 1.0f / (float)T;                 // (1-0)/(steps-1), steps = T+1
 
@@ -1466,6 +1477,249 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
 }
 
 // ------------------------------------------------------------------------------------------
+// final stage with per-ray termination and wave-level compaction of live samples (opt-in: cfg->compact_live)
+// ------------------------------------------------------------------------------------------
+// k_final_stage walks every ray of a wave through all T samples in lock-step; a gather instruction, an MFMA or a vector
+// instruction costs the same with 1 or 64 lanes active, so a ray that is already opaque (early_stop_eps), a ray that
+// misses the aabb (renderer.py:133-135) or a lane beyond the image edge only saves time once the WHOLE wave is dead.
+// Here a lane is no longer tied to a ray during the sample evaluation:
+//   * home lane r keeps ray r's compositing state (optical depth, colour features, next unassigned sample);
+//   * every iteration the wave ballots the rays that still want samples, ranks them with mbcnt (prefix count of the
+//     ballot) and deals its 64 evaluation slots out to them round-robin: slot s evaluates sample j_r + s / L of the
+//     (s mod L)-th live ray (ds_permute builds the compacted list, ds_bpermute hands out ray ids and cursors), up to
+//     CMP_KMAX consecutive samples per ray and iteration -> the 64 rows of every MFMA tile and every gather instruction
+//     are filled with live samples only;
+//   * slots write (delta*sigma, geometry features, t_mid) to LDS, home lanes composite their own samples in ascending
+//     order exactly like k_final_stage (fp64 optical depth, one fmaf chain per channel) and decide termination.
+// The assignment of iteration i+1 is made before iteration i has been composited (its first gather group is in flight
+// across the matrix-core phase, as in k_final_stage), so a ray that dies in iteration i still occupies its slots of
+// iteration i+1; their results are dropped.  With nothing to skip (every ray live for all T samples) slot s IS ray s and
+// the outputs are bit-identical to k_final_stage.  Per-ray state of the slots (origin, direction, spacing) sits in the 4
+// padding dwords of the wave's two feature-slab images, the per-sample records reuse the slab rows: no extra LDS.
+constexpr uint32_t CMP_KMAX = 4;
+
+template <typename TT, int K>
+__global__ __launch_bounds__(256, 2) void k_final_stage_cmp(FinalArgs a) {
+    constexpr int L = 16, GEO = 15, NSH = 16, NCOL = GEO + NSH, VH = 32, PG = 4, IN = 32;
+    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;
+    constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;
+    static_assert(K >= PG && K <= 8, "FinalLv instantiation");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += 256u)
+        reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    float *wave_base = lds + PACK_FLOATS + wave * WAVE_SLAB;
+    uint32_t *slab_hi = reinterpret_cast<uint32_t *>(wave_base), *slab_lo = slab_hi + 64 * SLAB_STRIDE;
+    float *fe = wave_base + lane;
+    __syncthreads();
+    clock_probe(0);
+
+    uint32_t n;
+    const uint32_t wg = tile_id(a.rc);
+    const bool ok = ray_of_lane(a.rc, wg, n);
+    const uint32_t col0 = wg * 256u + wave * 64u;                 // scratch column of the wave's lane 0
+    const uint32_t Npad = a.rc.Npad, T = a.T;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    bool alive = ok;
+    if (ray_misses(a.rc, rs)) alive = false;              // renderer.py:133-135; it is skipped here (weights 0)
+    // ray table in the slab's padding columns (dwords 16..19 of each 20-dword row)
+    *reinterpret_cast<float4 *>(slab_hi + lane * SLAB_STRIDE + 16) = make_float4(rs.o[0], rs.o[1], rs.o[2], rs.s_near);
+    *reinterpret_cast<float4 *>(slab_lo + lane * SLAB_STRIDE + 16) = make_float4(rs.d[0], rs.d[1], rs.d[2], rs.s_far);
+    __builtin_amdgcn_wave_barrier();
+    const float b0step = 1.0f / (float)T;
+    auto bin_col = [&](uint32_t j, uint32_t col) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + col];
+        if (a.bins0_tab) return a.bins0_tab[j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+
+    // ---- home-lane state ----
+    float fimg[GEO];
+#pragma unroll
+    for (int c = 0; c < GEO; ++c) fimg[c] = 0.0f;
+    float dep = 0.0f;
+    double cum = 0.0, wsum = 0.0;
+    uint32_t j_cur = 0;                                           // next sample of this ray not yet assigned to a slot
+
+    // ---- assignment of the wave's 64 slots ----
+    struct Assign { uint32_t L, rank, n; };                       // live rays (uniform); this ray's rank and sample count
+    uint32_t s_ray = lane, s_j = 0;                               // slot view: ray (lane index inside the wave) and sample
+    auto assign = [&](Assign &as) {
+        const bool want = alive && j_cur < T;
+        const uint64_t M = __ballot(want);
+        const uint32_t Lc = (uint32_t)__popcll(M);
+        as.L = Lc; as.rank = 0; as.n = 0;
+        if (Lc == 0u) { s_ray = lane; s_j = T - 1u; return; }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+        const uint32_t dst = want ? rank : Lc + (lane - rank);    // a permutation: live rays first, in lane order
+        const uint32_t list = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)lane);
+        const uint32_t inv = (uint32_t)(65536.0f / (float)Lc) + 1u;   // (x * inv) >> 16 == x / Lc for x < 64, Lc <= 64
+        const uint32_t q = (lane * inv) >> 16, rnk = lane - q * Lc;
+        s_ray = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rnk << 2), (int)list);
+        const uint32_t jr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_ray << 2), (int)j_cur);
+        const uint32_t sj = jr + q;
+        s_j = (q < CMP_KMAX && sj < T) ? sj : T - 1u;             // surplus slots redo an in-range sample; nobody reads them
+        uint32_t cnt = (((63u - rank) * inv) >> 16) + 1u;         // slots rank, rank + L, ... below 64
+        cnt = umin(umin(cnt, CMP_KMAX), T - umin(j_cur, T));
+        as.rank = rank; as.n = want ? cnt : 0u;
+        j_cur += as.n;
+    };
+    float tmid_n, delta_n, p_n[3], x01_n[3];
+    bool last_n;
+    auto slot_geometry = [&]() {
+        const float4 A = *reinterpret_cast<const float4 *>(slab_hi + s_ray * SLAB_STRIDE + 16);
+        const float4 B = *reinterpret_cast<const float4 *>(slab_lo + s_ray * SLAB_STRIDE + 16);
+        RaySetup q;
+        q.o[0] = A.x; q.o[1] = A.y; q.o[2] = A.z; q.s_near = A.w;
+        q.d[0] = B.x; q.d[1] = B.y; q.d[2] = B.z; q.s_far = B.w;
+        const uint32_t col = col0 + s_ray;
+        const float rb_prev = real_bin(q, bin_col(s_j, col)), rb_next = real_bin(q, bin_col(s_j + 1u, col));
+        tmid_n = (rb_next + rb_prev) / 2.0f;
+        delta_n = rb_next - rb_prev;
+        last_n = s_j == T - 1u;
+        sample_x01(a.rc, q, tmid_n, p_n, x01_n);
+    };
+
+    Assign cur, nxt;
+    GroupRegs<TT, 2, PG> g0;
+    assign(cur);
+    slot_geometry();
+    bool fast_n = all_interior(a.lv, x01_n);
+    issue_group_lv<TT, PG, K, 0, false>(a.lv, x01_n, g0);
+    __builtin_amdgcn_sched_barrier(0);
+    while (cur.L != 0u) {
+        const float tmid = tmid_n, delta = delta_n;
+        const bool last = last_n;
+        const float x01[3] = {x01_n[0], x01_n[1], x01_n[2]};
+        float h[16];
+        uint32_t *row_hi = slab_hi + lane * SLAB_STRIDE, *row_lo = slab_lo + lane * SLAB_STRIDE;
+        auto emit = [&](int l, const float (&acc)[2]) {
+            uint32_t ph, pl;
+            split2(acc[0], acc[1], ph, pl);
+            row_hi[l] = ph;
+            row_lo[l] = pl;
+        };
+        blend_group<TT, 2, PG, K, 0>(g0, emit);
+        __builtin_amdgcn_sched_barrier(0);
+        auto rest = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            static_for<1, L / PG>([&](auto gg) {
+                constexpr int GRP = decltype(gg)::value;
+                GroupRegs<TT, 2, PG> gr;
+                issue_group_lv<TT, PG, K, GRP, FAST>(a.lv, x01, gr);
+                __builtin_amdgcn_sched_barrier(0);
+                blend_group<TT, 2, PG, K, GRP>(gr, emit);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if (__builtin_expect(fast_n, 1)) rest(std::true_type{});
+        else {
+            rest(std::false_type{});
+            const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+            if (__builtin_expect(__any(oob), 0)) {
+                if (oob) for (int l = 0; l < L; ++l) { row_hi[l] = 0u; row_lo[l] = 0u; }
+            }
+        }
+        // next assignment (from the termination state of one iteration ago) + its first gather group
+        assign(nxt);
+        slot_geometry();
+        fast_n = all_interior(a.lv, x01_n);
+        issue_group_lv<TT, PG, K, 0, false>(a.lv, x01_n, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_wave_barrier();
+        grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+        __builtin_amdgcn_wave_barrier();
+        {   // per-sample record of this slot: [delta*sigma | 15 geometry features] in its hi row, t_mid in its lo row
+            const float sigma = expf_det(h[0]);
+            float ds = delta * sigma;
+            if (a.rc.last_opaque && last) ds = __builtin_inff();
+            float4 *rec = reinterpret_cast<float4 *>(row_hi);
+            rec[0] = make_float4(ds, h[1], h[2], h[3]);
+            rec[1] = make_float4(h[4], h[5], h[6], h[7]);
+            rec[2] = make_float4(h[8], h[9], h[10], h[11]);
+            rec[3] = make_float4(h[12], h[13], h[14], h[15]);
+            reinterpret_cast<float *>(row_lo)[0] = tmid;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- compositing by the home lanes, samples in ascending order (renderer.py:308-338) ----
+#pragma unroll 1
+        for (uint32_t k = 0; k < CMP_KMAX; ++k) {
+            const bool mine = k < cur.n && alive;
+            if (!__any(mine)) break;
+            if (mine) {
+                const uint32_t slot = cur.rank + k * cur.L;
+                const float4 *rec = reinterpret_cast<const float4 *>(slab_hi + slot * SLAB_STRIDE);
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                const float tm = reinterpret_cast<const float *>(slab_lo + slot * SLAB_STRIDE)[0];
+                const float g[GEO] = {r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+                const float ds = r0.x;
+                const float alpha = 1.0f - expf_det(-ds);
+                const float tr = expf_det(-(float)cum);
+                float w = alpha * tr;
+                if (w != w) w = 0.0f;
+                cum += (double)ds;
+                wsum += (double)w;
+                dep = __builtin_fmaf(w, tm, dep);
+#pragma unroll
+                for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, g[c], fimg[c]);
+                if (a.stop_cum > 0.0f && (float)cum > a.stop_cum) alive = false;   // remaining weights sum to < eps
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+    }
+    clock_probe(1);
+
+    // ---- per-ray colour head (as in k_final_stage) ----
+    __syncthreads();
+    stage_weights<NCOL, VH>(lds, a.vw[0]);
+    stage_weights<VH, VH>(lds + VW0, a.vw[1]);
+    stage_weights<VH, 3>(lds + VW0 + VW1, a.vw[2]);
+    __syncthreads();
+    float dirn[3] = {rs.d[0], rs.d[1], rs.d[2]};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float aa = dirn[0] * dirn[0], bb = dirn[1] * dirn[1], cc = dirn[2] * dirn[2];
+        const float nrm = sqrtf((aa + bb) + cc);
+        dirn[0] = dirn[0] / nrm; dirn[1] = dirn[1] / nrm; dirn[2] = dirn[2] / nrm;
+    }
+    const float ws = (float)wsum;
+    float sh[NSH];
+    sh_degree4(dirn[0], dirn[1], dirn[2], sh);
+#pragma unroll
+    for (int c = 0; c < GEO; ++c) fe[c * 64] = fimg[c];
+#pragma unroll
+    for (int c = 0; c < NSH; ++c) fe[(GEO + c) * 64] = sh[c] * ws;
+    static_assert(IN * 64 <= 2 * 64 * SLAB_STRIDE, "view MLP activations reuse the slab");
+    dense_ldsw_col<NCOL, VH, 1>(lds, fe, fe, 64u);
+    dense_ldsw_col<VH, VH, 1>(lds + VW0, fe, fe, 64u);
+    float rgb[3];
+    {
+        float v2[VH];
+#pragma unroll
+        for (int k = 0; k < VH; ++k) v2[k] = fe[k * 64];
+        dense_ldsw<VH, 3, 0>(lds + VW0 + VW1, v2, rgb);
+    }
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float sg = 1.0f / (1.0f + expf_det(-rgb[c]));
+            const float bgm = (1.0f - ws) * a.rc.bg;
+            a.image[(size_t)n * 3 + c] = sg + bgm;
+        }
+        a.depth[n] = dep;
+        a.wsum[n] = ws;
+        if (a.dbg_fimg) {
+#pragma unroll
+            for (int c = 0; c < GEO; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
+#pragma unroll
+            for (int c = 0; c < NSH; ++c) a.dbg_fimg[(size_t)n * NCOL + GEO + c] = sh[c] * ws;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // final stage, sample-parallel variant for small linear-order batches (the counterpart of k_prop_stage_sp)
 // ------------------------------------------------------------------------------------------
 // 4096 rays are 16 workgroups of k_final_stage, each wave alone on its SIMD for T serial samples of ~19 us.  Here
@@ -2103,6 +2357,16 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         for (uint32_t k = 0; k + 1 < S; ++k) { rcp = pack_pairs(&cfg->prop_grid[k], gl_prop[k], prop_pairs[k]); if (rcp) return rcp; }
     }
 
+    // opt-in compaction: k_final_stage_cmp replaces the last stage when nothing per-sample leaves the call (those tensors
+    // must be complete) and the table has the FinalLv shape; the proposal stages then drop waves of missed rays as well
+    bool use_cmp = false;
+    if (cfg->compact_live && mlp_mode == MLP_F16X3 && !cfg->with_feat && !io->xyzs_last && !io->geo_feat_last) {
+        bool any_dbg = false;
+        for (uint32_t k = 0; k < S; ++k) any_dbg = any_dbg || io->bins[k] || io->weights[k] || io->sigmas[k] || io->inds[k];
+        FinalLv probe;
+        use_cmp = !any_dbg && dense_prefix(gl_main) == 5 &&
+                  build_final_lv(gl_main, 5, pairs, cfg->grid.embeddings, 2u * (cfg->grid.table_dtype == SN_F16 ? 2u : 4u), probe);
+    }
     const uint32_t W = io->tile_w;
     const uint32_t chunk = chunk_rays(io->N, W);
     for (uint32_t first = 0; first < io->N; first += chunk) {
@@ -2129,6 +2393,10 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         {   // SN_RENDER_XCD=0 disables the XCD-aware tile order (A/B switch)
             const char *xs = getenv("SN_RENDER_XCD");
             rc.xcd_swizzle = !(xs && xs[0] == '0');
+            // compaction: workgroups differ in cost by the number of live rays of their tile; a contiguous tile range per
+            // XCD would leave the XCDs that own empty image bands idle (measured on the small-aabb scene: 4.4 instead of
+            // 3.0 ms), so tiles go round-robin over the XCDs in dispatch order
+            if (use_cmp) rc.xcd_swizzle = 0;
         }
 
         // scratch carve-up
@@ -2151,6 +2419,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             pa.dbg_sigma = io->sigmas[k] ? io->sigmas[k] + (size_t)first * pa.T : nullptr;
             pa.dbg_inds = io->inds[k + 1] ? io->inds[k + 1] + (size_t)first * (pa.Tn + 1) : nullptr;
             pa.pairs = prop_pairs[k];
+            pa.skip_miss = use_cmp ? 1 : 0;
             {
                 ProfScope ps(st, PK_PROP0 + (int)k);
                 const int K = dense_prefix(gl_prop[k]);
@@ -2218,7 +2487,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = (SN_FINAL_LV && !lv_ok) ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
         // few rays in linear order: lanes share rays (k_final_stage_sp); fewer samples per lane while CUs would idle
-        const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && n <= final_sp_max_rays() &&
+        const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && !use_cmp && n <= final_sp_max_rays() &&
                               fa.T <= 64u * FSP_MAX_SPL;
         if (final_sp) {
             auto lpr_log2_of = [&](uint32_t sl) { const uint32_t need = div_up(fa.T, 1u << sl); uint32_t l2 = 0; while ((1u << l2) < need) ++l2; return l2; };
@@ -2236,6 +2505,16 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             if (Kmain == 5) { if (f16) SN_LAUNCH_FINAL_SP(__half, 5); else SN_LAUNCH_FINAL_SP(float, 5); }
             else { if (f16) SN_LAUNCH_FINAL_SP(__half, -1); else SN_LAUNCH_FINAL_SP(float, -1); }
 #undef SN_LAUNCH_FINAL_SP
+        } else if (use_cmp) {
+            // per-ray termination + live-sample compaction (k_final_stage_cmp); f_image stays available
+            const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
+            if (f16) {
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_cmp<__half, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL((k_final_stage_cmp<__half, 5>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+            } else {
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_cmp<float, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL((k_final_stage_cmp<float, 5>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+            }
         } else if (mlp_mode == MLP_F16X3) {
             if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
             else SN_LAUNCH_FINAL_AUX(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);

@@ -163,11 +163,12 @@ class NeRFRenderer(nn.Module):
         field to skip it)."""
         tensors = self._plan_tensors(with_feat)
         key = (tuple((t.data_ptr(), t.dtype, t.device) for t in tensors), tuple(self.opt.num_steps), self.render_table_dtype,
-               with_feat, float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0))
+               with_feat, float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0), bool(getattr(self.opt, "compact_live", False)))
         if self._plan is None or self._plan_key != key:
             self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype,
                                        feat_encoder=self.s_grid if with_feat else None,
-                                       early_stop_eps=float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0))
+                                       early_stop_eps=float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0),
+                                       compact_live=bool(getattr(self.opt, "compact_live", False)))
             self._plan_key = key
         elif not getattr(self, "render_tables_static", False):
             self._plan.refresh_tables()        # also re-checks the fp16 range guard when parameters changed

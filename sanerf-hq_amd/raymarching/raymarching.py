@@ -404,7 +404,7 @@ class RenderPlan:
     the module keeps its fp32 parameters); arithmetic stays fp32 either way."""
 
     def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32, feat_encoder=None,
-                 early_stop_eps: float = 0.0):
+                 early_stop_eps: float = 0.0, compact_live: bool = False):
         self.keep: list = []
         cfg = _lib.RenderCfg()
         S = len(num_steps)
@@ -447,6 +447,7 @@ class RenderPlan:
             cfg.with_feat = 1
             self.feat_dim = feat_encoder.output_dim
         cfg.early_stop_eps = float(early_stop_eps)      # opt-in transmittance early-out of the last stage (0 = reference behaviour)
+        cfg.compact_live = int(bool(compact_live))      # opt-in per-ray termination + live-sample compaction (k_final_stage_cmp)
         self.cfg = cfg
         self._range_model = model
         self._range_versions = None

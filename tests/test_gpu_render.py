@@ -475,6 +475,80 @@ def test_early_stop_is_opt_in_and_bounded(gpu, orc):
     assert torch.equal(full["image"], base["image"])
 
 
+def test_compact_live_is_bit_identical_when_nothing_is_skipped(gpu, orc):
+    """SURVEY 8f-1 / north_star "wavefront prefix-scan compaction of live samples": k_final_stage_cmp deals a wave's 64
+    evaluation slots out to the rays still live.  On the contracted scene no ray misses and, without an eps, none
+    terminates: slot s is ray s and every output must equal the default kernel's bit for bit -- image tiles (incl. a
+    width that leaves lanes beyond the image edge dead from the start), linear ray order, both table precisions."""
+    from sanerf_hq_amd import raymarching as rm
+    for steps in ([128], [128, 64, 32], [7]):
+        params = synthetic_params(steps, seed=11)
+        model = product_model(params, steps, False, gpu)
+        for (H, W, tile) in ((48, 64, True), (40, 72, True), (30, 50, False)):
+            _, _, ro, rd = camera_rays(orc, H, W)
+            ro, rd = torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu)
+            for dt in (torch.float32, torch.float16):
+                a = rm.render_rays(rm.RenderPlan(model, steps, dt), ro, rd, tile_w=W if tile else 0, want=["f_image"])
+                a = {k: v.clone() for k, v in a.items()}
+                b = rm.render_rays(rm.RenderPlan(model, steps, dt, compact_live=True), ro, rd, tile_w=W if tile else 0, want=["f_image"])
+                for k in ("image", "depth", "weights_sum", "f_image"):
+                    assert torch.equal(a[k], b[k]), (steps, H, W, tile, dt, k, float((a[k] - b[k]).abs().max()))
+
+
+def test_compact_live_per_ray_termination_is_bounded(gpu, orc):
+    """Per-ray transmittance termination on top of the compaction: a ray stops taking samples once exp(-optical depth)
+    < eps, so what is dropped weighs less than eps in total -- the same bound as the wave-granular early-out, per ray."""
+    from sanerf_hq_amd import raymarching as rm
+    steps = [128]
+    params = synthetic_params(steps, seed=3, gain=40.0)          # sigma ~0 or huge: about half of all samples lie behind an opaque one
+    model = product_model(params, steps, False, gpu)
+    H, W = 64, 64
+    _, _, ro, rd = camera_rays(orc, H, W)
+    ro, rd = torch.from_numpy(ro).to(gpu), torch.from_numpy(rd).to(gpu)
+    base = {k: v.clone() for k, v in rm.render_rays(rm.RenderPlan(model, steps), ro, rd, tile_w=W, want=["f_image", "geo_feat_last"]).items()}
+    eps = 1e-4
+    for dt in (torch.float32, torch.float16):
+        ref = base if dt == torch.float32 else {k: v.clone() for k, v in rm.render_rays(rm.RenderPlan(model, steps, dt), ro, rd, tile_w=W, want=["f_image", "geo_feat_last"]).items()}
+        on = rm.render_rays(rm.RenderPlan(model, steps, dt, early_stop_eps=eps, compact_live=True), ro, rd, tile_w=W, want=["f_image"])
+        assert float((on["weights_sum"] - ref["weights_sum"]).abs().max()) <= 1.01 * eps
+        fmax = float(ref["geo_feat_last"].abs().max())
+        assert float((on["f_image"] - ref["f_image"]).abs().max()) <= 1.01 * eps * max(fmax, 1.0)
+        assert float((on["image"] - ref["image"]).abs().max()) <= 1e-4          # the RGB contract survives the opt-in
+    # per-sample outputs requested -> the default kernel runs (they must be complete)
+    full = rm.render_rays(rm.RenderPlan(model, steps, early_stop_eps=eps, compact_live=True), ro, rd, tile_w=W, want=["weights"])
+    assert torch.equal(full["image"], base["image"])
+
+
+def test_compact_live_skips_rays_that_miss_the_aabb(gpu, orc):
+    """renderer.py:133-135: a ray that misses the aabb gets near = far = 1e9.  The reference (and the default kernel, and
+    the oracle) still march it -- through infinite distances; with a single stage every delta is inf - inf, every weight
+    NaN -> 0, so the pixel is the background colour.  k_final_stage_cmp never assigns such a ray a slot: same image and
+    weights_sum bit for bit (hit AND missed rays), depth equal on hit rays and 0 instead of NaN on missed ones."""
+    from sanerf_hq_amd import raymarching as rm
+    H, W = 64, 80
+    _, _, ro_h, rd_h = camera_rays(orc, H, W)
+    ro, rd = torch.from_numpy(ro_h).to(gpu), torch.from_numpy(rd_h).to(gpu)
+    box = [-0.25, -0.25, -0.25, 0.25, 0.25, 0.25]
+    nears, fars = orc.near_far_from_aabb(ro_h, rd_h, np.asarray(box, np.float32), 0.2)
+    miss = torch.from_numpy(((nears == np.float32(1e9)) & (fars == np.float32(1e9))).reshape(-1)).to(gpu)
+    assert 0.2 < float(miss.float().mean()) < 0.9                 # the scene has both kinds
+    for steps in ([128], [128, 64, 32]):                          # with proposal stages: waves of missed rays leave those too
+        params = synthetic_params(steps, seed=5)
+        model = product_model(params, steps, False, gpu)
+        outs = []
+        for compact in (False, True):
+            plan = rm.RenderPlan(model, steps, compact_live=compact)
+            for i in range(6):
+                plan.cfg.aabb[i] = box[i]
+            outs.append({k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W).items()})
+        a, b = outs
+        assert torch.equal(a["image"], b["image"]) and torch.equal(a["weights_sum"], b["weights_sum"]), steps
+        assert torch.equal(a["depth"][~miss], b["depth"][~miss]), steps
+        assert float(b["weights_sum"][miss].abs().max()) == 0.0 and float(b["depth"][miss].abs().max()) == 0.0
+        want = orc.render(oracle_cfg(orc, params, steps, aabb=box), ro_h, rd_h)
+        assert np.abs(b["image"].cpu().numpy() - want["image"].reshape(-1, 3)).max() < 1e-5
+
+
 def test_rgb_training_step_vs_reference_fixture(gpu, orc):
     """RGB-mode training step (trainer.py:360-392): MSE + lambda_proposal * proposal_loss
     (renderer.py:30-57) with every parameter trainable; loss terms and gradients against the reference's autograd

@@ -67,7 +67,30 @@ def main():
     t_on = timeit(lambda: rm.render_rays(p_on, ro8, rd8, tile_w=W))
     d = float((rm.render_rays(p_on, ro8, rd8, tile_w=W)["weights_sum"] - rm.render_rays(p_off, ro8, rd8, tile_w=W)["weights_sum"]).abs().max())
     out["early_stop_opaque_field_800x800_flat128"] = {"ms_off": round(t_off * 1e3, 3), "ms_eps_1e-4": round(t_on * 1e3, 3), "max_abs_weights_sum_diff": d}
+    # ---- live-sample compaction (k_final_stage_cmp, cfg.compact_live): per-ray termination on the same opaque field, ----
+    # ---- and a scene whose aabb most rays miss (renderer.py:133-135), single stage and the reference schedule         ----
+    base_ws = rm.render_rays(p_off, ro8, rd8, tile_w=W)["weights_sum"].clone()
+    p_cmp, p_cmp0 = rm.RenderPlan(dense, steps, early_stop_eps=1e-4, compact_live=True), rm.RenderPlan(dense, steps, compact_live=True)
+    t_cmp, t_cmp0 = timeit(lambda: rm.render_rays(p_cmp, ro8, rd8, tile_w=W)), timeit(lambda: rm.render_rays(p_cmp0, ro8, rd8, tile_w=W))
+    d = float((rm.render_rays(p_cmp, ro8, rd8, tile_w=W)["weights_sum"] - base_ws).abs().max())
+    out["compact_live_opaque_field_800x800_flat128"] = {"ms_default_kernel": round(t_off * 1e3, 3), "ms_wave_early_out_eps_1e-4": round(t_on * 1e3, 3),
+                                                        "ms_compact_eps_1e-4": round(t_cmp * 1e3, 3), "ms_compact_nothing_to_skip": round(t_cmp0 * 1e3, 3),
+                                                        "max_abs_weights_sum_diff": d}
     del dense
+    box = [-0.25, -0.25, -0.25, 0.25, 0.25, 0.25]
+    for sch in ([128], [128, 64, 32]):
+        soft = product_model(synthetic_params(sch, seed=5), sch, False, dev)
+        plans = [rm.RenderPlan(soft, sch), rm.RenderPlan(soft, sch, compact_live=True)]
+        for pl in plans:
+            for i in range(6):
+                pl.cfg.aabb[i] = box[i]
+        ts = [timeit(lambda pl=pl: rm.render_rays(pl, ro8, rd8, tile_w=W)) for pl in plans]
+        o0, o1 = ({k: v.clone() for k, v in rm.render_rays(pl, ro8, rd8, tile_w=W).items()} for pl in plans)
+        out["compact_live_small_aabb_800x800_" + "_".join(map(str, sch))] = {
+            "ms_default_kernel": round(ts[0] * 1e3, 3), "ms_compact": round(ts[1] * 1e3, 3),
+            "rays_missing_the_aabb": round(float((o1["weights_sum"] == 0).float().mean()), 4),
+            "image_bit_equal": bool(torch.equal(o0["image"], o1["image"]))}
+        del soft
     # ---- C5 ----
     model = build(False, True, dev).train()
     for n_, p in model.named_parameters():
