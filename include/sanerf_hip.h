@@ -290,6 +290,21 @@ int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const fl
                         const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
                         sn_stream_t stream);
 
+/* Mask head (nerf/renderer.py:304-305, 376-385; network.py:104, 118-123) in one kernel:
+ *   out[n, :] = sum_t weights[n,t] * mask_mlp(cat([m_grid(xyzs[n,t]), extra[n,t]]))        out [N, dims[num_layers]]
+ * xyzs [N,T,3] (contracted sample positions; x01 = (xyz + bound) / (2 bound) as gridencoder/grid.py:156), extra [N,T,E]
+ * (the detached geometry features, E <= 16), weights [N,T].  Every lane of the matrix-core MLP kernel interpolates one
+ * level of its own sample straight into the first layer's B operand and the epilogue composites the logits, so neither
+ * the [N*T, L*8+E] input nor the [N*T, n_inst] logits are written.  Needs a 3-D fp32 grid with level_dim 8, hidden width
+ * 256, <= 32 outputs, no skip layers, T a power of two <= 128; anything else returns SN_ERR_UNSUPPORTED and the caller
+ * composes sn_grid_encode_forward_cat + sn_mlp_wide_forward + sn_rm_composite.  Inference only.  Range of the split-fp16
+ * arithmetic as sn_mlp_wide_forward (the overflow flag is not raised by this entry).  workspace >=
+ * sn_rm_mask_head_workspace_bytes(), 16-byte aligned. */
+size_t sn_rm_mask_head_workspace_bytes(const sn_mlp_desc *mlp);
+int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights, uint32_t N, uint32_t T, uint32_t E,
+                    float bound, const sn_grid_desc *grid, const sn_mlp_desc *mlp, float *out,
+                    void *workspace, size_t workspace_bytes, sn_stream_t stream);
+
 /* Weight gradient of an nn.Linear over a training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order
  * (deterministic).  K, N <= 64 (the radiance / proposal MLPs, nerf/network.py:9-29): register-tiled VALU kernel.
  * Otherwise N <= 256, any K (the per-sample mask head and the SAM head, network.py:31-66): v_mfma_f32_32x32x2_f32 over

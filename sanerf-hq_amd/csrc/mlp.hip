@@ -22,6 +22,7 @@
 // layer's 256 outputs, 16 k-steps), then x-input k-steps (layer 0 and skip layers; input width padded
 // to a multiple of 16).  Chunk = [mt 8][hi|lo][lane 64] uint4.
 #include "sn_common.h"
+#include <string.h>
 #include <type_traits>
 
 namespace sn {
@@ -54,6 +55,12 @@ struct WideArgs {
     float ln_eps;
     uint32_t N, din, nl, leaky, total_chunks, xs, out_lds;
     WideLayer layer[SN_MAX_LAYERS];
+    // XMODE 3 (sn_rm_mask_head): the input row of sample n is cat([grid(xyz[n]), extra[n]]) and is never materialised
+    const float *xyz, *extra, *wts;       // [N,3] positions, [N,E] appended channels, [N] compositing weights (N = rays * T)
+    const float *table;                   // grid rows, C = 8 floats (fp32)
+    uint32_t T, E;                        // samples per ray; appended channels (<= 16)
+    float bound, inv_den;                 // x01 = (xyz + bound) / (2 bound); inv_den = 1 / (2 bound) when that is exact, else 0
+    GridLevels g;
 };
 
 struct PackArgs {
@@ -192,6 +199,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         if (tid < 32u) lds_x[(uint32_t)WIDE_ROWS * xs + tid] = 0.0f;         // slack read by the last row's last k-step
     }
 
+    // XMODE 3: per-level constants where a lane can index them by ITS level (the two half-waves work on different levels)
+    uint32_t *lds_lv = reinterpret_cast<uint32_t *>(lds_x);             // [4][SN_MAX_LEVELS]: res, size, mode, off
+    float x01[3] = {0.0f, 0.0f, 0.0f};
+    bool x_oob = false;
+    if constexpr (XMODE == 3) {
+        if (tid < (uint32_t)SN_MAX_LEVELS) {
+            lds_lv[tid] = a.g.res[tid]; lds_lv[SN_MAX_LEVELS + tid] = a.g.size[tid];
+            lds_lv[2 * SN_MAX_LEVELS + tid] = a.g.mode[tid]; lds_lv[3 * SN_MAX_LEVELS + tid] = a.g.off[tid];
+        }
+        const float *p = a.xyz + (size_t)(ok ? n : a.N - 1u) * 3u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {   // grid.py:156
+            const float t = p[d] + a.bound;
+            x01[d] = a.inv_den != 0.0f ? t * a.inv_den : t / (2.0f * a.bound);
+            x_oob = x_oob || x01[d] < 0.0f || x01[d] > 1.0f;                // gridencoder.cu:105-130: zeros outside [0,1]
+        }
+    }
+
     floatx16 acc[WIDE_MT];
     uint4 hbh[WIDE_HKS], hbl[WIDE_HKS];                                  // previous layer's outputs as B operands
 #pragma unroll
@@ -299,6 +324,57 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
     };
 
+    // XMODE 3: k-step kx of the input is levels 2 kx (low half-wave) and 2 kx + 1 (high half-wave) of the C = 8 grid: every
+    // lane interpolates ONE level of its own sample -- its 8 features are exactly the lane's 8 B-operand values -- from 8
+    // corner rows of 32 bytes (two 16-byte loads each; arithmetic as grid.hip:k_grid_forward, gridencoder.cu:94-201).
+    // The gathers of k-step kx + 1 are in flight across the 24 MFMAs of k-step kx.
+    struct LevelRegs { float pos[3]; float cv[8][8]; };
+    auto issue_level = [&](uint32_t kx, LevelRegs &r) {
+        const uint32_t level = umin(2u * kx + half, a.g.L - 1u);
+        const uint32_t res = lds_lv[level], size = lds_lv[SN_MAX_LEVELS + level], mode = lds_lv[2 * SN_MAX_LEVELS + level];
+        const float *tab = a.table + (size_t)lds_lv[3 * SN_MAX_LEVELS + level] * 8u;
+        float deriv[3];
+        uint32_t cell[3];
+        grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, r.pos, deriv, cell);
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8u; ++idx) {
+            uint32_t p[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3u; ++d) p[d] = (idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
+            load_row<float, 8>(tab + (size_t)grid_row<3>(p, res, size, mode) * 8u, r.cv[idx]);
+        }
+    };
+    auto blend_level = [&](uint32_t kx, const LevelRegs &r, uint4 &bh, uint4 &bl) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 0.0f;
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8u; ++idx) {
+            float w = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3u; ++d) w *= (idx & (1u << d)) ? r.pos[d] : 1.0f - r.pos[d];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = __builtin_fmaf(w, r.cv[idx][c], v[c]);
+        }
+        const bool zero = x_oob || 2u * kx + half >= a.g.L;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = zero ? 0.0f : v[c];
+        split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
+        split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
+    };
+    auto extra_operand = [&](uint4 &bh, uint4 &bl) {                     // the appended channels: extra[n][8 half + 0..7], zero padded
+        float v[8];
+        const float *row = a.extra + (size_t)(ok ? n : a.N - 1u) * a.E;
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+            const uint32_t c = 8u * half + i;
+            const float t = row[c < a.E ? c : a.E - 1u];
+            v[i] = c < a.E ? t : 0.0f;
+        }
+        split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
+        split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
+    };
+
     for (uint32_t l = 0; l < a.nl; ++l) {
         const WideLayer L = a.layer[l];
         // bias -> accumulator init (register r of this lane is neuron 32 mt + (r&3) + 8 (r>>2) + 4 half)
@@ -315,10 +391,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #pragma unroll
             for (int k = 0; k < WIDE_HKS; ++k) run_chunk(hbh[k], hbl[k], npairs);
         }
+        if constexpr (XMODE == 3) {
+            if (L.x_ks) {
+                const uint32_t gks = (a.g.L + 1u) >> 1;                   // k-steps that carry grid levels; one more for the extras
+                LevelRegs lr;
+                issue_level(0u, lr);
+                for (uint32_t k = 0; k < gks; ++k) {
+                    uint4 bh, bl;
+                    blend_level(k, lr, bh, bl);
+                    if (k + 1u < gks) issue_level(k + 1u, lr);
+                    run_chunk(bh, bl, npairs);
+                }
+                if (a.E) {
+                    uint4 bh, bl;
+                    extra_operand(bh, bl);
+                    run_chunk(bh, bl, npairs);
+                }
+            }
+        } else {
         for (uint32_t k = 0; k < L.x_ks; ++k) {
             uint4 bh, bl;
             x_operand(k, bh, bl);
             run_chunk(bh, bl, npairs);
+        }
         }
         if (l + 1u < a.nl) {
             // activation (network.py:65-66) + split into the next layer's B operands
@@ -350,6 +445,51 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(acc[mt][r], 0.0f, chk);
         if (ok && chk != chk) g_wide_overflow = 1;
+    }
+    if constexpr (XMODE == 3) {
+        // renderer.py:384: out[ray, m] = sum_t w[ray, t] * logits[ray, t, m].  Rows are samples in [ray][t] order and T divides
+        // 128 or is a multiple of 32 that divides 128 (checked on the host): a ray's samples sit in T consecutive lanes of one
+        // half-wave image (T <= 32) or in T / 32 whole waves of this workgroup.  Fixed reduction tree: deterministic.
+        const float w = ok ? a.wts[n] : 0.0f;
+        const uint32_t Tl = a.T < 32u ? a.T : 32u;                        // lanes (rows) of one wave that share a ray
+        float sum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = w * acc[0][r];
+#pragma unroll
+            for (uint32_t d = 1; d < 32u; d <<= 1) { const float o = __shfl_xor(t, (int)d, 32); t = d < Tl ? t + o : t; }
+            sum[r] = t;
+        }
+        const uint32_t j = lane & 31u;
+        float *part = reinterpret_cast<float *>(lds_w);                  // [4 waves][32 neurons]: the weight ring is dead
+        if (a.T > 32u) {
+            __syncthreads();
+            if (j == 0u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[wave * 32u + (r & 3) + 8u * (r >> 2) + 4u * half] = sum[r];
+            }
+            __syncthreads();
+            const uint32_t wpr = a.T >> 5;                                // waves per ray: 2 or 4
+            if (j == 0u && (wave % wpr) == 0u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = (r & 3) + 8u * (r >> 2) + 4u * half;
+                    float t = sum[r];
+                    for (uint32_t q = 1; q < wpr; ++q) t += part[(wave + q) * 32u + m];
+                    sum[r] = t;
+                }
+            }
+            if ((wave % wpr) != 0u) return;
+        }
+        if (ok && (j % Tl) == 0u) {
+            float *orow = a.out + (size_t)(n / a.T) * LL.out;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = (r & 3) + 8u * (r >> 2) + 4u * half;
+                if (m < LL.out) orow[m] = sum[r];
+            }
+        }
+        return;
     }
     float mean = 0.0f, rstd = 1.0f;
     if (a.ln_w) {
@@ -537,6 +677,77 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
 #undef SN_MLP_LAUNCH
     SN_LAUNCH_CHECK("k_mlp_wide");
+    return SN_OK;
+}
+
+// Mask head in one kernel (renderer.py:304-305, 376-385): k_mlp_wide<3> builds each sample's MLP input -- the C = 8 hash-grid
+// levels of its position and the appended geometry channels -- in registers, straight into the B operands of the first
+// layer, and composites the per-sample logits with the ray's weights in its epilogue.  Neither the [N*T, 143] input nor
+// the [N*T, n_inst] logits exist in memory.
+extern "C" size_t sn_rm_mask_head_workspace_bytes(const sn_mlp_desc *mlp) { return sn_mlp_wide_workspace_bytes(mlp); }
+
+extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights, uint32_t N, uint32_t T, uint32_t E,
+                               float bound, const sn_grid_desc *grid, const sn_mlp_desc *mlp, float *out,
+                               void *workspace, size_t workspace_bytes, sn_stream_t stream) {
+    SN_REQUIRE(grid && mlp, "mask_head: grid/mlp is NULL");
+    if (N == 0) return SN_OK;
+    SN_REQUIRE(xyzs && weights && out && workspace && (extra || E == 0), "mask_head: xyzs/extra/weights/out/workspace must be device pointers");
+    SN_REQUIRE(table_aligned(workspace) && grid->embeddings && table_aligned(grid->embeddings), "mask_head: workspace / table must be 16-byte aligned");
+    SN_REQUIRE(bound > 0.0f, "mask_head: bound must be positive");
+    if (!(grid->D == 3 && grid->C == 8 && grid->table_dtype == SN_F32 && grid->L >= 1 && grid->L <= SN_MAX_LEVELS && E <= 16u)) {
+        set_error("mask_head: fused path needs a 3-D fp32 grid with level_dim 8 (network.py:104) and <= 16 appended channels "
+                  "(got D=%u C=%u dtype=%d E=%u)", grid->D, grid->C, (int)grid->table_dtype, E);
+        return SN_ERR_UNSUPPORTED;
+    }
+    if (!(T >= 1 && T <= 128u && (T & (T - 1u)) == 0u)) {
+        set_error("mask_head: samples per ray must be a power of two <= 128 for the in-kernel compositing (got %u)", T);
+        return SN_ERR_UNSUPPORTED;
+    }
+    const uint32_t nl = mlp->num_layers;
+    SN_REQUIRE(mlp->dims[0] == grid->L * 8u + E, "mask_head: mlp input width %u != %u grid features + %u appended", mlp->dims[0], grid->L * 8u, E);
+    SN_REQUIRE((grid->L & 1u) == 0u || E == 0u, "mask_head: an odd number of levels cannot be followed by appended channels");
+    PackArgs pa;
+    size_t u4 = 0;
+    int rc = wide_plan(mlp, pa.layer, &u4);
+    if (rc) return rc;
+    if (mlp->dims[nl] > 32u || mlp->skip_mask != 0u) {
+        set_error("mask_head: fused path composites at most 32 outputs and no skip layers (got %u outputs, skip mask %u)", mlp->dims[nl], mlp->skip_mask);
+        return SN_ERR_UNSUPPORTED;
+    }
+    SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mask_head: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
+    const uint64_t rows64 = (uint64_t)N * T;
+    SN_REQUIRE(rows64 < (1ull << 32), "mask_head: N*T does not fit 32 bits");
+    const uint32_t rows = (uint32_t)rows64, width = mlp->dims[0];
+    hipStream_t st = (hipStream_t)stream;
+    pa.din = width; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace);
+    uint32_t max_threads = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        pa.w[l] = mlp->weight[l];
+        pa.in_dim[l] = l == 0 ? width : (uint32_t)WIDE;
+        const uint32_t nks = (pa.layer[l].uses_h ? WIDE_HKS : 0) + pa.layer[l].x_ks;
+        const uint32_t th = nks * (uint32_t)WIDE_MT * 64u;
+        if (th > max_threads) max_threads = th;
+    }
+    hipLaunchKernelGGL(k_pack_mlp_wide, dim3(div_up(max_threads, 256), nl), dim3(256), 0, st, pa);
+    SN_LAUNCH_CHECK("k_pack_mlp_wide");
+    WideArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.out = out; wa.pack = pa.pack;
+    wa.N = rows; wa.din = width; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
+    for (uint32_t l = 0; l < nl; ++l) { wa.bias[l] = mlp->bias[l]; wa.layer[l] = pa.layer[l]; }
+    wa.xyz = xyzs; wa.extra = extra; wa.wts = weights; wa.table = reinterpret_cast<const float *>(grid->embeddings);
+    wa.T = T; wa.E = E; wa.bound = bound;
+    {
+        int e = 0;
+        const float m = frexpf(2.0f * bound, &e);
+        wa.inv_den = (m == 0.5f && e > -100 && e < 100) ? 1.0f / (2.0f * bound) : 0.0f;
+    }
+    rc = build_grid_levels(&wa.g, grid->offsets, grid->D, grid->C, grid->L, grid->S, grid->H, grid->gridtype, (int)grid->align_corners, grid->interp);
+    if (rc) return rc;
+    const size_t lds = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 4u * SN_MAX_LEVELS * sizeof(uint32_t);
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mlp_wide<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);
+    SN_LAUNCH_CHECK("k_mlp_wide<3>");
     return SN_OK;
 }
 

@@ -15,6 +15,7 @@ Two execution paths:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -231,6 +232,13 @@ class NeRFRenderer(nn.Module):
                 results["samvit"] = samvit.view(H, W, -1)
         if return_mask > 0:                                 # renderer.py:304-305, 376-385
             if opt.mask_mlp_type == "default":
+                mlp = self.mask_mlp[0]
+                if (not torch.is_grad_enabled() and weights.is_cuda and len(self.mask_mlp) == 1
+                        and rm.mask_head_fusable(self.m_grid, mlp, weights.shape[1], geo_feat.shape[-1])
+                        and os.environ.get("SN_MASK_HEAD", "fused") != "unfused"):
+                    # inference: grid gather -> matrix-core MLP -> compositing in one kernel, nothing per-sample written
+                    results["instance_mask_logits"] = rm.mask_head(weights, xyzs, geo_feat, self.m_grid, mlp, self.bound)
+                    return
                 if torch.is_grad_enabled() and self.m_grid.embeddings.requires_grad:
                     mlp_in = torch.cat([self.m_grid(xyzs, bound=self.bound), geo_feat.detach()], dim=-1)
                 else:   # inference: features and geometry channels land in one [.., 143] buffer in a single pass

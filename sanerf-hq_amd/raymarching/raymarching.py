@@ -378,6 +378,42 @@ def mlp_forward(x: torch.Tensor, mlp, layer_norm: Optional[torch.nn.LayerNorm] =
     return out
 
 
+def mask_head_fusable(encoder, mlp, T: int, E: int) -> bool:
+    """Can sn_rm_mask_head take this head (renderer.py:376-385)?  fp32 3-D grid with level_dim 8, 256-wide MLP without skip
+    layers and at most 32 outputs, a power-of-two number of samples per ray <= 128, at most 16 appended channels."""
+    return (encoder.input_dim == 3 and encoder.level_dim == 8 and encoder.embeddings.dtype == torch.float32
+            and (encoder.num_levels % 2 == 0 or E == 0) and E <= 16 and 1 <= T <= 128 and (T & (T - 1)) == 0
+            and getattr(mlp, "dim_hidden", 0) == 256 and mlp.dim_out <= 32 and not (getattr(mlp, "skip_layers", None) or [])
+            and mlp.dim_in == encoder.output_dim + E)
+
+
+def mask_head(weights: torch.Tensor, xyzs: torch.Tensor, extra: torch.Tensor, encoder, mlp, bound: float) -> torch.Tensor:
+    """composite(weights, mlp(cat([encoder(xyzs, bound), extra], -1))) in ONE kernel (renderer.py:304-305, 376-385):
+    weights [N,T], xyzs [N,T,3], extra [N,T,E] -> [N, mlp.dim_out].  Inference only; see mask_head_fusable()."""
+    N, T = weights.shape
+    E = int(extra.shape[-1]) if extra is not None else 0
+    assert xyzs.shape == (N, T, 3)
+    L = _lib.lib()
+    w = weights.detach().contiguous().float()
+    x = xyzs.detach().contiguous().float()
+    e = extra.detach().contiguous().float() if E else None
+    gdesc = _lib.GridDesc()
+    _fill_grid(gdesc, encoder, encoder.embeddings.detach().contiguous())
+    mdesc = _lib.MlpDesc()
+    keep: list = []
+    _fill_mlp(mdesc, list(mlp.net), mlp.dim_in, keep)
+    mdesc.activation = 1 if getattr(mlp, "skip_layers", None) is not None else 0      # SkipConnMLP: LeakyReLU(0.01)
+    need = int(L.sn_rm_mask_head_workspace_bytes(C.byref(mdesc)))
+    if need == 0:
+        raise RuntimeError("mask_head: " + L.sn_last_error().decode())
+    ws = torch.empty(need, dtype=torch.uint8, device=w.device)
+    out = torch.empty(N, mdesc.dims[mdesc.num_layers], device=w.device, dtype=torch.float32)
+    _lib.check(L.sn_rm_mask_head(_lib.dev(x, "xyzs"), _lib.dev(e, "extra"), _lib.dev(w, "weights"), N, T, E, float(bound),
+                                 C.byref(gdesc), C.byref(mdesc), _lib.dev(out, "out"), ws.data_ptr(), ws.numel(), _lib.stream()),
+               "sn_rm_mask_head")
+    return out
+
+
 def _fill_mlp(desc: _lib.MlpDesc, layers: Sequence[torch.nn.Linear], dim_in: int, keep: list) -> None:
     desc.num_layers = len(layers)
     desc.activation = 0

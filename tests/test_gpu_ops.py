@@ -532,6 +532,58 @@ def test_wide_mlp_matches_oracle_and_torch(gpu, orc, kind, N):
     assert float((got - ref_t).abs().max()) <= 1e-4 * max(scale, 1.0), "vs torch / rocBLAS"
 
 
+@pytest.mark.parametrize("N,T_,n_inst,bound", [(300, 32, 2, 2.0), (37, 128, 2, 2.0), (501, 8, 5, 2.0), (130, 64, 3, 1.5), (1000, 1, 2, 2.0), (64, 16, 32, 2.0)])
+def test_fused_mask_head_equals_its_unfused_composition(gpu, orc, N, T_, n_inst, bound):
+    """sn_rm_mask_head (renderer.py:304-305, 376-385 in one kernel: every lane interpolates one m_grid level of its own
+    sample into the first layer's B operand, logits composited in the epilogue) against the three-kernel composition it
+    replaces -- m_grid.forward_cat -> mlp_forward -> composite, each pinned to the oracle elsewhere -- and against the
+    oracle's fp32 MLP on those features.  Same feature arithmetic and MLP kernel; only the summation tree of the
+    compositing differs."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=8, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).to(gpu)
+    with torch.no_grad():
+        enc.embeddings.copy_(T(synth.hash_uniform(tuple(enc.embeddings.shape), 77, -1.0, 1.0), gpu))
+    mlp = SkipConnMLP(143, n_inst, 256, 3, skip_layers=[], bias=False).to(gpu)
+    with torch.no_grad():
+        for i, lin in enumerate(mlp.net):
+            lin.weight.copy_(T(synth.linear_weight(lin.weight.shape[0], lin.weight.shape[1], 500 + i, 2.0), gpu))
+    rng = np.random.default_rng(N + T_)
+    xyz = T(rng.uniform(-bound, bound, (N, T_, 3)).astype(np.float32), gpu)
+    xyz[0, 0, 0] = bound * 1.5                                        # outside the grid: zero features (gridencoder.cu:105-130)
+    geo = T(rng.standard_normal((N, T_, 15)).astype(np.float32), gpu)
+    w = T(rng.uniform(0, 0.2, (N, T_)).astype(np.float32), gpu)
+    assert rm.mask_head_fusable(enc, mlp, T_, 15)
+    got = rm.mask_head(w, xyz, geo, enc, mlp, bound)
+    with torch.no_grad():
+        mlp_in = enc.forward_cat(xyz, geo, bound=bound)
+        logits = rm.mlp_forward(mlp_in.reshape(-1, 143), mlp).reshape(N, T_, n_inst)
+        ref = rm.composite(w, logits)
+    assert got.shape == (N, n_inst)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 2e-6 * scale * max(1, T_ // 8)
+    om = orc.make_mlp([l.weight.detach().cpu().numpy() for l in mlp.net], None, "leaky", [])
+    ref_o = (orc.mlp_forward(om, mlp_in.reshape(-1, 143).cpu().numpy()).reshape(N, T_, n_inst) * w.cpu().numpy()[..., None]).sum(1)
+    assert np.abs(got.cpu().numpy() - ref_o).max() <= 1e-4 * scale
+    again = rm.mask_head(w, xyz, geo, enc, mlp, bound)
+    assert torch.equal(got, again)                                    # fixed reduction tree: deterministic
+
+
+def test_fused_mask_head_rejects_what_it_cannot_do(gpu):
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    enc8 = GridEncoder(input_dim=3, num_levels=16, level_dim=8, base_resolution=16, log2_hashmap_size=12, desired_resolution=64).to(gpu)
+    enc2 = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=12, desired_resolution=64).to(gpu)
+    mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+    assert not rm.mask_head_fusable(enc8, mlp, 33, 15)                # samples per ray not a power of two
+    assert not rm.mask_head_fusable(enc2, SkipConnMLP(47, 2, 256, 3, skip_layers=[], bias=False).to(gpu), 32, 15)
+    x, g, w = torch.zeros(4, 33, 3, device=gpu), torch.zeros(4, 33, 15, device=gpu), torch.zeros(4, 33, device=gpu)
+    with pytest.raises(RuntimeError, match="power of two"):
+        rm.mask_head(w, x, g, enc8, mlp, 2.0)
+
+
 def test_wide_mlp_rejects_unsupported_shapes(gpu):
     """sn_mlp_wide_forward states its limits through the error channel instead of computing something else."""
     from sanerf_hq_amd import raymarching as rm

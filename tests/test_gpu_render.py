@@ -163,6 +163,23 @@ def test_heads_vs_reference_fixture(gpu, orc):
     np.testing.assert_allclose(out["instance_mask_logits"].cpu().numpy(), g["instance_mask_logits"], rtol=0, atol=RGB_TOL)
 
 
+def test_mask_head_fused_and_unfused_routes_agree(gpu, orc, monkeypatch):
+    """NeRFRenderer._heads at inference: the one-kernel mask head (default) vs the three-kernel route it replaced
+    (SN_MASK_HEAD=unfused), both against the reference fixture."""
+    g = golden("render_heads")
+    params = params_from_spec(spec_of(g))
+    model = product_model(params, [128, 64, 32], True, gpu)
+    n_side = int(g["HW"][2])
+    outs = {}
+    for route in ("fused", "unfused"):
+        monkeypatch.setenv("SN_MASK_HEAD", route)
+        with torch.no_grad():
+            outs[route] = model.render(T(g["rays_o"], gpu), T(g["rays_d"], gpu), staged=False, perturb=False, return_mask=1,
+                                       H=n_side, W=n_side)["instance_mask_logits"].clone()
+        np.testing.assert_allclose(outs[route].cpu().numpy(), g["instance_mask_logits"], rtol=0, atol=RGB_TOL)
+    assert float((outs["fused"] - outs["unfused"]).abs().max()) <= 1e-5
+
+
 def test_mask_training_step_vs_reference_fixture(gpu, orc):
     """BASELINE configs[4]: forward+backward of m_grid + mask_mlp under the mask NLL (trainer.py:401-428,473),
     radiance field frozen; grads within 1e-3 of the reference's autograd."""

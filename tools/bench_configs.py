@@ -56,6 +56,22 @@ def main():
     out["C3_sam_head_400x400"] = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
     del model
     torch.cuda.empty_cache()
+    # ---- mask head at inference (renderer.py:304-305, 376-385): 400x400, [128,64,32]: the one-kernel head vs the three-kernel route ----
+    model = build(False, True, dev).eval()
+
+    def mask_render():
+        with torch.no_grad():
+            return model.render(ro, rd, staged=False, perturb=False, return_mask=1, H=H, W=W, tile_w=W)
+    os.environ["SN_MASK_HEAD"] = "unfused"
+    t_unf = timeit(mask_render)
+    ref_logits = mask_render()["instance_mask_logits"].clone()
+    os.environ["SN_MASK_HEAD"] = "fused"
+    t_fus = timeit(mask_render)
+    dlog = float((mask_render()["instance_mask_logits"] - ref_logits).abs().max())
+    out["mask_head_400x400"] = {"ms_fused_head": round(t_fus * 1e3, 3), "ms_three_kernel_head": round(t_unf * 1e3, 3),
+                                "rgb_only_ms": round(t_rgb * 1e3, 3), "max_abs_logit_diff": dlog}
+    del model
+    torch.cuda.empty_cache()
     # ---- opt-in early termination on an opaque field: 800x800, [128], MLP gain 40 (sigma ~0 or huge) ----
     from helpers import product_model  # noqa: E402
     steps = [128]
