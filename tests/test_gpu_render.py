@@ -285,6 +285,84 @@ def test_full_size_properties(gpu, orc):
     np.testing.assert_allclose(dep[idx].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
 
 
+def test_config3_full_size_heads_spot_checked(gpu, orc):
+    """BASELINE configs[2] at its full size (400x400 rays, [128,64,32], 256-d SAM-feature head + mask head): finite,
+    deterministic, tile order == linear order for the heads, and 256 random pixels against the CPU oracle."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    steps = [128, 64, 32]
+    params = synthetic_params(steps, heads=True, seed=21)
+    model = product_model(params, steps, True, gpu)
+    H = W = 400
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    with torch.no_grad():
+        a = model.render(ro, rd, staged=False, perturb=False, return_feats=1, return_mask=1, H=H, W=W, tile_w=W)
+        a = {k: v.clone() for k, v in a.items() if torch.is_tensor(v)}
+        b = model.render(ro, rd, staged=False, perturb=False, return_feats=1, return_mask=1, H=H, W=W, tile_w=W)
+    for k in ("image", "samvit", "instance_mask_logits"):
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], b[k]), k
+    assert a["samvit"].shape == (H, W, 256) and a["instance_mask_logits"].shape == (H * W, 2)
+    idx = (synth.hash_u01(256, 9) * (H * W)).astype(np.int64)
+    want = orc.render(oracle_cfg(orc, params, steps, heads=True), ro[idx].cpu().numpy(), rd[idx].cpu().numpy())
+    np.testing.assert_allclose(a["image"][idx].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a["samvit"].reshape(-1, 256)[idx].cpu().numpy(), want["samvit"], rtol=0, atol=RGB_TOL)
+    np.testing.assert_allclose(a["instance_mask_logits"][idx].cpu().numpy(), want["instance_mask_logits"], rtol=0, atol=RGB_TOL)
+
+
+def test_config5_full_size_training_step_properties(gpu, orc):
+    """BASELINE configs[4] at its full size (4096 rays, mask NLL, radiance field frozen): the forward logits of 256 random
+    rays against the CPU oracle; the table gradient from the sorted backward against the atomic backward (two independent
+    HIP paths) within the 1e-3 budget; exact linearity of the backward in the upstream gradient; every
+    untouched row's gradient exactly zero."""
+    from sanerf_hq_amd import ops, raymarching as rm, synth
+    from helpers import make_opt
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    steps = [128, 64, 32]
+    params = synthetic_params(steps, heads=True, seed=31)
+    model = NeRFNetwork(make_opt(with_mask=True))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    model = model.to(gpu).train()
+    for n_, p in model.named_parameters():
+        p.requires_grad_(n_.startswith("m_grid") or n_.startswith("mask_mlp"))
+    H = W = 512
+    N = 4096
+    roF, rdF = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    pix = torch.from_numpy((synth.hash_u01(N, 99) * (H * W)).astype(np.int64)).to(gpu)
+    ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
+    labels = torch.from_numpy((synth.hash_u01(N, 100) < 0.5).astype(np.int64)).to(gpu)
+
+    def step(mode, scale=1.0):
+        ops.GRID_BACKWARD_MODE = mode
+        try:
+            for p in model.parameters():
+                p.grad = None
+            o = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=False, return_mask=1)
+            pm = torch.softmax(o["instance_mask_logits"], dim=-1).clamp(min=1e-6, max=1 - 1e-6)
+            loss = (-torch.log(torch.gather(pm, -1, labels[..., None]))).mean()
+            (loss * scale).backward()
+            return o["instance_mask_logits"].detach().clone(), float(loss.detach()), model.m_grid.embeddings.grad.clone(), \
+                [lin.weight.grad.clone() for lin in model.mask_mlp[0].net]
+        finally:
+            ops.GRID_BACKWARD_MODE = "auto"
+
+    logits, loss, g_sorted, gw = step("sorted")
+    assert np.isfinite(loss) and torch.isfinite(g_sorted).all()
+    sub = (synth.hash_u01(256, 7) * N).astype(np.int64)
+    want = orc.render(oracle_cfg(orc, params, steps, heads=True), ro[sub].cpu().numpy(), rd[sub].cpu().numpy())
+    np.testing.assert_allclose(logits[sub].cpu().numpy(), want["instance_mask_logits"], rtol=0, atol=RGB_TOL)
+    _, loss2, g_atomic, gw2 = step("atomic")
+    assert loss2 == loss
+    rel = float((g_sorted - g_atomic).double().norm() / g_atomic.double().norm())
+    assert rel < 1e-5, rel
+    assert torch.equal((g_sorted.abs().sum(-1) > 0), (g_atomic.abs().sum(-1) > 0)) or \
+        int(((g_sorted.abs().sum(-1) > 0) != (g_atomic.abs().sum(-1) > 0)).sum()) <= 1e-4 * int((g_atomic.abs().sum(-1) > 0).sum())
+    for x, y in zip(gw, gw2):
+        assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
+    _, _, g2, gw3 = step("sorted", scale=2.0)                           # the backward is linear in the upstream gradient
+    assert float((g2 - 2 * g_sorted).abs().max()) <= 1e-6 * float(g_sorted.abs().max())
+    assert model.grid.embeddings.grad is None
+
+
 def test_row_band_shards_assemble_the_full_image(gpu, orc):
     """The multi-GPU path (dist.py) renders contiguous 16-row-aligned bands per rank and concatenates them:
     on one GPU, rendering every rank's band separately must reproduce the single-launch image bit for bit."""
