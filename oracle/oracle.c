@@ -460,6 +460,12 @@ void orc_grad_weight_decay(const float *embeddings, float *grad, const int32_t *
 static void sh_eval_f(float x, float y, float z, uint32_t C, float *o) { ORC_SH_BODY(float) }
 static void sh_eval_d(double x, double y, double z, uint32_t C, double *o) { ORC_SH_BODY(double) }
 
+/* shencoder.cu:125-353: closed-form partials of the polynomials above, x, y, z independent.  Derived symbolically from
+ * ORC_SH_BODY by tools/gen_oracle_sh_grad.py, which also checked all 3 x 64 of them coefficient by coefficient against the
+ * reference's list (worst relative difference 2e-16) -- pinned by the reference's own source, not by this file. */
+#include "sh_grad.inc"
+static void sh_grad_f(float x, float y, float z, uint32_t C, float *dx, float *dy, float *dz) { ORC_SH_GRAD_BODY(float) }
+
 void orc_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D,
                            uint32_t degree, float *dy_dx) {
     const uint32_t C2 = degree * degree;
@@ -467,25 +473,32 @@ void orc_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint
     for (int64_t b = 0; b < (int64_t)B; b++) {
         const float *in = inputs + (size_t)b * D;
         sh_eval_f(in[0], in[1], in[2], degree, outputs + (size_t)b * C2);
-        if (dy_dx) {
-            /* shencoder.cu:125-353 lists the closed-form partials of the polynomials
-             * above (x, y, z treated as independent).  They are not re-typed here:
-             * the oracle differentiates its own fp64 restatement by a 4th-order
-             * central difference, which is exact to ~1e-11 for these degree<=7
-             * polynomials on [-1,1].  dy_dx layout [B, D, C2] (shencoder.cu:126-128). */
-            const double h = 1e-3;
-            double p2[64], p1[64], m1[64], m2[64];
-            for (uint32_t d = 0; d < 3; d++) {
-                double v[3] = {in[0], in[1], in[2]};
-                const double c = v[d];
-                v[d] = c + 2 * h; sh_eval_d(v[0], v[1], v[2], degree, p2);
-                v[d] = c + h;     sh_eval_d(v[0], v[1], v[2], degree, p1);
-                v[d] = c - h;     sh_eval_d(v[0], v[1], v[2], degree, m1);
-                v[d] = c - 2 * h; sh_eval_d(v[0], v[1], v[2], degree, m2);
-                float *o = dy_dx + (size_t)b * D * C2 + (size_t)d * C2;
-                for (uint32_t k = 0; k < C2; k++)
-                    o[k] = (float)((-p2[k] + 8 * p1[k] - 8 * m1[k] + m2[k]) / (12 * h));
-            }
+        if (dy_dx) {   /* layout [B, D, C2] (shencoder.cu:126-128) */
+            float *dx = dy_dx + (size_t)b * D * C2;
+            sh_grad_f(in[0], in[1], in[2], degree, dx, dx + C2, dx + 2 * (size_t)C2);
+        }
+    }
+}
+
+/* Test helper (tests/test_oracle_identities.py): the same dy_dx by a 4th-order central difference of the fp64 forward
+ * restatement -- an independent check of the closed forms above. */
+void orc_sh_dy_dx_fd(const float *inputs, uint32_t B, uint32_t D, uint32_t degree, float *dy_dx) {
+    const uint32_t C2 = degree * degree;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        const float *in = inputs + (size_t)b * D;
+        const double h = 1e-3;
+        double p2[64], p1[64], m1[64], m2[64];
+        for (uint32_t d = 0; d < 3; d++) {
+            double v[3] = {in[0], in[1], in[2]};
+            const double c = v[d];
+            v[d] = c + 2 * h; sh_eval_d(v[0], v[1], v[2], degree, p2);
+            v[d] = c + h;     sh_eval_d(v[0], v[1], v[2], degree, p1);
+            v[d] = c - h;     sh_eval_d(v[0], v[1], v[2], degree, m1);
+            v[d] = c - 2 * h; sh_eval_d(v[0], v[1], v[2], degree, m2);
+            float *o = dy_dx + (size_t)b * D * C2 + (size_t)d * C2;
+            for (uint32_t k = 0; k < C2; k++)
+                o[k] = (float)((-p2[k] + 8 * p1[k] - 8 * m1[k] + m2[k]) / (12 * h));
         }
     }
 }

@@ -52,6 +52,8 @@ void orc_grad_weight_decay(const float *embeddings, float *grad, const int32_t *
 /* ---- shencoder (shencoder.cu) ------------------------------------------ */
 void orc_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D,
                            uint32_t degree, float *dy_dx);
+/* test helper: dy_dx of the same encoder by a 4th-order central difference of the fp64 forward (independent check of the closed forms) */
+void orc_sh_dy_dx_fd(const float *inputs, uint32_t B, uint32_t D, uint32_t degree, float *dy_dx);
 void orc_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D,
                             uint32_t degree, const float *dy_dx, float *grad_inputs);
 

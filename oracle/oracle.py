@@ -265,6 +265,15 @@ def sh_encode_forward(inputs, degree, calc_grad_inputs=False):
     return out, dy_dx
 
 
+def sh_dy_dx_fd(inputs, degree):
+    """dy_dx [B, 3*degree^2] by a 4th-order central difference of the fp64 forward (test helper)."""
+    inputs = _f32(inputs)
+    B, D = inputs.shape
+    dy_dx = np.empty((B, D * degree * degree), dtype=np.float32)
+    lib().orc_sh_dy_dx_fd(_ptr(inputs), C.c_uint32(B), C.c_uint32(D), C.c_uint32(degree), _ptr(dy_dx))
+    return dy_dx
+
+
 def sh_encode_backward(grad, inputs, degree, dy_dx):
     grad = _f32(grad); inputs = _f32(inputs); dy_dx = _f32(dy_dx)
     B, D = inputs.shape

@@ -218,6 +218,12 @@ def test_sh_gradients_vs_finite_differences(orc):
         yp, _ = orc.sh_encode_forward(dp, 8); ym, _ = orc.sh_encode_forward(dm, 8)
         fd = (yp.astype(np.float64) - ym.astype(np.float64)) / (2 * h)
         np.testing.assert_allclose(dy[:, k], fd, rtol=0, atol=5e-3)
+    # the closed forms (oracle/sh_grad.inc: derived symbolically from the forward polynomials and checked coefficient by
+    # coefficient against shencoder.cu:125-353 by tools/gen_oracle_sh_grad.py) against the 4th-order fp64 difference the
+    # oracle used before: agreement to fp32 round-off, every degree
+    for deg in range(1, 9):
+        _, dyc = orc.sh_encode_forward(d, deg, True)
+        np.testing.assert_allclose(dyc, orc.sh_dy_dx_fd(d, deg), rtol=5e-6, atol=1e-5)
     g = rng.standard_normal((40, 64)).astype(np.float32)
     gi = orc.sh_encode_backward(g, d, 8, dy.reshape(40, -1))
     np.testing.assert_allclose(gi, np.einsum("bc,bdc->bd", g, dy), rtol=1e-5, atol=1e-5)
