@@ -178,6 +178,30 @@ class NeRFRenderer(nn.Module):
             self._plan.cfg.aabb[i] = ab[i]
         return self._plan
 
+    def _fused_shape(self) -> bool:
+        """Is this field the shape sn_rm_render_rays instantiates (nerf/network.py:93-98, 131-143: L=16 F=2 grid, 32-64-64-16
+        and 31-32-32-3 bias-free ReLU MLPs, degree-4 SH, L=5 F=2 proposal grids with 10-16-1 MLPs)?  Any other field -- a
+        subclass with its own sizes, e.g. BASELINE configs[0]: L=8 grid, 16-32-16 MLP -- renders through the stage loop over
+        the stand-alone HIP operators (grid_encode, SH, sample_pdf, weights, composite) instead; the library itself would
+        answer SN_ERR_UNSUPPORTED."""
+        def dims(mlp):
+            net = list(getattr(mlp, "net", []))
+            return [net[0].weight.shape[1]] + [l.weight.shape[0] for l in net] if net and all(l.bias is None for l in net) else None
+        try:
+            g = self.grid
+            ok = (g.input_dim == 3 and g.num_levels == 16 and g.level_dim == 2 and g.gridtype_id == 0 and not g.align_corners
+                  and g.interp_id == 0 and dims(self.grid_mlp) == [32, 64, 64, 16] and dims(self.view_mlp) == [31, 32, 32, 3]
+                  and getattr(self.view_encoder, "degree", 0) == 4)
+            n_prop = len(self.opt.num_steps) - 1
+            if ok and n_prop > 0:
+                encs, mlps = list(self.prop_encoders), list(self.prop_mlp)
+                ok = len(encs) >= n_prop and all(
+                    e.input_dim == 3 and e.num_levels == 5 and e.level_dim == 2 and e.gridtype_id == 0 and not e.align_corners
+                    and e.interp_id == 0 and dims(m) == [10, 16, 1] for e, m in zip(encs[:n_prop], mlps[:n_prop]))
+            return bool(ok)
+        except AttributeError:
+            return False
+
     def _sam_fusable(self) -> bool:
         """f_sam can be accumulated inside the fused render (no graph through s_grid wanted, standard hash grid)."""
         if not self.opt.with_sam or not self.opt.sam_use_view_direction:
@@ -193,7 +217,7 @@ class NeRFRenderer(nn.Module):
             return {}                                       # the reference's mesh branch is commented out (renderer.py:257,386)
         if bg_color is None:
             bg_color = 1
-        if perturb or self._needs_field_grad(update_proposal):
+        if perturb or self._needs_field_grad(update_proposal) or not self._fused_shape():
             return self._run_autograd(rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
                                       return_feats, return_mask, H, W)
         return self._run_fused(rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w)
