@@ -314,6 +314,15 @@ size_t sn_linear_wgrad_workspace_bytes(uint32_t M, uint32_t K, uint32_t N);
 int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uint32_t N, float *dw,
                     void *workspace, size_t workspace_bytes, sn_stream_t stream);
 
+/* Dense Adam step of one parameter tensor in a single pass: the single-tensor recipe of torch.optim.Adam (the reference's
+ * optimiser, main.py:283: Adam(params, eps=1e-15), betas (0.9, 0.999), no amsgrad) -- exp_avg.lerp_(g, 1-beta1);
+ * exp_avg_sq = beta2 * exp_avg_sq + (1-beta2) g^2; param -= lr / (1-beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1-beta2^step) + eps)
+ * -- with 16-byte accesses, 4 streams read and 3 written.  Same dense semantics (untouched rows keep moving by their
+ * momentum); elements whose gradient and both moments are exactly zero are skipped (their update is exactly zero).
+ * Hyper-parameters are doubles like the Python floats torch derives its scalars from.  step counts from 1.  zero_grad != 0: the gradient is cleared in the same pass (for callers that accumulate in place). */
+int sn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, double lr, double beta1, double beta2,
+                 double eps, double weight_decay, uint32_t step, int maximize, int zero_grad, sn_stream_t stream);
+
 /* Measurement hook (bench.py): bracket every kernel sn_rm_render_rays launches with hipEvents on the
  * caller's stream.  Classes: 0 weight pack, 1..3 proposal stage k, 4 final stage.  profile_read
  * synchronises, returns summed device milliseconds and launch counts per class, and resets. */

@@ -742,3 +742,37 @@ def test_get_rays_one_camera_per_ray_matches_the_reference(gpu):
     assert draw["rays_d"].shape == (index.numel(), 3) and int(draw["i"].max()) < W and int(draw["j"].max()) < H
     with pytest.raises(RuntimeError, match="poses"):
         get_rays(cams[:3], intr[:1], H, W, 10, random_sample=True)
+
+
+@pytest.mark.parametrize("n,wd", [(4096 * 33 + 3, 0.0), (1 << 20, 0.0), (1000, 1e-3)])
+def test_single_pass_adam_matches_torch_adam(gpu, n, wd):
+    """sanerf_hq_amd.optim.Adam (sn_adam_step: one kernel per tensor) against torch.optim.Adam -- the reference's optimiser,
+    main.py:283, eps=1e-15 -- over 6 steps with a sparse gradient pattern (most rows untouched on most steps, like a hash
+    table): parameters, both moments and the state_dict layout agree; rows never touched stay bit-identical."""
+    from sanerf_hq_amd.optim import Adam
+    rng = np.random.default_rng(n)
+    p0 = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(gpu)
+    pa, pb = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa = Adam([dict(params=[pa], lr=1e-2)], eps=1e-15, weight_decay=wd)
+    ob = torch.optim.Adam([dict(params=[pb], lr=1e-2)], eps=1e-15, weight_decay=wd, foreach=False)
+    never = torch.ones(n, dtype=torch.bool, device=gpu)
+    for step in range(6):
+        g = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(gpu)
+        mask = torch.from_numpy(rng.uniform(size=n) < 0.2).to(gpu)
+        mask[: n // 3] = False                                      # the first third never receives a gradient
+        g = g * mask
+        never &= ~mask
+        pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+        scale = float(pb.abs().max())
+        assert float((pa - pb).abs().max()) <= 2e-6 * scale, step
+    sa, sb = oa.state[pa], ob.state[pb]
+    assert float(sa["step"]) == float(sb["step"]) == 6
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert float((sa[k] - sb[k]).abs().max()) <= 1e-6 * max(float(sb[k].abs().max()), 1e-30)
+    if wd == 0.0:
+        assert torch.equal(pa.detach()[never], p0[never])           # exactly-zero updates are skipped, exactly
+        assert never.any()
+    assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
+    ob2 = torch.optim.Adam([dict(params=[pb], lr=1e-2)], eps=1e-15, weight_decay=wd)
+    ob2.load_state_dict(oa.state_dict())                            # a checkpoint written with one loads into the other

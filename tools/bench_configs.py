@@ -134,6 +134,9 @@ def main():
     t_step = timeit(step)
     out["C5_mask_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_step * 1e3, 3),
                                                "rays_per_s_fwd_bwd": round(N / t_fb, 1)}
+    from sanerf_hq_amd.optim import Adam as HipAdam  # noqa: E402   (csrc/optim.hip: the same dense update, one pass per tensor)
+    optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
+    out["C5_mask_training_step_4096_rays"]["fwd_bwd_single_pass_adam_ms"] = round(timeit(step) * 1e3, 3)
     try:   # torch's single-kernel Adam over the 160 MiB table (same update rule; the reference constructs the default one)
         optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15, fused=True)
         out["C5_mask_training_step_4096_rays"]["fwd_bwd_fused_adam_ms"] = round(timeit(step) * 1e3, 3)

@@ -6,7 +6,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tmp_ab/$name; mkdir -p $out
 cd $root/sanerf-hq_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function"
-for f in grid grid_sorted encoders raymarch heads mlp; do
+for f in grid grid_sorted encoders raymarch heads mlp optim; do
   [ -f $root/sanerf-hq_amd/csrc/$f.o ] && cp $root/sanerf-hq_amd/csrc/$f.o $out/$f.o || /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $out/$f.o
 done
 /opt/rocm/bin/hipcc $FLAGS "$@" -c render.hip -o $out/render.o
