@@ -86,6 +86,81 @@ def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, coords=None, device="c
     return results
 
 
+def collate_rays(poses, intrinsics, H, W, num_rays, index=None, images=None, masks=None, error_map=None, cam_near_far=None,
+                 random_image_batch=True, use_error_map=False, error_map_size=128, num_local_sample=0, local_patch_size=1):
+    """Device-side core of a training step's `NeRFDataset.collate` (nerf/provider.py:894-1114, RGB / mask modes): choose
+    the cameras, draw the pixels, build their rays and gather the supervision at exactly those pixels -- all on the GPU the
+    dataset was preloaded to, no H x W intermediate, no host round trip.
+
+      poses [M,4,4], intrinsics [M,4] (or [1,4] / ndarray[4]), images [M,H,W,3|4] uint8, masks [M,H,W,C], error_map
+      [M, S*S], cam_near_far [M,2] -- the preloaded dataset tensors; `index` = the loader's image index (a [1] tensor or
+      int) used when random_image_batch is off (provider.py:908-913 draws one camera per ray otherwise).
+      use_error_map: pixels from the error-map multinomial (provider.py:959-963) instead of uniformly (:964-968).
+      num_local_sample > 0: the mixed-sampling extra of provider.py:970-984 -- that many patches of local_patch_size^2
+      rays around cells drawn from their images' error maps, appended to rays / masks / error_maps / cam_near_far.
+
+    Returns the reference's result keys: rays_o, rays_d, index, poses, intrinsics, H, W, inds_coarse[, images, masks,
+    error_maps, cam_near_far], plus the pixel coordinates i, j."""
+    dev = poses.device
+    M = poses.shape[0]
+    if isinstance(intrinsics, np.ndarray):
+        intrinsics = torch.as_tensor(intrinsics.reshape(-1, 4).astype(np.float32), device=dev)
+    intr_all = intrinsics.reshape(-1, 4).float()
+    if random_image_batch:
+        index = torch.randint(0, M, size=(num_rays,), device=dev)                        # provider.py:912
+        random_sample = True
+    else:
+        index = torch.as_tensor([index] if isinstance(index, int) else index, device=dev).reshape(-1).long()
+        random_sample = False
+    cam_pose = poses[index]
+    cam_intr = intr_all[index] if intr_all.shape[0] == M else intr_all
+    emap = None if error_map is None else error_map[index]
+    if use_error_map:
+        rays = get_rays(cam_pose, cam_intr, H, W, num_rays, device=dev, patch_size=1, incoherent_mask=emap,
+                        include_incoherent_region=True, incoherent_mask_size=error_map_size, random_sample=random_sample)
+    else:
+        rays = get_rays(cam_pose, cam_intr, H, W, num_rays, device=dev, patch_size=1, incoherent_mask=None,
+                        include_incoherent_region=False, incoherent_mask_size=H, random_sample=True)
+    res = {"H": H, "W": W, "index": index, "poses": cam_pose, "intrinsics": cam_intr, "rays_o": rays["rays_o"], "rays_d": rays["rays_d"],
+           "i": rays["i"], "j": rays["j"], "inds_coarse": rays["inds_coarse"]}
+    loc = None
+    if num_local_sample > 0:                                                             # provider.py:970-984
+        li = torch.randint(0, M, size=(num_local_sample,), device=dev)
+        li_exp = li[:, None].expand(-1, local_patch_size * local_patch_size).reshape(-1)
+        parts = []
+        for k in range(num_local_sample):    # one patch per drawn image (the reference's single call draws one centre for all)
+            parts.append(get_rays(poses[li[k:k + 1]].expand(local_patch_size * local_patch_size, 4, 4), cam_intr[:1], H, W, 1, device=dev,
+                                  patch_size=local_patch_size, incoherent_mask=None if error_map is None else error_map[li[k:k + 1]],
+                                  include_incoherent_region=error_map is not None, incoherent_mask_size=error_map_size, random_sample=False))
+        loc = {k_: torch.cat([p_[k_] for p_ in parts], 0) for k_ in ("rays_o", "rays_d", "i", "j")}
+        res["poses"] = torch.cat([res["poses"], poses[li_exp]], 0)
+        res["rays_o"] = torch.cat([res["rays_o"], loc["rays_o"]], 0)
+        res["rays_d"] = torch.cat([res["rays_d"], loc["rays_d"]], 0)
+    if images is not None:                                                               # provider.py:1004-1014
+        res["images"] = images[index, rays["j"], rays["i"]].float() / 255
+    if masks is not None:                                                                # provider.py:1020-1035
+        m = masks[index, rays["j"], rays["i"]]
+        if loc is not None:
+            m = torch.cat([m, masks[li_exp, loc["j"], loc["i"]]], 0)
+        res["masks"] = m.view(-1, masks.shape[-1])
+    if error_map is not None:                                                            # provider.py:1038-1060
+        # the reference scales both pixel coordinates by error_map_size / H (its datasets are square); the column uses W here,
+        # which is the same number for a square image and stays inside the map otherwise
+        sj, si = error_map_size / H, error_map_size / W
+        e = error_map[index, (rays["j"] * sj).long() * error_map_size + (rays["i"] * si).long()]
+        if loc is not None:
+            e = torch.cat([e, error_map[li_exp, (loc["j"] * sj).long() * error_map_size + (loc["i"] * si).long()]], 0)
+        res["error_maps"] = e.view(-1)
+    else:
+        res["error_maps"] = None
+    if cam_near_far is not None:                                                         # provider.py:1063-1068
+        c = cam_near_far[index]
+        if loc is not None:
+            c = torch.cat([c, cam_near_far[li_exp]], 0)
+        res["cam_near_far"] = c
+    return res
+
+
 # ---------------------------------------------------------------------------------------------
 # checkpoints in the reference's format (nerf/trainer.py:1685-1741 save, :1779-1800 load)
 # ---------------------------------------------------------------------------------------------

@@ -776,3 +776,48 @@ def test_single_pass_adam_matches_torch_adam(gpu, n, wd):
     assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
     ob2 = torch.optim.Adam([dict(params=[pb], lr=1e-2)], eps=1e-15, weight_decay=wd)
     ob2.load_state_dict(oa.state_dict())                            # a checkpoint written with one loads into the other
+
+
+def test_collate_rays_draws_cameras_pixels_and_supervision_on_the_device(gpu):
+    """the device-side core of NeRFDataset.collate (provider.py:894-1114).  Every returned ray must be the
+    ray of pixel (j, i) of camera `index` (checked against full-image rays of that camera), and every gathered
+    supervision value the dataset tensor's entry at exactly that (camera, pixel) -- in the one-camera-per-ray mode
+    (random_image_batch), the single-image error-map mode, and with the mixed local patches appended."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.nerf import collate_rays
+    torch.manual_seed(0)
+    M, H, W, S = 5, 48, 64, 16
+    poses = torch.stack([torch.from_numpy(synth.orbit_pose(1.0 + 0.1 * k, 10.0 * k, 40.0 * k)) for k in range(M)]).to(gpu)
+    intr = torch.tensor([list(synth.pinhole_intrinsics(H, W))] * M, device=gpu)
+    images = torch.randint(0, 256, (M, H, W, 3), dtype=torch.uint8, device=gpu)
+    masks = torch.randint(0, 3, (M, H, W, 1), device=gpu)
+    emap = torch.rand(M, S * S, device=gpu) + 0.01
+    cnf = torch.rand(M, 2, device=gpu)
+    full = [rm.generate_rays(poses[k], [float(v) for v in intr[k]], H, W, device=gpu) for k in range(M)]
+
+    def check(res, n_main, n_total):
+        idx, i, j = res["index"], res["i"], res["j"]
+        cam = idx if idx.numel() == n_main else idx.expand(n_main)
+        pix = j * W + i
+        for k in range(M):
+            sel = cam == k
+            if sel.any():
+                assert torch.equal(res["rays_o"][:n_main][sel], full[k][0][pix[sel]]) and torch.equal(res["rays_d"][:n_main][sel], full[k][1][pix[sel]])
+        assert torch.equal(res["images"], images[cam, j, i].float() / 255)
+        assert torch.equal(res["masks"][:n_main], masks[cam, j, i].view(-1, 1))
+        assert torch.equal(res["error_maps"][:n_main], emap[cam, (j * (S / H)).long() * S + (i * (S / W)).long()])
+        assert torch.equal(res["cam_near_far"][:idx.numel()], cnf[idx])                 # [1, 2] in the single-image mode, like the reference
+        assert res["rays_o"].shape == (n_total, 3) and res["masks"].shape[0] == n_total
+        assert res["cam_near_far"].shape[0] == idx.numel() + (n_total - n_main)
+
+    a = collate_rays(poses, intr, H, W, 512, images=images, masks=masks, error_map=emap, cam_near_far=cnf,
+                     random_image_batch=True, error_map_size=S)
+    assert a["index"].shape == (512,) and len(torch.unique(a["index"])) == M
+    check(a, 512, 512)
+    b = collate_rays(poses, intr, H, W, 128, index=torch.tensor([3]), images=images, masks=masks, error_map=emap, cam_near_far=cnf,
+                     random_image_batch=False, use_error_map=True, error_map_size=S)
+    assert b["inds_coarse"].shape == (1, 128) and len(torch.unique(b["inds_coarse"])) == 128      # drawn without replacement
+    check(b, 128, 128)
+    c = collate_rays(poses, intr, H, W, 256, images=images, masks=masks, error_map=emap, cam_near_far=cnf,
+                     random_image_batch=True, error_map_size=S, num_local_sample=3, local_patch_size=4)
+    check(c, 256, 256 + 3 * 16)
