@@ -305,6 +305,17 @@ int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights,
                     float bound, const sn_grid_desc *grid, const sn_mlp_desc *mlp, float *out,
                     void *workspace, size_t workspace_bytes, sn_stream_t stream);
 
+/* Backward-data pass of a 256-wide perceptron without skip layers (the autograd of nerf/network.py:31-66 for the per-sample
+ * mask head in training, trainer.py:401-428) in one kernel: grad_out [N, dims[nl]] -> grad_in [N, dims[0]], and for every
+ * hidden layer l < nl-1 grad_hidden[l] [N, 256] = d loss / d (pre-activation of layer l) -- what sn_linear_wgrad needs.
+ * hidden[l] [N, 256] = the forward's saved (post-activation) output of layer l: its sign selects the LeakyReLU / ReLU branch
+ * exactly as torch's in-place backward does.  Products as split-fp16 with fp32 accumulation on the matrix cores; every row is
+ * scaled by a power of two (exact) so that small gradient rows keep their precision.  hidden / grad_hidden are host arrays of
+ * nl-1 device pointers. */
+size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp);
+int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, uint32_t N,
+                         float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes, sn_stream_t stream);
+
 /* Weight gradient of an nn.Linear over a training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order
  * (deterministic).  K, N <= 64 (the radiance / proposal MLPs, nerf/network.py:9-29): register-tiled VALU kernel.
  * Otherwise N <= 256, any K (the per-sample mask head and the SAM head, network.py:31-66): v_mfma_f32_32x32x2_f32 over

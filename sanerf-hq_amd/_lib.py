@@ -89,6 +89,8 @@ _SIGNATURES = {
     "sn_mlp_wide_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "sn_mlp_wide_forward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _f32, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
     "sn_mlp_wide_overflow": (_int, [_vp]),
+    "sn_mlp_wide_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
+    "sn_mlp_wide_backward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _u32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_mask_head_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "sn_rm_mask_head": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _f32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _vp, _vp, C.c_size_t, _vp]),
     "sn_adam_step": (_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _u32, _int, _int, _vp]),

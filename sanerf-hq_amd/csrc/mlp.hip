@@ -61,6 +61,10 @@ struct WideArgs {
     uint32_t T, E;                        // samples per ray; appended channels (<= 16)
     float bound, inv_den;                 // x01 = (xyz + bound) / (2 bound); inv_den = 1 / (2 bound) when that is exact, else 0
     GridLevels g;
+    // XMODE 4 (sn_mlp_wide_backward): "layer" b multiplies by W^T of forward layer nl-1-b; its 256 outputs are masked with the
+    // activation derivative taken from the forward's saved outputs and written out (the weight gradients need them)
+    const float *mask[SN_MAX_LAYERS];     // [N, 256] post-activation output of the forward layer that FED forward layer nl-1-b
+    float *dump[SN_MAX_LAYERS];           // [N, 256] out: gradient w.r.t. that layer's pre-activation
 };
 
 struct PackArgs {
@@ -69,6 +73,7 @@ struct PackArgs {
     uint32_t din, nl;
     WideLayer layer[SN_MAX_LAYERS];
     uint4 *pack;
+    uint32_t transposed;                  // 1: w[l] is read as its transpose (backward pass): element [m][k] = w[l][k * in_dim[l] + m]
 };
 
 __device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo) {
@@ -111,7 +116,7 @@ __global__ void k_pack_mlp_wide(PackArgs a) {
             valid = valid && c < a.din;
             col = (L.uses_h ? (uint32_t)WIDE : 0u) + c;   // skip layers see cat([h, x]) (network.py:61-63)
         }
-        v[i] = valid ? W[(size_t)m * row + col] : 0.0f;
+        v[i] = valid ? (a.transposed ? W[(size_t)col * row + m] : W[(size_t)m * row + col]) : 0.0f;
     }
     uint4 ph, pl;
     split2h(v[0], v[1], ph.x, pl.x); split2h(v[2], v[3], ph.y, pl.y);
@@ -299,6 +304,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         ++g;
     };
 
+    // XMODE 4: the upstream gradient rows span many orders of magnitude (a sample's weight multiplies its row) and values
+    // below 2^-14 would lose their lo half to fp16 subnormals, so every row is scaled by a power of two that brings its
+    // largest entry to [1, 2) -- exact -- and the outputs are scaled back, exactly, on the way out
+    float row_scale = 1.0f, row_unscale = 1.0f;
+    if constexpr (XMODE == 4) {
+        float mx = 0.0f;
+        for (uint32_t c = 8u * half; c < a.din; c += 16u) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t cc = c + i;
+                const float t = xrow[cc < a.din ? cc : a.din - 1u];
+                mx = fmaxf(mx, cc < a.din ? fabsf(t) : 0.0f);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const uint32_t bits = __float_as_uint(mx);
+        int e = (int)((bits >> 23) & 255u) - 127;
+        if (mx > 0.0f && mx < __builtin_inff() && e > -100 && e < 100) {
+            row_scale = __uint_as_float((uint32_t)(127 - e) << 23);
+            row_unscale = __uint_as_float((uint32_t)(127 + e) << 23);
+        }
+    }
+
     auto x_operand = [&](uint32_t kx, uint4 &bh, uint4 &bl) {            // x[n][16 kx + 8 half + 0..7], zero padded
         float v[8];
         const uint32_t c0 = 16u * kx + 8u * half;
@@ -317,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint32_t c = c0 + i;
                 const float t = xrow[c < a.din ? c : a.din - 1u];         // always in range: no divergent branch around the load
-                v[i] = (ok && c < a.din) ? t : 0.0f;
+                v[i] = (ok && c < a.din) ? t * row_scale : 0.0f;         // row_scale = 1 outside the backward mode
             }
         }
         split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
@@ -415,6 +443,39 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             run_chunk(bh, bl, npairs);
         }
         }
+        if constexpr (XMODE == 4) {
+            if (l + 1u < a.nl) {
+                // derivative of the activation (network.py:65-66; leaky_relu / relu keep the sign, so the saved OUTPUT tells the
+                // branch, as in torch's in-place backward), gradient w.r.t. the pre-activation written out, then split
+                const float slope = a.leaky ? 0.01f : 0.0f;
+                const float *mrow = a.mask[l] + (size_t)(ok ? n : a.N - 1u) * WIDE;
+                float *drow = a.dump[l] + (size_t)(ok ? n : 0u) * WIDE;
+#pragma unroll
+                for (int mt = 0; mt < WIDE_MT; ++mt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t m0 = 32u * mt + 8u * q + 4u * half;
+                        const float4 h = *reinterpret_cast<const float4 *>(mrow + m0);
+                        float4 v;
+                        v.x = acc[mt][4 * q + 0] * (h.x > 0.0f ? 1.0f : slope);
+                        v.y = acc[mt][4 * q + 1] * (h.y > 0.0f ? 1.0f : slope);
+                        v.z = acc[mt][4 * q + 2] * (h.z > 0.0f ? 1.0f : slope);
+                        v.w = acc[mt][4 * q + 3] * (h.w > 0.0f ? 1.0f : slope);
+                        acc[mt][4 * q + 0] = v.x; acc[mt][4 * q + 1] = v.y; acc[mt][4 * q + 2] = v.z; acc[mt][4 * q + 3] = v.w;
+                        if (ok) *reinterpret_cast<float4 *>(drow + m0) = make_float4(v.x * row_unscale, v.y * row_unscale, v.z * row_unscale, v.w * row_unscale);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < WIDE_MT; ++mt) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        uint4 &bh = hbh[2 * mt + hf], &bl = hbl[2 * mt + hf];
+                        split2h(acc[mt][8 * hf + 0], acc[mt][8 * hf + 1], bh.x, bl.x); split2h(acc[mt][8 * hf + 2], acc[mt][8 * hf + 3], bh.y, bl.y);
+                        split2h(acc[mt][8 * hf + 4], acc[mt][8 * hf + 5], bh.z, bl.z); split2h(acc[mt][8 * hf + 6], acc[mt][8 * hf + 7], bh.w, bl.w);
+                    }
+                }
+            }
+        } else
         if (l + 1u < a.nl) {
             // activation (network.py:65-66) + split into the next layer's B operands
 #pragma unroll
@@ -555,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float t = acc[mt][4 * qd + i];
+                float t = acc[mt][4 * qd + i] * row_unscale;       // 1 outside the backward mode
                 if (a.ln_w) {              // wave-uniform; index clamped so that the loads need no per-lane branch
                     const uint32_t mi = m0 + i < LL.out ? m0 + i : LL.out - 1u;
                     t = (t - mean) * rstd * a.ln_w[mi] + a.ln_b[mi];
@@ -635,7 +696,7 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mlp_wide: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
     const uint32_t nl = mlp->num_layers, din = mlp->dims[0];
     hipStream_t st = (hipStream_t)stream;
-    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace);
+    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         pa.w[l] = mlp->weight[l];
@@ -680,6 +741,71 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     return SN_OK;
 }
 
+// Backward-data pass of a 256-wide perceptron in one kernel (the autograd of nerf/network.py:31-66 for the per-sample mask
+// head during training, trainer.py:401-428): grad_in = ((grad_out W_{nl-1}) * act'(h_{nl-2}) ... W_0), with the gradient
+// w.r.t. every hidden pre-activation written out for the weight-gradient kernels (sn_linear_wgrad).  The same machinery
+// as the forward -- transposed formulation, split-fp16 products with fp32 accumulation, weights streamed through LDS --
+// run over the transposed weights in reverse layer order; the activation step is the mask from the forward's saved
+// outputs, so no rounding difference can flip a LeakyReLU branch (which is what rules out a split-fp16 FORWARD under the
+// 1e-3 gradient bar).
+extern "C" size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp) {
+    if (!mlp || mlp->num_layers < 1 || mlp->num_layers > SN_MAX_LAYERS) return 0;
+    sn_mlp_desc b = *mlp;
+    const uint32_t nl = mlp->num_layers;
+    for (uint32_t l = 0; l <= nl; ++l) b.dims[l] = mlp->dims[nl - l];
+    for (uint32_t l = 0; l < nl; ++l) { b.weight[l] = mlp->weight[nl - 1 - l]; b.bias[l] = nullptr; }
+    b.skip_mask = 0;
+    return sn_mlp_wide_workspace_bytes(&b);
+}
+
+extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, uint32_t N,
+                                    float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes,
+                                    sn_stream_t stream) {
+    SN_REQUIRE(mlp, "mlp_wide_backward: mlp is NULL");
+    if (N == 0) return SN_OK;
+    const uint32_t nl = mlp->num_layers;
+    SN_REQUIRE(nl >= 2 && nl <= SN_MAX_LAYERS, "mlp_wide_backward: num_layers=%u outside 2..%d", nl, SN_MAX_LAYERS);
+    SN_REQUIRE(grad_out && hidden && grad_hidden && grad_in && workspace, "mlp_wide_backward: NULL pointer");
+    SN_REQUIRE(table_aligned(workspace) && table_aligned(grad_in), "mlp_wide_backward: workspace/grad_in must be 16-byte aligned");
+    if (mlp->skip_mask != 0u) { set_error("mlp_wide_backward: skip layers are not supported (use autograd's GEMMs)"); return SN_ERR_UNSUPPORTED; }
+    sn_mlp_desc b = *mlp;                                                   // the backward pass as an MLP over the transposed weights
+    for (uint32_t l = 0; l <= nl; ++l) b.dims[l] = mlp->dims[nl - l];
+    for (uint32_t l = 0; l < nl; ++l) { b.weight[l] = mlp->weight[nl - 1 - l]; b.bias[l] = nullptr; }
+    PackArgs pa;
+    size_t u4 = 0;
+    int rc = wide_plan(&b, pa.layer, &u4);
+    if (rc) return rc;
+    SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mlp_wide_backward: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
+    hipStream_t st = (hipStream_t)stream;
+    pa.din = b.dims[0]; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 1;
+    uint32_t max_threads = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        pa.w[l] = b.weight[l];
+        pa.in_dim[l] = mlp->dims[nl - 1 - l];                                // columns of the forward layer's [out, in] weight
+        const uint32_t nks = (pa.layer[l].uses_h ? WIDE_HKS : 0) + pa.layer[l].x_ks;
+        const uint32_t th = nks * (uint32_t)WIDE_MT * 64u;
+        if (th > max_threads) max_threads = th;
+    }
+    hipLaunchKernelGGL(k_pack_mlp_wide, dim3(div_up(max_threads, 256), nl), dim3(256), 0, st, pa);
+    SN_LAUNCH_CHECK("k_pack_mlp_wide");
+    WideArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.x = grad_out; wa.out = grad_in; wa.pack = pa.pack;
+    wa.N = N; wa.din = b.dims[0]; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
+    for (uint32_t l = 0; l < nl; ++l) wa.layer[l] = pa.layer[l];
+    for (uint32_t l = 0; l + 1 < nl; ++l) {                                   // after backward layer l: forward layer nl-2-l's output
+        SN_REQUIRE(hidden[nl - 2 - l] && grad_hidden[nl - 2 - l], "mlp_wide_backward: hidden[%u] / grad_hidden[%u] is NULL", nl - 2 - l, nl - 2 - l);
+        SN_REQUIRE(table_aligned(hidden[nl - 2 - l]) && table_aligned(grad_hidden[nl - 2 - l]), "mlp_wide_backward: hidden tensors must be 16-byte aligned");
+        wa.mask[l] = hidden[nl - 2 - l];
+        wa.dump[l] = grad_hidden[nl - 2 - l];
+    }
+    const size_t lds = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 256u;
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mlp_wide<4>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);
+    SN_LAUNCH_CHECK("k_mlp_wide<4>");
+    return SN_OK;
+}
+
 // Mask head in one kernel (renderer.py:304-305, 376-385): k_mlp_wide<3> builds each sample's MLP input -- the C = 8 hash-grid
 // levels of its position and the appended geometry channels -- in registers, straight into the B operands of the first
 // layer, and composites the per-sample logits with the ray's weights in its epilogue.  Neither the [N*T, 143] input nor
@@ -719,7 +845,7 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     SN_REQUIRE(rows64 < (1ull << 32), "mask_head: N*T does not fit 32 bits");
     const uint32_t rows = (uint32_t)rows64, width = mlp->dims[0];
     hipStream_t st = (hipStream_t)stream;
-    pa.din = width; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace);
+    pa.din = width; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         pa.w[l] = mlp->weight[l];

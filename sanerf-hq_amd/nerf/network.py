@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from ..activation import trunc_exp
 from ..encoding import get_encoder
-from ..ops import small_linear
+from ..ops import small_linear, wide_mlp_fusable, wide_mlp_train
 from .renderer import NeRFRenderer
 
 # constants the reference hard-codes in NeRFNetwork.__init__ (network.py:90-143)
@@ -58,6 +58,8 @@ class SkipConnMLP(nn.Module):
         self.net = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(fan_in, fan_out))
 
     def forward(self, x):
+        if wide_mlp_fusable(x, list(self.net), self.skip_layers):           # training: one kernel for the whole backward data path
+            return wide_mlp_train(x, list(self.net), leaky=True)
         h = x
         for i, layer in enumerate(self.net):
             if i in self.skip_layers:

@@ -17,6 +17,9 @@ from __future__ import annotations
 
 from typing import Tuple
 
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -406,6 +409,97 @@ class _small_linear(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
         return gx, gw, gb
+
+
+WIDE_MLP_BACKWARD_MIN_ROWS = 16384
+_wide_bwd_ws: dict = {}
+
+
+class _wide_mlp_train(Function):
+    """A bias-free 256-wide perceptron without skip layers under autograd (the per-sample mask head in training,
+    network.py:118-123 / trainer.py:401-428).  Forward: the usual GEMMs (rocBLAS fp32 -- a split-fp16 forward would round
+    pre-activations differently and flip LeakyReLU branches of ~1e-6 of the units, which alone costs the 1e-3 gradient
+    budget) with every hidden output saved.  Backward: ONE kernel for the whole data path (sn_mlp_wide_backward: grad of the
+    input and of every hidden pre-activation, masks from the saved outputs) + sn_linear_wgrad per layer."""
+
+    @staticmethod
+    def forward(ctx, x, leaky, *weights):
+        hs = []
+        h = x
+        for i, w in enumerate(weights):
+            h = torch.nn.functional.linear(h, w)
+            if i + 1 < len(weights):
+                h = torch.nn.functional.leaky_relu(h, inplace=True) if leaky else torch.relu_(h)
+                hs.append(h)
+        ctx.save_for_backward(x, *hs, *weights)
+        ctx.nl, ctx.leaky = len(weights), bool(leaky)
+        return h
+
+    @staticmethod
+    def backward(ctx, gy):
+        nl = ctx.nl
+        saved = ctx.saved_tensors
+        x, hs, ws = saved[0], saved[1:nl], saved[nl:]
+        lib = _lib.lib()
+        gy2 = gy.reshape(-1, gy.shape[-1]).contiguous().float()
+        N = gy2.shape[0]
+        x2 = x.reshape(N, -1)
+        desc = _lib.MlpDesc()
+        desc.num_layers = nl
+        desc.activation = 1 if ctx.leaky else 0
+        desc.skip_mask = 0
+        desc.dims[0] = x2.shape[1]
+        for i, w in enumerate(ws):
+            desc.weight[i] = w.data_ptr()
+            desc.bias[i] = None
+            desc.dims[i + 1] = w.shape[0]
+        need = int(lib.sn_mlp_wide_backward_workspace_bytes(C.byref(desc)))
+        if need == 0:
+            raise RuntimeError("wide MLP backward: " + lib.sn_last_error().decode())
+        ws_buf = _wide_bwd_ws.get(x.device)
+        if ws_buf is None or ws_buf.numel() < need:
+            ws_buf = torch.empty(need, dtype=torch.uint8, device=x.device)
+            _wide_bwd_ws[x.device] = ws_buf
+        gx = torch.empty(N, x2.shape[1], device=x.device, dtype=torch.float32)
+        gh = [torch.empty(N, 256, device=x.device, dtype=torch.float32) for _ in range(nl - 1)]
+        hid = (C.c_void_p * (nl - 1))(*[h.reshape(N, 256).data_ptr() for h in hs])
+        ghp = (C.c_void_p * (nl - 1))(*[g.data_ptr() for g in gh])
+        _lib.check(lib.sn_mlp_wide_backward(C.byref(desc), _lib.dev(gy2, "grad_output"), hid, N, _lib.dev(gx, "grad_input"), ghp,
+                                            ws_buf.data_ptr(), ws_buf.numel(), _lib.stream()), "sn_mlp_wide_backward")
+        grads_w = []
+        inputs = [x2.contiguous()] + [h.reshape(N, 256) for h in hs]
+        outs = gh + [gy2]
+        for i in range(nl):
+            if not ctx.needs_input_grad[2 + i]:
+                grads_w.append(None)
+                continue
+            K, Nn = inputs[i].shape[1], outs[i].shape[1]
+            wneed = int(lib.sn_linear_wgrad_workspace_bytes(N, K, Nn))
+            wsb = _wgrad_ws.get(x.device)
+            if wsb is None or wsb.numel() < wneed:
+                wsb = torch.empty(max(wneed, 1 << 20), dtype=torch.uint8, device=x.device)
+                _wgrad_ws[x.device] = wsb
+            gw = torch.empty(Nn, K, device=x.device, dtype=torch.float32)
+            _lib.check(lib.sn_linear_wgrad(_lib.dev(inputs[i], "x"), _lib.dev(outs[i], "grad_output"), N, K, Nn, _lib.dev(gw, "grad_weight"),
+                                           wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_linear_wgrad")
+            grads_w.append(gw)
+        return (gx.reshape(x.shape) if ctx.needs_input_grad[0] else None), None, *grads_w
+
+
+def wide_mlp_fusable(x: torch.Tensor, layers, skip_layers) -> bool:
+    """Training-time route of a SkipConnMLP / MLP through _wide_mlp_train: CUDA fp32, autograd on, many rows, no bias, no
+    skip layers, hidden width 256, at most 256 outputs."""
+    rows = x.numel() // max(x.shape[-1], 1)
+    return (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and rows >= WIDE_MLP_BACKWARD_MIN_ROWS
+            and not skip_layers and len(layers) >= 2 and all(l.bias is None and l.weight.dtype == torch.float32 for l in layers)
+            and all(l.weight.shape[0] == 256 for l in layers[:-1]) and layers[-1].weight.shape[0] <= 256
+            and all(l.weight.shape[1] == 256 for l in layers[1:]) and layers[0].weight.shape[1] <= 1024
+            and any(l.weight.requires_grad for l in layers)
+            and os.environ.get("SN_WIDE_MLP_BACKWARD", "fused") != "torch")
+
+
+def wide_mlp_train(x: torch.Tensor, layers, leaky: bool) -> torch.Tensor:
+    return _wide_mlp_train.apply(x, leaky, *[l.weight for l in layers])
 
 
 def small_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:

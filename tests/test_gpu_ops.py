@@ -821,3 +821,39 @@ def test_collate_rays_draws_cameras_pixels_and_supervision_on_the_device(gpu):
     c = collate_rays(poses, intr, H, W, 256, images=images, masks=masks, error_map=emap, cam_near_far=cnf,
                      random_image_batch=True, error_map_size=S, num_local_sample=3, local_patch_size=4)
     check(c, 256, 256 + 3 * 16)
+
+
+@pytest.mark.parametrize("N,din,n_out,leaky", [(20000, 143, 2, True), (16384 + 77, 64, 5, True), (33000, 143, 2, False)])
+def test_wide_mlp_fused_backward_matches_autograd(gpu, N, din, n_out, leaky):
+    """sn_mlp_wide_backward (one kernel: gradient of the input and of every hidden pre-activation on the matrix cores, masks
+    from the forward's saved outputs) + sn_linear_wgrad against torch autograd over the same forward (rocBLAS fp32).  The
+    upstream gradient rows span 8 orders of magnitude like a training step's (a sample's weight multiplies its row): the
+    per-row power-of-two scaling must keep small rows accurate."""
+    from sanerf_hq_amd import ops, synth
+    ws = [T(synth.linear_weight(256, din, 700, 2.0), gpu), T(synth.linear_weight(256, 256, 701, 2.0), gpu), T(synth.linear_weight(n_out, 256, 702, 2.0), gpu)]
+    rng = np.random.default_rng(N)
+    x = T(rng.standard_normal((N, din)).astype(np.float32), gpu)
+    gy = T((rng.standard_normal((N, n_out)) * 10.0 ** rng.uniform(-9, -1, (N, 1))).astype(np.float32), gpu)
+    gy[5] = 0.0                                                           # an all-zero row
+    act = (lambda t: torch.nn.functional.leaky_relu(t)) if leaky else torch.relu
+
+    def run(fused):
+        xs = x.clone().requires_grad_(True)
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        if fused:
+            y = ops._wide_mlp_train.apply(xs, leaky, *wl)
+        else:
+            y = torch.nn.functional.linear(act(torch.nn.functional.linear(act(torch.nn.functional.linear(xs, wl[0])), wl[1])), wl[2])
+        y.backward(gy)
+        return y.detach(), xs.grad, [w.grad for w in wl]
+
+    ya, gxa, gwa = run(True)
+    yb, gxb, gwb = run(False)
+    assert torch.equal(ya, yb)                                            # the forward is the same GEMM chain
+    # per-row accuracy of the input gradient: relative to each row's own magnitude (small rows are not swamped)
+    rn = gxb.norm(dim=1)
+    rel = (gxa - gxb).norm(dim=1) / rn.clamp_min(1e-30)
+    assert float(rel[rn > 0].max()) < 2e-5, float(rel[rn > 0].max())
+    assert float(gxa[5].abs().max()) == 0.0
+    for a_, b_ in zip(gwa, gwb):
+        assert float((a_ - b_).norm() / b_.norm()) < 1e-5
