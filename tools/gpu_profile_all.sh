@@ -18,6 +18,8 @@ done; done
 stats c3_sam_head python $root/tools/c3_profile.py
 stats train_rgb python $root/tools/train_profile.py rgb
 stats train_mask python $root/tools/train_profile.py mask
+stats mask_head python $root/tools/mask_profile.py mask
+stats compact_live python $root/tools/mask_profile.py compact
 rm -f $out/*_under_rocprof.log
 # PMC passes (primary configuration of each schedule, fp32 tables)
 for sch in flat128 ref; do
@@ -42,6 +44,7 @@ done
 python $root/tools/traffic_from_pmc.py $out > $out/latest_traffic.json
 # micro-benchmarks
 [ -x $root/tools/ubench/gathers_ub ] && timeout 300 $root/tools/ubench/gathers_ub > $out/ubench_gathers.txt 2>&1
+[ -x $root/tools/ubench/valu_rate_ub ] && timeout 120 $root/tools/ubench/valu_rate_ub > $out/ubench_valu_rate.txt 2>&1
 python $root/tools/mlp_bench.py > $out/ubench_head_mlp.txt 2>&1
 python $root/tools/wgrad_bench.py 2>/dev/null | tail -1 > $out/ubench_wgrad.json
 python $root/tools/prop_sp_ab.py 2>/dev/null | tail -1 > $out/small_batch_kernels_ab.json

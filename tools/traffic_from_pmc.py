@@ -18,9 +18,22 @@ def parse(path):
     return vals
 
 
+def source_fingerprint():
+    """Same sha256 over the kernel sources as bench.py's: ties this PMC profile to the code it was taken from."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "sanerf-hq_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     d = sys.argv[1]
     out = {}
+    fp = source_fingerprint()
     for sch in ("flat128", "ref"):
         p = os.path.join(d, f"pmc_{sch}.txt")
         if not os.path.exists(p):
@@ -32,7 +45,7 @@ def main():
         read_b = 128 * rd128 + 64 * (rd - rd128)
         write_b = v.get("WRITE_SIZE", 0.0) * 1024
         out[f"{sch}_f32"] = {
-            "rays": 640000, "kernel": "k_final_stage",
+            "rays": 640000, "kernel": "k_final_stage", "source_fingerprint": fp,
             "hbm_read_bytes_per_launch": int(read_b), "hbm_write_bytes_per_launch": int(write_b),
             "hbm_bytes_per_launch": int(read_b + write_b),
             "raw": {"TCC_EA0_RDREQ_sum": rd, "TCC_EA0_RDREQ_128B_sum": rd128, "FETCH_SIZE_KiB": v.get("FETCH_SIZE"),

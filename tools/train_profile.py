@@ -23,7 +23,8 @@ if mode == "rgb":
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_params([128, 64, 32], seed=1).items()}, strict=False)
     model = model.to(dev).train()
     gt = torch.from_numpy(synth.hash_uniform((N, 3), 42, 0.0, 1.0)).to(dev)
-    optim = torch.optim.Adam(model.get_params(1e-2), eps=1e-15)
+    from sanerf_hq_amd.optim import Adam as HipAdam
+    optim = (torch.optim.Adam if os.environ.get("SN_PROFILE_TORCH_ADAM") else HipAdam)(model.get_params(1e-2), eps=1e-15)
     def step():
         optim.zero_grad(set_to_none=True)
         o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=True)
@@ -37,7 +38,8 @@ else:
     for n_, p in model.named_parameters():
         p.requires_grad_(n_.startswith("m_grid") or n_.startswith("mask_mlp"))
     labels = torch.from_numpy((synth.hash_u01(N, 100) < 0.5).astype(np.int64)).to(dev)
-    optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
+    from sanerf_hq_amd.optim import Adam as HipAdam
+    optim = (torch.optim.Adam if os.environ.get("SN_PROFILE_TORCH_ADAM") else HipAdam)([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
     def step():
         optim.zero_grad(set_to_none=True)
         o = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=False, return_mask=1)
