@@ -44,6 +44,7 @@ struct WideLayer {
     uint32_t out;                         // true output width
     uint32_t w_off;                       // first uint4 of the layer in the packed stream
     uint32_t has_bias;
+    uint32_t narrow;                      // last layer with <= 64 outputs fed by h only: 4 k-steps x 1 tile pair per chunk (see run_chunk4)
 };
 
 struct WideArgs {
@@ -121,7 +122,11 @@ __global__ void k_pack_mlp_wide(PackArgs a) {
     uint4 ph, pl;
     split2h(v[0], v[1], ph.x, pl.x); split2h(v[2], v[3], ph.y, pl.y);
     split2h(v[4], v[5], ph.z, pl.z); split2h(v[6], v[7], ph.w, pl.w);
-    const size_t base = (size_t)L.w_off + (size_t)ks * WIDE_MT * 128u + (size_t)mt * 128u;   // [chunk = ks >> 1][ks & 1][mt][hi|lo][lane]
+    size_t base = (size_t)L.w_off + (size_t)ks * WIDE_MT * 128u + (size_t)mt * 128u;   // [k-step][mt][hi|lo][lane]: one chunk per k-step
+    if (L.narrow) {                                                        // [chunk = ks / 4][slot = ks % 4][mt 0..1][hi|lo][lane]
+        if (mt >= 2u) return;
+        base = (size_t)L.w_off + (size_t)(ks >> 2) * WIDE_CHUNK_U4 + (size_t)(ks & 3u) * 256u + (size_t)mt * 128u;
+    }
     a.pack[base + lane] = ph;
     a.pack[base + 64u + lane] = pl;
 }
@@ -327,6 +332,39 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         }
     }
 
+    // A narrow last layer (the mask head's 256 -> n_inst: one tile pair) would stream 16 chunks of which 7/8 are zero
+    // padding -- 39 % of the whole weight stream of that MLP.  Its packed form holds 4 k-steps x 1 pair per chunk instead.
+    auto run_chunk4 = [&](const uint4 (&bh)[4], const uint4 (&bl)[4]) {
+        const uint32_t later = total_chunks - 1u - g;
+        if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
+        else if (later == 1u) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __syncthreads();
+        const bool more = g + 3u < total_chunks;
+        const uint4 *nsrc = a.pack + (size_t)(g + 3u) * WIDE_CHUNK_U4 + tid;
+        const uint32_t ndst = lds_w_off + ((g + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+        }
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        floatx16 c0 = acc[0], c1 = acc[1];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const half8_t A0h = __builtin_bit_cast(half8_t, buf[sl * 256]), A0l = __builtin_bit_cast(half8_t, buf[sl * 256 + 64]);
+            const half8_t A1h = __builtin_bit_cast(half8_t, buf[sl * 256 + 128]), A1l = __builtin_bit_cast(half8_t, buf[sl * 256 + 192]);
+            const half8_t Bh = __builtin_bit_cast(half8_t, bh[sl]), Bl = __builtin_bit_cast(half8_t, bl[sl]);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first, as in run_chunk
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+        }
+        acc[0] = c0; acc[1] = c1;
+        ++g;
+    };
+
     auto x_operand = [&](uint32_t kx, uint4 &bh, uint4 &bl) {            // x[n][16 kx + 8 half + 0..7], zero padded
         float v[8];
         const uint32_t c0 = 16u * kx + 8u * half;
@@ -415,7 +453,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             }
         }
         const uint32_t npairs = (L.mt + 1u) >> 1;
-        if (L.uses_h) {
+        if (L.narrow) {
+#pragma unroll
+            for (int c = 0; c < WIDE_HKS / 4; ++c) {
+                const uint4 bh4[4] = {hbh[4 * c], hbh[4 * c + 1], hbh[4 * c + 2], hbh[4 * c + 3]};
+                const uint4 bl4[4] = {hbl[4 * c], hbl[4 * c + 1], hbl[4 * c + 2], hbl[4 * c + 3]};
+                run_chunk4(bh4, bl4);
+            }
+        } else if (L.uses_h) {
 #pragma unroll
             for (int k = 0; k < WIDE_HKS; ++k) run_chunk(hbh[k], hbl[k], npairs);
         }
@@ -652,7 +697,8 @@ static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) 
         L.mt = div_up(L.out, 32);
         L.has_bias = m->bias[l] ? 1u : 0u;
         L.w_off = (uint32_t)off;
-        off += (size_t)((L.uses_h ? WIDE_HKS : 0) + L.x_ks) * WIDE_CHUNK_U4;
+        L.narrow = (l + 1 == nl && L.uses_h && L.x_ks == 0u && L.mt <= 2u) ? 1u : 0u;
+        off += L.narrow ? (size_t)(WIDE_HKS / 4) * WIDE_CHUNK_U4 : (size_t)((L.uses_h ? WIDE_HKS : 0) + L.x_ks) * WIDE_CHUNK_U4;
     }
     SN_REQUIRE(off < (1ull << 31), "mlp_wide: packed weights too large");
     *total_u4 = off;
