@@ -1,7 +1,7 @@
 """Randomised parity sweep of the fused renderer against the CPU oracle (not part of the test suite: run on the GPU box,
 python tools/fuzz_parity.py [cases] [seed]).  Per case: random schedule (1-3 stages, odd step counts), image size, table
 precision, camera, optional per-ray near/far clamps; tiled and linear ray order (the latter takes the several-lanes-per-ray
-kernels for small batches) must agree bit for bit with each other; sample indices must equal the oracle's, image / depth /
+kernels for small batches) and the opt-in compacting final stage must agree bit for bit with each other; sample indices must equal the oracle's, image / depth /
 weights_sum stay within the fp32 contract."""
 import os
 import sys
@@ -44,7 +44,14 @@ def main():
         tiled = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=W, **kw).items()}
         linear = rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=0, out={}, **kw)
         want = orc.render(oracle_cfg(orc, params, steps, table_f16=f16), ro, rd, cam_near_far=cnf, debug=True)
-        same_order = all(torch.equal(tiled[k], linear[k]) for k in tiled)
+        # the opt-in compacting final stage must reproduce the default kernels bit for bit while nothing is skipped (contracted
+        # scene: no ray misses the aabb), in both ray orders
+        planc = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32, compact_live=True)
+        kwc = dict(cam_near_far=kw["cam_near_far"])
+        cmp_t = rm.render_rays(planc, T(ro, dev), T(rd, dev), tile_w=W, out={}, **kwc)
+        cmp_l = rm.render_rays(planc, T(ro, dev), T(rd, dev), tile_w=0, out={}, **kwc)
+        compact_ok = all(torch.equal(tiled[k], cmp_t[k]) and torch.equal(tiled[k], cmp_l[k]) for k in ("image", "depth", "weights_sum"))
+        same_order = all(torch.equal(tiled[k], linear[k]) for k in tiled) and compact_ok
         inds_ok = all(np.array_equal(tiled[f"inds{k}"].cpu().numpy(), want[f"inds{k}"]) for k in range(1, S))
         ok = same_order and inds_ok
         e_img = float(np.abs(tiled["image"].cpu().numpy() - want["image"]).max())
@@ -53,7 +60,7 @@ def main():
         # north_star: RGB within 1e-4 (the split-fp16 MLP's error grows with the MLP gain drawn above; the test suite's scenes stay < 1e-5)
         ok = ok and e_img <= 1e-4 and e_ws <= 2e-6 and e_dep <= 1.0
         print(f"case {c}: steps={steps} {H}x{W} f16={f16} cnf={cnf is not None}  dRGB={e_img:.1e} dwsum={e_ws:.1e} ddepth(rel 1e-5 units)={e_dep:.2f} "
-              f"tiled==linear:{same_order} inds:{inds_ok}  {'ok' if ok else 'MISMATCH'}")
+              f"tiled==linear==compact:{same_order} inds:{inds_ok}  {'ok' if ok else 'MISMATCH'}")
         bad += 0 if ok else 1
     print("mismatching cases:", bad)
     sys.exit(1 if bad else 0)
