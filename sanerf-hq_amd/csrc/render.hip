@@ -149,7 +149,11 @@ struct Corner { float v[C]; };
 #define SN_BLEND_PKW 1       // packed corner-weight products in the final stage's blends, fp32 tables (same-box: 7.25 -> 7.19 ms; fp16 tables 6.75 -> 6.90, so not there)
 #endif
 #ifndef SN_PROP_GROUP
-#define SN_PROP_GROUP 3      // proposal stage, fp32 tables: levels gathered in groups of 3 + 2 (all 5 at once spills at 128 VGPRs): [128,64,32] 4.70 -> 4.55 ms same-box; fp16 tables fit and lose 2 % with the split
+#define SN_PROP_GROUP 2      // proposal stage: levels gathered in groups of 2 + 2 + 1.  History: all 5 at once spilled at 128 VGPRs; 3 + 2 fitted
+                             // (4.70 -> 4.55 ms); 2 + 2 + 1 fits 96 VGPRs = 5 waves per SIMD instead of 4 (SN_PROP_WAVES): [128,64,32] 4.53 -> 4.44 ms fp32
+#endif
+#ifndef SN_PROP_GROUP_H
+#define SN_PROP_GROUP_H 2    // the same for fp16 tables (78 VGPRs): 4.10 -> 3.98 ms
 #endif
 #ifndef SN_FINAL_LV
 #define SN_FINAL_LV 1        // final stage, K > 0: host-precomputed level constants + wave-uniform interior fast path (FinalLv); A/B switch
@@ -668,8 +672,12 @@ __device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &
     return nr == 1e9f && fr == 1e9f;
 }
 
+#ifndef SN_PROP_WAVES
+#define SN_PROP_WAVES 5      // waves per SIMD the proposal stage is compiled for (register budget 512 / N in steps of 8: 96 VGPRs); the
+                             // stage is bound by each wave's dependent chain, so a fifth wave buys 3-4 % (profiles/r02/ab_round2_experiments.txt)
+#endif
 template <typename TT, int L, int C, int HID, int K>
-__global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
+__global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     constexpr int IN = L * C;
     __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];   // k-major [IN][HID]
     __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];        // [1][HID]
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(256, 4) void k_prop_stage(PropArgs a) {
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
         float feat[L * C];
-        encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : L)>(table, a.g, x01, feat, &a.pairs);
+        encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : SN_PROP_GROUP_H)>(table, a.g, x01, feat, &a.pairs);
         float h[HID], raw[1];
         const uint32_t oz = opaque_zero();
         dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
