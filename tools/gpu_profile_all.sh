@@ -42,6 +42,7 @@ WRITE_SIZE
 LIST
 done
 python $root/tools/traffic_from_pmc.py $out > $out/latest_traffic.json
+cp $out/latest_traffic.json $root/profiles/latest_traffic.json      # the un-profiled bench line at the end of this script reads it (same sources: fingerprint matches)
 # micro-benchmarks
 [ -x $root/tools/ubench/gathers_ub ] && timeout 300 $root/tools/ubench/gathers_ub > $out/ubench_gathers.txt 2>&1
 [ -x $root/tools/ubench/valu_rate_ub ] && timeout 120 $root/tools/ubench/valu_rate_ub > $out/ubench_valu_rate.txt 2>&1
