@@ -31,6 +31,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+#ifndef SN_WIDE_DMA_EARLY
+#define SN_WIDE_DMA_EARLY 1  // the 4 LDS-DMA pieces of chunk g+3 right after the barrier instead of one per tile pair: 0.465 -> 0.450 ms (SAM head MLP, 160 000 rows)
+#endif
+#ifndef SN_WIDE_ABLATE
+#define SN_WIDE_ABLATE 0     // timing experiments only (wrong results): 1 = no per-chunk barrier, 2 = no weight DMA after the prologue, 3 = both
+#endif
 constexpr int WIDE = 256;                 // hidden width this build instantiates
 constexpr int WIDE_MT = WIDE / 32;        // output tiles of a hidden layer
 constexpr int WIDE_HKS = WIDE / 16;       // k-steps that consume a hidden layer
@@ -270,8 +276,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         else if (later == 1u) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
+#if !(SN_WIDE_ABLATE & 1)
         __syncthreads();                   // every wave's pieces of chunk g are in LDS; buffer (g+3)%4 (chunk g-1) is free
-        const bool more = g + 3u < total_chunks;
+#endif
+        const bool more = g + 3u < total_chunks && !(SN_WIDE_ABLATE & 2);
         const uint4 *nsrc = a.pack + (size_t)(g + 3u) * WIDE_CHUNK_U4 + tid;
         const uint32_t ndst = lds_w_off + ((g + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
         const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
@@ -280,6 +288,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         // of the next pair are read one pair ahead, and the scheduling barrier keeps the compiler from hoisting all
         // the chunk's LDS reads (64 registers) to its top
         const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+#if SN_WIDE_DMA_EARLY
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+        }
+#endif
         uint4 ah[2][2], al[2][2];
         ah[0][0] = buf[0]; al[0][0] = buf[64]; ah[0][1] = buf[128]; al[0][1] = buf[192];
 #pragma unroll
@@ -302,7 +316,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             acc[2 * pr] = c0; acc[2 * pr + 1] = c1;
             }
             // the 4 DMA pieces of chunk g+3 go out one per pair (their issue overlaps the matrix pipe)
+#if !SN_WIDE_DMA_EARLY
             if (more) dma16(nsrc + pr * 256, ndst + (uint32_t)pr * 4096u);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         static_assert(PIECES == WIDE_MT / 2, "one DMA piece per output-tile pair");

@@ -1,15 +1,18 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> [-DSWITCH=value ...]   -> tmp_ab/<name>.so : the library built with extra defines (same-box A/B via SN_LIB)
+# usage: [VARIANT_FILE=mlp] tools/build_variant.sh <name> [-DSWITCH=value ...]   -> tmp_ab/<name>.so : the library with ONE source file
+#        (default render.hip) rebuilt with extra defines, the other objects taken from the tree (same-box A/B via SN_LIB)
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tmp_ab/$name; mkdir -p $out
 cd $root/sanerf-hq_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function"
-for f in grid grid_sorted encoders raymarch heads mlp optim; do
+vf=${VARIANT_FILE:-render}
+for f in grid grid_sorted encoders raymarch render heads mlp optim; do
+  [ "$f" = "$vf" ] && continue
   [ -f $root/sanerf-hq_amd/csrc/$f.o ] && cp $root/sanerf-hq_amd/csrc/$f.o $out/$f.o || /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $out/$f.o
 done
-/opt/rocm/bin/hipcc $FLAGS "$@" -c render.hip -o $out/render.o
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $vf.hip -o $out/$vf.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $out/*.o -o $root/tmp_ab/$name.so
 rm -rf $out
 echo built tmp_ab/$name.so
