@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
     };
 
+    const float act_slope = a.leaky ? 0.01f : 0.0f;
     for (uint32_t l = 0; l < a.nl; ++l) {
         const WideLayer L = a.layer[l];
         // bias -> accumulator init (register r of this lane is neuron 32 mt + (r&3) + 8 (r>>2) + 4 half)
@@ -546,8 +547,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
+                        // t > 0 ? t : t * slope (slope 0.01 or 0) as a multiply and a max: slope < 1, so t * slope > t exactly
+                        // when t < 0 (same product, same result; -0 instead of +0 for ReLU of a negative, which the split maps to 0 too)
                         const float t = acc[mt][8 * hf + i];
-                        v[i] = t > 0.0f ? t : (a.leaky ? t * 0.01f : 0.0f);
+                        v[i] = __builtin_fmaxf(t, t * act_slope);
                     }
                     uint4 &bh = hbh[2 * mt + hf], &bl = hbl[2 * mt + hf];
                     split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
