@@ -20,7 +20,8 @@ One "step" = one whole-image render of this rank's band (+ at N>1 the all-gather
 overlaps the render of frame k+1, everything in flight is drained inside the timed region).
 
 Prints ONE JSON line (rank 0): the contract fields plus
-  roofline     — dominant kernel (final stage), HIP-event time measured inside the timed region, against the
+  roofline     — dominant kernel (final stage), HIP-event time per step (all launches of a step summed: an image
+                 beyond 2^21 rays is rendered in row chunks) measured inside the timed region, against the
                  ceilings that bind: the gather address rate of the texture addressers at the
                  shader clock measured in the kernel, the fabric-side traffic from the committed PMC passes;
                  the SURVEY 8(d) algorithmic figure is kept, labelled as cache-absorbed
@@ -228,7 +229,9 @@ def main():
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        per = lambda i: (ms[i] / cnt[i]) if cnt[i] else None     # noqa: E731
+        # kernel time per STEP (= per whole band): an image beyond 2^21 rays is rendered in row chunks, i.e. several launches per
+        # kernel class and step; the ceilings below are priced per band, so the launches of one step are summed
+        per = lambda i: (ms[i] / n_steps) if cnt[i] else None     # noqa: E731
         return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=n_total / (elapsed / n_steps),
                     ms_per_step=elapsed / n_steps * 1e3, median_ms=per_step[len(per_step) // 2], tables=tables,
                     s_bytes=2 if tables == "f16" else 4, final_ms=per(4), final_launches=int(cnt[4]), pack_ms=per(0),
@@ -277,6 +280,7 @@ def main():
         "peak": round(N_CU * clock_hz / GATHER_CYCLES_PER_CU / 1e9, 3) if clock_hz else None,
         "frac": round(ta_floor / final_ms, 4) if ta_floor else None,
         "avg_kernel_ms": round(final_ms, 4), "launches": m["final_launches"],
+        "launches_per_step": round(m["final_launches"] / max(args.steps, 1), 2),
         "floor_ms": round(ta_floor, 4) if ta_floor else None,
         "floor_ms_at_peak_clock": round(floor_ms(PEAK_CLOCK_HZ), 4),
         "shader_clock_mhz": round(m["shader_mhz"], 1), "clock_probe_ms": round(m["probe_ms"], 3),
