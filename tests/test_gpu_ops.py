@@ -857,3 +857,23 @@ def test_wide_mlp_fused_backward_matches_autograd(gpu, N, din, n_out, leaky):
     assert float(gxa[5].abs().max()) == 0.0
     for a_, b_ in zip(gwa, gwb):
         assert float((a_ - b_).norm() / b_.norm()) < 1e-5
+
+
+def test_new_entry_points_accept_empty_batches(gpu):
+    """N = 0 through the round-2 entry points: nothing is launched, nothing faults, shapes are right."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    from sanerf_hq_amd.optim import Adam
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=8, base_resolution=16, log2_hashmap_size=12, desired_resolution=64).to(gpu)
+    mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+    out = rm.mask_head(torch.zeros(0, 32, device=gpu), torch.zeros(0, 32, 3, device=gpu), torch.zeros(0, 32, 15, device=gpu), enc, mlp, 2.0)
+    assert out.shape == (0, 2)
+    p = torch.nn.Parameter(torch.zeros(0, device=gpu))
+    p.grad = torch.zeros(0, device=gpu)
+    Adam([p], lr=1e-3).step()
+    q = torch.nn.Parameter(torch.ones(7, device=gpu))                   # a tail shorter than one 16-byte vector
+    q.grad = torch.full((7,), 0.5, device=gpu)
+    ref = torch.nn.Parameter(q.detach().clone()); ref.grad = q.grad.clone()
+    Adam([q], lr=1e-2, eps=1e-15).step(); torch.optim.Adam([ref], lr=1e-2, eps=1e-15).step()
+    assert float((q - ref).abs().max()) < 1e-6
