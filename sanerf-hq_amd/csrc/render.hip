@@ -672,6 +672,12 @@ __device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &
     return nr == 1e9f && fr == 1e9f;
 }
 
+#ifndef SN_PROP_PB
+#define SN_PROP_PB 4         // cdf entries per block of the sample_pdf merge (pass 2 of the proposal stage); 8: same, 16: slower (select chains)
+#endif
+#ifndef SN_PROP_ABLATE_PASS2
+#define SN_PROP_ABLATE_PASS2 0
+#endif
 #ifndef SN_PROP_WAVES
 #define SN_PROP_WAVES 5      // waves per SIMD the proposal stage is compiled for (register budget 512 / N in steps of 8: 96 VGPRs); the
                              // stage is bound by each wave's dependent chain, so a fifth wave buys 3-4 % (profiles/r02/ab_round2_experiments.txt)
@@ -741,36 +747,70 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     }
 
     // ---- pass 2: sample_pdf (renderer.py:84-119) as one merge of cdf against u ----
+    // The cdf is walked in blocks of PB entries: the block's weights and bins are fetched with independent, coalesced loads
+    // (the former one-entry-at-a-time merge chained T dependent global loads per ray and cost 19 % of the stage), its PB
+    // prefix values are formed in the oracle's order (fp64 running sum of the pdf, rounded per prefix, clamped at 1), and
+    // every lane then emits the outputs whose searchsorted(right=True) count falls inside the block.
+#if SN_PROP_ABLATE_PASS2
+    return;   // timing experiment only
+#endif
     const float wsum = (float)wacc;
     const uint32_t Tq = a.Tn + 1u;
     const float ustart = (float)(0.5 / Tq), uend = (float)(1 - 0.5 / Tq);
     const float ustep = (uend - ustart) / (float)(Tq - 1u);
-    uint32_t i = 0;
+    auto u_at = [&](uint32_t j) -> float { return a.u_tab ? a.u_tab[j < Tq ? j : Tq - 1u] : linspace_at(ustart, uend, ustep, Tq, j); };
+    constexpr uint32_t PB = SN_PROP_PB;
+    uint32_t jq = 0;
+    float uj = u_at(0);
     double acc = 0.0;
-    float c_prev = 0.0f, c_cur = 0.0f;
-    float b_cur = bin_at(0), b_prev = b_cur;
-    for (uint32_t j = 0; j < Tq; ++j) {
-        const float uj = a.u_tab ? a.u_tab[j] : linspace_at(ustart, uend, ustep, Tq, j);
-        while (i <= T && c_cur <= uj) {
-            c_prev = c_cur; b_prev = b_cur;
-            ++i;
-            if (i <= T) {
-                const float pdf = (a.w_scr[(size_t)(i - 1) * Npad + r] + 0.01f) / wsum;
+    float c_start = 0.0f, b_start = bin_at(0);              // cdf[ib], bins[ib]
+    for (uint32_t ib = 0; ib < T; ib += PB) {
+        const bool last_block = ib + PB >= T;
+        float e_c[PB + 1], e_b[PB + 1];                     // entries ib .. ib+PB of the cdf and the bins (past T: repeats of entry T)
+        e_c[0] = c_start; e_b[0] = b_start;
+        float wv[PB];
+#pragma unroll
+        for (uint32_t k = 0; k < PB; ++k) {
+            const uint32_t idx = ib + k < T ? ib + k : T - 1u;
+            wv[k] = a.w_scr[(size_t)idx * Npad + r];
+            e_b[k + 1] = bin_at(idx + 1u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PB; ++k) {
+            if (ib + k < T) {                               // uniform
+                const float pdf = (wv[k] + 0.01f) / wsum;
                 acc += (double)pdf;
                 const float c = (float)acc;
-                c_cur = c > 1.0f ? 1.0f : c;
-                b_cur = bin_at(i);
+                e_c[k + 1] = c > 1.0f ? 1.0f : c;
+            } else {
+                e_c[k + 1] = e_c[k];
             }
         }
-        float c0, c1, bb0, bb1;
-        if (i == 0) { c0 = c_cur; bb0 = b_cur; c1 = c_cur; bb1 = b_cur; }
-        else if (i > T) { c0 = c_prev; bb0 = b_prev; c1 = c_prev; bb1 = b_prev; }
-        else { c0 = c_prev; bb0 = b_prev; c1 = c_cur; bb1 = b_cur; }
-        float t = nan_to_num((uj - c0) / (c1 - c0));
-        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-        const float m = t * (bb1 - bb0);
-        a.bins_out[(size_t)j * Npad + r] = bb0 + m;
-        if (ok && a.dbg_inds) a.dbg_inds[(size_t)n * Tq + j] = (int32_t)i;
+        const uint32_t nb = last_block ? T - ib : PB;       // real entries after e[0] in this block
+        // outputs of this block: all whose u is below the block's last cdf value; in the last block all that remain
+        while (jq < Tq && (last_block || e_c[PB] > uj)) {
+            uint32_t cnt = 0;                                // entries e[0..nb] that are <= uj (e is non-decreasing)
+#pragma unroll
+            for (uint32_t m = 0; m <= PB; ++m) cnt += (m <= nb && e_c[m] <= uj) ? 1u : 0u;
+            const uint32_t i = ib + cnt;                     // = searchsorted(cdf, u, right=True): every entry before ib is <= e[0]
+            // below = entry i-1, above = entry i; i == 0 -> both entry 0; i > T -> both entry T (renderer.py:104-107 clamps)
+            const uint32_t lo_m = cnt == 0u ? 0u : cnt - 1u, hi_m = cnt > nb ? nb : cnt;
+            float c0 = e_c[0], c1 = e_c[0], bb0 = e_b[0], bb1 = e_b[0];
+#pragma unroll
+            for (uint32_t m = 1; m <= PB; ++m) {
+                c0 = lo_m == m ? e_c[m] : c0; bb0 = lo_m == m ? e_b[m] : bb0;
+                c1 = hi_m == m ? e_c[m] : c1; bb1 = hi_m == m ? e_b[m] : bb1;
+            }
+            if (cnt > nb) { c0 = c1; bb0 = bb1; }            // i > T: below = above = the last entry
+            float t = nan_to_num((uj - c0) / (c1 - c0));
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            const float m = t * (bb1 - bb0);
+            a.bins_out[(size_t)jq * Npad + r] = bb0 + m;
+            if (ok && a.dbg_inds) a.dbg_inds[(size_t)n * Tq + jq] = (int32_t)i;
+            ++jq;
+            uj = u_at(jq);
+        }
+        c_start = e_c[PB]; b_start = e_b[PB];
     }
 }
 
