@@ -1,5 +1,7 @@
 """CPU: closed-form identities that pin the encoder arithmetic the reference ships only as CUDA
 (hash grid, SH) and the build's own scalar recipes (exp, half conversion)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -267,3 +269,26 @@ def test_mlp_matches_torch_linear(orc):
     h = torch.nn.functional.leaky_relu(h @ torch.from_numpy(ws[1]).T + torch.from_numpy(bs[1]))
     h = torch.cat([h, xt], -1) @ torch.from_numpy(ws[2]).T + torch.from_numpy(bs[2])
     np.testing.assert_allclose(y, h.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_sh_gradient_include_is_what_the_generator_emits(tmp_path, monkeypatch):
+    """oracle/sh_grad.inc is generated (tools/gen_oracle_sh_grad.py: symbolic partials of the oracle's own SH polynomials); the
+    committed file must be exactly what the generator produces from the committed oracle.c."""
+    sympy = pytest.importorskip("sympy")
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_oracle_sh_grad", os.path.join(root, "tools", "gen_oracle_sh_grad.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(root, "oracle", "sh_grad.inc")).read()
+    real_open = open
+
+    def fake_open(path, mode="r", *a, **k):          # redirect the generator's output file, leave everything else alone
+        if str(path).endswith("sh_grad.inc") and "w" in mode:
+            return real_open(tmp_path / "sh_grad.inc", mode, *a, **k)
+        return real_open(path, mode, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    table = gen.emit(gen.oracle_polys())
+    monkeypatch.undo()
+    assert len(table) == 192
+    assert (tmp_path / "sh_grad.inc").read_text() == committed
