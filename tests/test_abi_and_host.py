@@ -268,3 +268,29 @@ def test_sam_feature_cache_container(tmp_path):
     m = feature_map(samvit, 32, 32, size=(64, 64))
     want = torch.nn.functional.interpolate(samvit.reshape(1, 32, 32, 256).permute(0, 3, 1, 2), (64, 64), mode="bilinear")
     assert m.shape == (1, 256, 64, 64) and torch.equal(m, want)
+
+
+def test_round2_host_logic_has_no_cpu_fallback():
+    """The Python mirror of the round-2 entry points refuses CPU tensors instead of falling back (the product path must
+    fail loudly without the HIP kernels), and the mask head's fusability rule is plain host logic."""
+    import torch
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    from sanerf_hq_amd.optim import Adam
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        Adam([p], lr=1e-3).step()
+    with pytest.raises(ValueError):
+        Adam([p], lr=1e-3, amsgrad=True)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=8, base_resolution=16, log2_hashmap_size=10, desired_resolution=64)
+    mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False)
+    assert rm.mask_head_fusable(enc, mlp, 32, 15)
+    assert not rm.mask_head_fusable(enc, mlp, 48, 15)                                   # samples per ray not a power of two
+    assert not rm.mask_head_fusable(enc, mlp, 256, 15)                                  # more than 128 samples per ray
+    assert not rm.mask_head_fusable(enc, SkipConnMLP(143, 2, 256, 4, skip_layers=[2], bias=False), 32, 15)   # skip layer
+    assert not rm.mask_head_fusable(enc, SkipConnMLP(143, 2, 128, 3, skip_layers=[], bias=False), 32, 15)    # hidden width
+    assert not rm.mask_head_fusable(enc, mlp, 32, 14)                                   # input width does not match
+    with pytest.raises(RuntimeError, match="CUDA"):
+        rm.mask_head(torch.zeros(2, 32), torch.zeros(2, 32, 3), torch.zeros(2, 32, 15), enc, mlp, 2.0)
