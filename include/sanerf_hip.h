@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 5
+#define SN_ABI_VERSION 6
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -242,8 +242,15 @@ typedef struct sn_render_io {
     const float *cam_near_far;              /* [N,2] device or NULL */
     uint32_t     N;
     uint32_t     tile_w;                    /* >0: rays are a row-major image of this width; lanes map to 8x8 pixel tiles */
-    const float *bins0_table;               /* device [num_steps[0]+1] or NULL (-> linspace recipe) */
-    const float *u_table[SN_MAX_STAGES];    /* device [num_steps[k]+1] for k>=1 or NULL */
+    const float *bins0_table;               /* device [num_steps[0]+1], or per ray [N, bins0_ray_stride], or NULL (-> linspace recipe) */
+    const float *u_table[SN_MAX_STAGES];    /* device [num_steps[k]+1] for k>=1, or per ray [N, u_ray_stride[k]], or NULL */
+    uint32_t     bins0_ray_stride;          /* 0: bins0_table is one table shared by all rays; else floats per ray (>= num_steps[0]+1):
+                                             * the per-ray perturbed bins of a training step (renderer.py:267-270) */
+    uint32_t     u_ray_stride[SN_MAX_STAGES]; /* the same for u_table[k]: sample_pdf's perturbed u (renderer.py:101-102) */
+    int32_t      skip_final;                /* != 0: run the proposal stages only and write the LAST stage's resampled bins to
+                                             * bins[num_stages-1] ([N,T_last+1]); image / depth / weights_sum may be NULL.  A training
+                                             * step whose proposal networks are not updated (trainer.py:372-373: 4 steps of 5 after step
+                                             * 3000) takes its final-stage sample positions from here and differentiates only that stage */
     /* outputs */
     float       *image;                     /* [N,3] */
     float       *depth;                     /* [N] */

@@ -655,8 +655,10 @@ struct PropArgs {
     const float *w0, *w1;        // MLP weights (device), [HID][IN], [1][HID]
     uint32_t T, Tn;              // steps of this stage; bins of the next stage = Tn + 1
     const float *bins_in;        // scratch [T+1][Npad] or NULL (stage 0)
-    const float *bins0_tab;      // device [T+1] or NULL (stage 0 only)
-    const float *u_tab;          // device [Tn+1] or NULL
+    const float *bins0_tab;      // device [T+1] (bins0_stride 0) or per ray [N][bins0_stride], or NULL (stage 0 only)
+    const float *u_tab;          // device [Tn+1] (u_stride 0) or per ray [N][u_stride], or NULL
+    uint32_t bins0_stride, u_stride;
+    float *dbg_bins_next;        // [N,Tn+1] or NULL: the resampled bins in the reference's layout (io->skip_final)
     float *w_scr;                // scratch [T][Npad]
     float *bins_out;             // scratch [Tn+1][Npad]
     float *dbg_bins, *dbg_w, *dbg_sigma;  // [N,T+1], [N,T], [N,T] or NULL
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
 
     auto bin_at = [&](uint32_t j) -> float {
         if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
-        if (a.bins0_tab) return a.bins0_tab[j];
+        if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
         return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
     };
 
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     const uint32_t Tq = a.Tn + 1u;
     const float ustart = (float)(0.5 / Tq), uend = (float)(1 - 0.5 / Tq);
     const float ustep = (uend - ustart) / (float)(Tq - 1u);
-    auto u_at = [&](uint32_t j) -> float { return a.u_tab ? a.u_tab[j < Tq ? j : Tq - 1u] : linspace_at(ustart, uend, ustep, Tq, j); };
+    auto u_at = [&](uint32_t j) -> float { return a.u_tab ? a.u_tab[(size_t)n * a.u_stride + (j < Tq ? j : Tq - 1u)] : linspace_at(ustart, uend, ustep, Tq, j); };
     constexpr uint32_t PB = SN_PROP_PB;
     uint32_t jq = 0;
     float uj = u_at(0);
@@ -806,6 +808,7 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
             t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
             const float m = t * (bb1 - bb0);
             a.bins_out[(size_t)jq * Npad + r] = bb0 + m;
+            if (ok && a.dbg_bins_next) a.dbg_bins_next[(size_t)n * Tq + jq] = bb0 + m;
             if (ok && a.dbg_inds) a.dbg_inds[(size_t)n * Tq + jq] = (int32_t)i;
             ++jq;
             uj = u_at(jq);
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
     const float b0step = 1.0f / (float)T;
     auto bin_src = [&](uint32_t j) -> float {
         if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
-        if (a.bins0_tab) return a.bins0_tab[j];
+        if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
         return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
     };
     for (uint32_t j = c; j <= T; j += SP_LPR) l_bins[rl][j] = bin_src(j);
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
     const float ustart = (float)(0.5 / Tq), uend = (float)(1 - 0.5 / Tq);
     const float ustep = (uend - ustart) / (float)(Tq - 1u);
     for (uint32_t jq = c; jq < Tq; jq += SP_LPR) {
-        const float uj = a.u_tab ? a.u_tab[jq] : linspace_at(ustart, uend, ustep, Tq, jq);
+        const float uj = a.u_tab ? a.u_tab[(size_t)n * a.u_stride + jq] : linspace_at(ustart, uend, ustep, Tq, jq);
         uint32_t lo = 0u, hi = T + 1u;                                                   // number of cdf[0..T] entries <= uj
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -937,6 +940,7 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
         t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
         const float m = t * (bb1 - bb0);
         a.bins_out[(size_t)jq * Npad + r] = bb0 + m;
+        if (ok && a.dbg_bins_next) a.dbg_bins_next[(size_t)n * Tq + jq] = bb0 + m;
         if (ok && a.dbg_inds) a.dbg_inds[(size_t)n * Tq + jq] = (int32_t)i;
     }
 }
@@ -954,6 +958,7 @@ struct FinalArgs {
     uint32_t T;
     const float *bins_in;        // scratch [T+1][Npad] or NULL (single-stage)
     const float *bins0_tab;
+    uint32_t bins0_stride;       // 0: bins0_tab is one shared table; else per ray [N][bins0_stride]
     uint32_t sh_degree;
     float *image, *depth, *wsum;
     float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
@@ -1319,7 +1324,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     const float b0step = 1.0f / (float)T;
     auto bin_at = [&](uint32_t j) -> float {
         if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
-        if (a.bins0_tab) return a.bins0_tab[j];
+        if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
         return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
     };
 
@@ -1812,7 +1817,7 @@ __global__ __launch_bounds__(256, 1) void k_final_stage_sp(FinalArgs a, uint32_t
     const float b0step = 1.0f / (float)T;
     auto bin_at = [&](uint32_t j) -> float {
         if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
-        if (a.bins0_tab) return a.bins0_tab[j];
+        if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
         return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
     };
     float dirn[3] = {rs.d[0], rs.d[1], rs.d[2]};
@@ -1979,6 +1984,7 @@ struct FeatArgs {
     uint32_t T;
     const float *bins_in;        // scratch [T+1][Npad] or NULL (single-stage)
     const float *bins0_tab;
+    uint32_t bins0_stride;
     const float *w_in;           // scratch [T][Npad]
     float *out;                  // [N, L*C]
 };
@@ -1996,7 +2002,7 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
     const float b0step = 1.0f / (float)T;
     auto bin_at = [&](uint32_t j) -> float {
         if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
-        if (a.bins0_tab) return a.bins0_tab[j];
+        if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
         return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
     };
     const uint32_t l0 = blockIdx.y * LG;
@@ -2293,7 +2299,10 @@ size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
     SN_REQUIRE(cfg && io, "render_rays: cfg/io is NULL");
     if (io->N == 0) return SN_OK;   // empty batch: nothing to launch, pointers may be NULL
-    SN_REQUIRE(io->rays_o && io->rays_d && io->image && io->depth && io->weights_sum, "render_rays: rays/outputs must be device pointers");
+    SN_REQUIRE(io->rays_o && io->rays_d, "render_rays: rays must be device pointers");
+    if (io->skip_final) SN_REQUIRE(cfg->num_stages >= 2 && io->bins[cfg->num_stages - 1] && !cfg->with_feat,
+                                   "render_rays: skip_final needs >= 2 stages, io->bins[last] for the resampled bins, and no feature stage");
+    else SN_REQUIRE(io->image && io->depth && io->weights_sum, "render_rays: outputs must be device pointers");
     const uint32_t S = cfg->num_stages;
     SN_REQUIRE(S >= 1 && S <= SN_MAX_STAGES, "render_rays: num_stages=%u outside 1..%d", S, SN_MAX_STAGES);
     for (uint32_t k = 0; k < S; ++k) SN_REQUIRE(cfg->num_steps[k] >= 1, "render_rays: num_steps[%u] must be >= 1", k);
@@ -2408,7 +2417,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     // opt-in compaction: k_final_stage_cmp replaces the last stage when nothing per-sample leaves the call (those tensors
     // must be complete) and the table has the FinalLv shape; the proposal stages then drop waves of missed rays as well
     bool use_cmp = false;
-    if (cfg->compact_live && mlp_mode == MLP_F16X3 && !cfg->with_feat && !io->xyzs_last && !io->geo_feat_last) {
+    if (cfg->compact_live && mlp_mode == MLP_F16X3 && !cfg->with_feat && !io->xyzs_last && !io->geo_feat_last && !io->skip_final &&
+        io->bins0_ray_stride == 0) {
         bool any_dbg = false;
         for (uint32_t k = 0; k < S; ++k) any_dbg = any_dbg || io->bins[k] || io->weights[k] || io->sigmas[k] || io->inds[k];
         FinalLv probe;
@@ -2459,8 +2469,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             pa.rc = rc; pa.g = gl_prop[k]; pa.table = cfg->prop_grid[k].embeddings;
             pa.w0 = cfg->prop_mlp[k].weight[0]; pa.w1 = cfg->prop_mlp[k].weight[1];
             pa.T = cfg->num_steps[k]; pa.Tn = cfg->num_steps[k + 1];
-            pa.bins_in = b_scr[k]; pa.bins0_tab = k == 0 ? io->bins0_table : nullptr;
-            pa.u_tab = io->u_table[k + 1];
+            pa.bins_in = b_scr[k];
+            pa.bins0_stride = io->bins0_ray_stride; pa.u_stride = io->u_ray_stride[k + 1];
+            pa.bins0_tab = (k == 0 && io->bins0_table) ? io->bins0_table + (size_t)first * pa.bins0_stride : nullptr;
+            pa.u_tab = io->u_table[k + 1] ? io->u_table[k + 1] + (size_t)first * pa.u_stride : nullptr;
+            pa.dbg_bins_next = (io->skip_final && k + 2 == S && io->bins[S - 1]) ? io->bins[S - 1] + (size_t)first * (cfg->num_steps[S - 1] + 1) : nullptr;
             pa.w_scr = w_scr[k]; pa.bins_out = b_scr[k + 1];
             pa.dbg_bins = io->bins[k] ? io->bins[k] + (size_t)first * (pa.T + 1) : nullptr;
             pa.dbg_w = io->weights[k] ? io->weights[k] + (size_t)first * pa.T : nullptr;
@@ -2493,7 +2506,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.rc = rc; fa.g = gl_main; fa.table = cfg->grid.embeddings; fa.mlp_pack = pack;
         for (int l = 0; l < 3; ++l) { fa.w[l] = cfg->grid_mlp.weight[l]; fa.vw[l] = cfg->view_mlp.weight[l]; }
         fa.T = cfg->num_steps[S - 1];
-        fa.bins_in = b_scr[S - 1]; fa.bins0_tab = S == 1 ? io->bins0_table : nullptr;
+        if (io->skip_final) continue;                      // proposal stages only: their last resampled bins went to io->bins[S-1]
+        fa.bins_in = b_scr[S - 1]; fa.bins0_stride = io->bins0_ray_stride;
+        fa.bins0_tab = (S == 1 && io->bins0_table) ? io->bins0_table + (size_t)first * fa.bins0_stride : nullptr;
         fa.sh_degree = cfg->sh_degree;
         fa.image = io->image + (size_t)first * 3; fa.depth = io->depth + first; fa.wsum = io->weights_sum + first;
         fa.dbg_bins = io->bins[S - 1] ? io->bins[S - 1] + (size_t)first * (fa.T + 1) : nullptr;
@@ -2576,7 +2591,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         if (cfg->with_feat) {
             FeatArgs ft;
             ft.rc = rc; ft.g = gl_feat; ft.table = cfg->feat_grid.embeddings; ft.T = cfg->num_steps[S - 1];
-            ft.bins_in = b_scr[S - 1]; ft.bins0_tab = S == 1 ? io->bins0_table : nullptr;
+            ft.bins_in = b_scr[S - 1]; ft.bins0_stride = io->bins0_ray_stride;
+            ft.bins0_tab = (S == 1 && io->bins0_table) ? io->bins0_table + (size_t)first * ft.bins0_stride : nullptr;
             ft.w_in = w_scr[S - 1];
             ft.out = io->f_feat + (size_t)first * gl_feat.L * gl_feat.C;
             const bool h16 = cfg->feat_grid.table_dtype == SN_F16;

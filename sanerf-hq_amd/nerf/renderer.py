@@ -315,8 +315,36 @@ class NeRFRenderer(nn.Module):
         all_bins, all_weights = [], []
         steps = opt.num_steps
         bins = weights = None
+        # Proposal networks that receive no gradient in this call (trainer.py:372-373: after step 3000 they are updated on every
+        # 5th step only; mask / SAM training never updates them) are pure inference: their stages run in the fused kernels --
+        # per-ray perturbed bins and u as inputs, exactly the reference's jitter (renderer.py:101-102, 267-270) -- and only the
+        # last stage, which carries the gradients, goes through the autograd operators below.
+        prop_needs_grad = update_proposal and torch.is_grad_enabled() and any(
+            p.requires_grad for m in (list(self.prop_encoders) + list(self.prop_mlp)) for p in m.parameters())
+        wants_prop_loss = self.training and not opt.with_mask and not opt.with_sam and opt.lambda_proposal > 0 and update_proposal
+        first_stage = 0
+        if (len(steps) > 1 and not prop_needs_grad and not wants_prop_loss and rays_o.is_cuda and self._fused_shape()
+                and os.environ.get("SN_FUSED_PROPOSALS", "1") != "0"):
+            b0 = torch.linspace(0, 1, steps[0] + 1, device=device)
+            u_tabs = None
+            if perturb:
+                b0 = (b0.unsqueeze(0).expand(N, -1) + (torch.rand(N, steps[0] + 1, device=device) - 0.5) / steps[0]).clamp(0, 1)
+                u_tabs = {}
+                for k in range(1, len(steps)):
+                    Tq = steps[k] + 1
+                    base = torch.linspace(0.5 / Tq, 1 - 0.5 / Tq, steps=Tq, device=device)
+                    u_tabs[k] = base.unsqueeze(0).expand(N, -1) + (torch.rand(N, Tq, device=device) - 0.5) / Tq
+            with torch.no_grad():
+                got = rm.render_rays(self._get_plan(), rays_o, rays_d, cam_near_far=cam_near_far, bins0_table=b0, u_tables=u_tabs,
+                                     skip_final=True, out={})
+            bins = got[f"bins{len(steps) - 1}"]
+            first_stage = len(steps) - 1
         for k, T in enumerate(steps):
-            if k == 0:
+            if k < first_stage:
+                continue
+            if k == first_stage and first_stage > 0:
+                pass                                            # bins of the last stage came from the fused proposal stages
+            elif k == 0:
                 bins = torch.linspace(0, 1, T + 1, device=device).unsqueeze(0).expand(N, -1)
                 if perturb:
                     bins = (bins + (torch.rand_like(bins) - 0.5) / T).clamp(0, 1)

@@ -540,7 +540,8 @@ class RenderPlan:
 
 def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: float = 1.0, tile_w: int = 0,
                 want: Sequence[str] = (), u_tables: Optional[Dict[int, torch.Tensor]] = None,
-                bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None):
+                bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None,
+                skip_final: bool = False):
     """Fused render of N rays.  Returns dict(image [N,3], depth [N], weights_sum [N]) plus the
     per-stage tensors named in `want`: 'bins', 'weights', 'sigmas', 'inds' (all stages),
     'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'; a plan built with `feat_encoder` also
@@ -568,16 +569,31 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         keep.append(cnf)
         io.cam_near_far = _lib.dev(cnf, "cam_near_far")
     io.N, io.tile_w = N, int(tile_w)
-    if bins0_table is not None:
+    if bins0_table is not None:      # [T0+1]: one table for all rays; [N, T0+1]: per ray (a training step's perturbed bins)
         b0 = bins0_table.to(device).contiguous().float(); keep.append(b0); io.bins0_table = b0.data_ptr()
+        if b0.dim() == 2:
+            if b0.shape != (N, plan.num_steps[0] + 1):
+                raise RuntimeError(f"bins0_table: expected [{N}, {plan.num_steps[0] + 1}] per-ray bins, got {tuple(b0.shape)}")
+            io.bins0_ray_stride = b0.shape[1]
     if u_tables:
         for k, u in u_tables.items():
             u = u.to(device).contiguous().float(); keep.append(u); io.u_table[k] = u.data_ptr()
-    io.image = _lib.dev(buf("image", (N, 3)), "image")
-    io.depth = _lib.dev(buf("depth", (N,)), "depth")
-    io.weights_sum = _lib.dev(buf("weights_sum", (N,)), "weights_sum")
+            if u.dim() == 2:
+                if u.shape != (N, plan.num_steps[k] + 1):
+                    raise RuntimeError(f"u_tables[{k}]: expected [{N}, {plan.num_steps[k] + 1}] per-ray values, got {tuple(u.shape)}")
+                io.u_ray_stride[k] = u.shape[1]
     S = plan.cfg.num_stages
     want = set(want)
+    if skip_final:                   # proposal stages only: the last stage's resampled bins [N, T_last+1] are the result
+        if S < 2:
+            raise RuntimeError("render_rays(skip_final=True) needs a schedule with proposal stages")
+        io.skip_final = 1
+        want = set()
+        io.bins[S - 1] = buf(f"bins{S - 1}", (N, plan.num_steps[S - 1] + 1)).data_ptr()
+    else:
+        io.image = _lib.dev(buf("image", (N, 3)), "image")
+        io.depth = _lib.dev(buf("depth", (N,)), "depth")
+        io.weights_sum = _lib.dev(buf("weights_sum", (N,)), "weights_sum")
     for k in range(S):
         T = plan.num_steps[k]
         if "bins" in want:
@@ -595,7 +611,7 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         io.geo_feat_last = buf("geo_feat_last", (N, Tl, plan.geo)).data_ptr()
     if "f_image" in want:
         io.f_image = buf("f_image", (N, plan.ncol)).data_ptr()
-    if plan.cfg.with_feat:
+    if plan.cfg.with_feat and not skip_final:
         io.f_feat = buf("f_feat", (N, plan.feat_dim)).data_ptr()
     ws = plan.workspace(N, int(tile_w), device)
     io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sanerf_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names, "ctypes signature table out of sync with the header"
-    assert lib.sn_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.sn_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_library_reports_missing_device_loudly():

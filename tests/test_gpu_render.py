@@ -247,6 +247,57 @@ def test_rgb_training_path_is_differentiable(gpu, orc):
     assert torch.isfinite(pert["image"]).all()
 
 
+def test_training_step_with_frozen_proposals_uses_the_fused_proposal_stages(gpu, orc, monkeypatch):
+    """trainer.py:372-373: after step 3000 four training steps of five run with update_proposal=False.  Their proposal stages
+    are inference and go through the fused kernels (render_rays(skip_final=True) with per-ray bins / u tables); only the last
+    stage is differentiated.  With perturb=False both routes must give the same image (to fp32 round-off) and the same
+    gradients of the field; with perturb=True the jitter is
+    random, so only sanity (finite, proposal nets untouched) is checked; per-ray tables are checked directly against the
+    stand-alone sample_pdf."""
+    from sanerf_hq_amd import raymarching as rm
+    steps = [128, 64, 32]
+    params = synthetic_params(steps, seed=9)
+    model = product_model(params, steps, False, gpu).train()
+    _, _, ro, rd = camera_rays(orc, 24, 24)
+    ro_t, rd_t = T(ro, gpu), T(rd, gpu)
+    N = ro_t.shape[0]
+    res = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("SN_FUSED_PROPOSALS", route)
+        for p in model.parameters():
+            p.grad = None
+        out = model.render(ro_t, rd_t, staged=False, perturb=False, update_proposal=False)
+        out["image"].square().mean().backward()
+        res[route] = (out["image"].detach().clone(), model.grid.embeddings.grad.clone(), model.grid_mlp.net[0].weight.grad.clone(),
+                      model.view_mlp.net[2].weight.grad.clone())
+        assert all(p.grad is None for m in (model.prop_encoders, model.prop_mlp) for p in m.parameters())
+    # the operator chain evaluates the proposal MLPs with torch GEMMs, the fused stages with the oracle's fmaf chains: sigma differs
+    # in the last bit, hence bins by an ulp
+    assert float((res["1"][0] - res["0"][0]).abs().max()) <= 2e-5
+    # (a sample position that moves by an ulp across a cell border of a fine level sends its table gradient to other rows:
+    # the sparse table gradient gets the wider bound)
+    for a_, b_, tol in zip(res["1"][1:], res["0"][1:], (1e-2, 1e-3, 1e-3)):
+        assert float((a_ - b_).double().norm() / b_.double().norm()) <= tol
+    monkeypatch.setenv("SN_FUSED_PROPOSALS", "1")
+    pert = model.render(ro_t, rd_t, staged=False, perturb=True, update_proposal=False)
+    assert torch.isfinite(pert["image"]).all() and float((pert["image"] - res["1"][0]).abs().max()) > 0
+    # per-ray tables: the fused stages against the operator chain on the SAME perturbed inputs
+    torch.manual_seed(1)
+    b0 = (torch.linspace(0, 1, 129, device=gpu).expand(N, -1) + (torch.rand(N, 129, device=gpu) - 0.5) / 128).clamp(0, 1)
+    u1 = torch.linspace(0.5 / 65, 1 - 0.5 / 65, 65, device=gpu).expand(N, -1) + (torch.rand(N, 65, device=gpu) - 0.5) / 65
+    u2 = torch.linspace(0.5 / 33, 1 - 0.5 / 33, 33, device=gpu).expand(N, -1) + (torch.rand(N, 33, device=gpu) - 0.5) / 33
+    model.eval()
+    with torch.no_grad():
+        plan = rm.RenderPlan(model, steps)
+        fused = rm.render_rays(plan, ro_t, rd_t, bins0_table=b0, u_tables={1: u1, 2: u2}, skip_final=True)["bins2"].clone()
+        full = rm.render_rays(plan, ro_t, rd_t, bins0_table=b0, u_tables={1: u1, 2: u2}, want=["bins", "weights"], out={})
+        assert torch.equal(full["bins0"], b0) and torch.equal(full["bins2"], fused)
+        chain1 = rm.sample_pdf(full["bins0"], full["weights0"], 65, u=u1)
+        assert torch.equal(chain1, full["bins1"])
+        chain2 = rm.sample_pdf(full["bins1"], full["weights1"], 33, u=u2)
+        assert torch.equal(chain2, fused)
+
+
 def test_fp16_tables_stay_close(gpu, orc):
     """Half-precision table storage (BASELINE configs[1] says fp16): arithmetic stays fp32, so the result equals
     the oracle run on the rounded tables; versus fp32 tables the image moves by table-rounding error only."""

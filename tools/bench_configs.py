@@ -170,6 +170,12 @@ def main():
     t_st = timeit(rgb_step)
     out["RGB_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_st * 1e3, 3),
                                           "rays_per_s_step": round(N / t_st, 1)}
+    # trainer.py:372-373: after step 3000 the proposal networks are updated on every 5th step only; the other four run this:
+    def rgb_fwd_bwd_frozen_proposal():
+        optim.zero_grad(set_to_none=True)
+        o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=False)
+        torch.nn.functional.mse_loss(o["image"], gt).backward()
+    out["RGB_training_step_4096_rays"]["fwd_bwd_without_proposal_update_ms"] = round(timeit(rgb_fwd_bwd_frozen_proposal) * 1e3, 3)
     opt.lambda_distort = 0.02                                       # the reference's default loss: + distortion term
     out["RGB_training_step_4096_rays"]["fwd_bwd_with_distort_loss_ms"] = round(timeit(rgb_fwd_bwd) * 1e3, 3)
     opt.lambda_distort = 0.0
