@@ -17,6 +17,7 @@ for sch in flat128 ref; do for tb in f32 f16; do
 done; done
 stats c3_sam_head python $root/tools/c3_profile.py
 stats train_rgb python $root/tools/train_profile.py rgb
+stats train_rgb_noprop python $root/tools/train_profile.py rgb_noprop
 stats train_mask python $root/tools/train_profile.py mask
 stats mask_head python $root/tools/mask_profile.py mask
 stats compact_live python $root/tools/mask_profile.py compact

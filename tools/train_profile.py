@@ -17,7 +17,7 @@ H = W = 512; N = 4096
 roF, rdF = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
 pix = torch.from_numpy((synth.hash_u01(N, 99) * (H * W)).astype(np.int64)).to(dev)
 ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
-if mode == "rgb":
+if mode in ("rgb", "rgb_noprop"):
     opt = make_opt(); opt.lambda_proposal, opt.lambda_distort = 1.0, 0.0
     model = NeRFNetwork(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_params([128, 64, 32], seed=1).items()}, strict=False)
@@ -25,10 +25,14 @@ if mode == "rgb":
     gt = torch.from_numpy(synth.hash_uniform((N, 3), 42, 0.0, 1.0)).to(dev)
     from sanerf_hq_amd.optim import Adam as HipAdam
     optim = (torch.optim.Adam if os.environ.get("SN_PROFILE_TORCH_ADAM") else HipAdam)(model.get_params(1e-2), eps=1e-15)
+    upd = mode == "rgb"                                        # "rgb_noprop": the step the reference runs 4 times of 5 after step 3000 (trainer.py:372-373)
     def step():
         optim.zero_grad(set_to_none=True)
-        o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=True)
-        (torch.nn.functional.mse_loss(o["image"], gt) + o["proposal_loss"]).backward()
+        o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=upd)
+        loss = torch.nn.functional.mse_loss(o["image"], gt)
+        if upd:
+            loss = loss + o["proposal_loss"]
+        loss.backward()
         optim.step()
 else:
     opt = make_opt(with_mask=True)
