@@ -481,16 +481,44 @@ __device__ __forceinline__ void issue_level_lv(const FinalLv &lv, const float (&
     }
 }
 
-template <typename T, int G, int K, int GRP, bool FAST>
-__device__ __forceinline__ void issue_group_lv(const FinalLv &lv, const float (&x01)[3], GroupRegs<T, 2, G> &r) {
+// levels L0 .. L0+G-1 (a "span": the gather groups of the final stage need not be equally long)
+template <typename T, int L0, int G, int K, bool FAST>
+__device__ __forceinline__ void issue_span_lv(const FinalLv &lv, const float (&x01)[3], GroupRegs<T, 2, G> &r) {
     r.oob = false;
     static_for<0, G>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        constexpr int l = GRP * G + k;
+        constexpr int l = L0 + k;
         constexpr bool DENSE = l < K;
         issue_level_lv<T, DENSE, FAST, xswap_level<T, DENSE ? 0 : 1, l>(), l>(lv, x01, r.pos[k], r.cv[k]);
     });
 }
+template <typename T, int G, int K, int GRP, bool FAST>
+__device__ __forceinline__ void issue_group_lv(const FinalLv &lv, const float (&x01)[3], GroupRegs<T, 2, G> &r) {
+    issue_span_lv<T, GRP * G, G, K, FAST>(lv, x01, r);
+}
+template <typename T, int L0, int G, int K, typename Emit>
+__device__ __forceinline__ void blend_span(const GroupRegs<T, 2, G> &r, Emit emit) {
+    static_for<0, G>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int l = L0 + k;
+        constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
+        float acc[2];
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        emit(l, acc);
+    });
+}
+// gather spans of the final stage (FinalLv path).  Span 0 is issued for sample j+1 before the matrix-core phase of sample j
+// (its registers are live across that phase), so it has to be short when the MLP needs many registers; it must be all dense.
+#ifndef SN_FINAL_SPANS
+#define SN_FINAL_SPANS 0
+#endif
+template <int CFG> struct FinalSpans;
+template <> struct FinalSpans<0> { static constexpr int N = 4; static constexpr int B[5] = {0, 4, 8, 12, 16}; };
+template <> struct FinalSpans<1> { static constexpr int N = 4; static constexpr int B[5] = {0, 2, 6, 11, 16}; };
+template <> struct FinalSpans<2> { static constexpr int N = 4; static constexpr int B[5] = {0, 3, 7, 12, 16}; };
+template <> struct FinalSpans<3> { static constexpr int N = 4; static constexpr int B[5] = {0, 1, 6, 11, 16}; };
+template <> struct FinalSpans<4> { static constexpr int N = 5; static constexpr int B[6] = {0, 2, 5, 9, 13, 16}; };
 
 // FAST test of one sample (see FinalLv): wave-uniform
 __device__ __forceinline__ bool all_interior(const FinalLv &lv, const float (&x01)[3]) {
@@ -1139,9 +1167,23 @@ __global__ void k_pack_grid_mlp_f16(const float *__restrict__ w1, const float *_
     pack[(vec * 2u + 1u) * 64u + lane] = pl;
 }
 
+#ifndef SN_FINAL_ABLATE
+#define SN_FINAL_ABLATE 0    // timing / power experiments only (wrong results): 1 = no matrix-core MLP in k_final_stage, 2 = one weight read
+                             // per layer (no LDS weight stream), 4 = matrix instructions replaced by a vector op, 8 = two products of three
+#endif
 __device__ __forceinline__ floatx16 mfma3(const uint4 &ah, const uint4 &al, const uint4 &bh, const uint4 &bl, floatx16 acc) {
     const half8_t Ah = __builtin_bit_cast(half8_t, ah), Al = __builtin_bit_cast(half8_t, al);
     const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+#if SN_FINAL_ABLATE & 4
+    acc[0] += __uint_as_float((ah.x ^ bh.x) & 0x3fffffffu); acc[5] += __uint_as_float((al.y ^ bl.y) & 0x3fffffffu);
+    acc[9] += __uint_as_float((ah.z ^ bl.z) & 0x3fffffffu); acc[14] += __uint_as_float((al.w ^ bh.w) & 0x3fffffffu);
+    return acc;
+#endif
+#if SN_FINAL_ABLATE & 8
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+    return acc;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);   // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
@@ -1174,7 +1216,7 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
             for (int st = 0; st < 2; ++st) {
                 const uint4 bh = *reinterpret_cast<const uint4 *>(slab_hi + row + 8 * st);
                 const uint4 bl = *reinterpret_cast<const uint4 *>(slab_lo + row + 8 * st);
-                const int vec = mt * 2 + st;
+                const int vec = (SN_FINAL_ABLATE & 2) ? 0 : mt * 2 + st;
                 acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
             }
             h1[mt] = acc;
@@ -1187,20 +1229,33 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
             for (int q = 0; q < 4; ++q) {
                 uint4 bh, bl;
                 acc_to_b(h1[q >> 1], q & 1, bh, bl);
-                const int vec = 4 + mt * 4 + q;
+                const int vec = (SN_FINAL_ABLATE & 2) ? 4 : 4 + mt * 4 + q;
                 acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
             }
             h2[mt] = acc;
             __builtin_amdgcn_sched_barrier(0);
         }
         floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if SN_FINAL_ABLATE & 16
+        // timing experiment: layer 3 off the matrix cores -- 64 relu + 64 fma (dot) + 64 fma (accumulate) of vector work instead
+        {
+            float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float x0 = relu_bits(h2[0][i]), x1 = relu_bits(h2[1][i]);
+                d0 = __builtin_fmaf(x0, __uint_as_float(0x3c000000u + i), d0); d1 = __builtin_fmaf(x1, __uint_as_float(0x3c100000u + i), d1);
+                acc[i & 7] = __builtin_fmaf(d0, x0, acc[i & 7]); acc[(i + 3) & 7] = __builtin_fmaf(d1, x1, acc[(i + 3) & 7]);
+            }
+        }
+#else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 bh, bl;
             acc_to_b(h2[q >> 1], q & 1, bh, bl);
-            const int vec = 12 + q;
+            const int vec = (SN_FINAL_ABLATE & 2) ? 12 : 12 + q;
             acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
         }
+#endif
 #pragma unroll
         for (int r = 0; r < 8; ++r) res[tile][r] = acc[r];
         __builtin_amdgcn_sched_barrier(0);
@@ -1208,6 +1263,76 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(res[0][r]), __float_as_uint(res[1][r]), false, false);
+        const int base = (r & 3) + 8 * (r >> 2);
+        out[base] = __uint_as_float(rr[0]);
+        out[base + 4] = __uint_as_float(rr[1]);
+    }
+}
+
+// The same MLP with BOTH 32-sample tiles of the wave advancing together: every weight operand is read from LDS once per
+// wave-sample instead of once per tile (64 -> 32 ds_read_b128 of 1 KiB; the weight stream was 12 % of the final stage:
+// timing with the reads removed, profiles/r03/ab_round3_experiments.txt) and the matrix pipe always has two to four
+// independent accumulators in flight.  Every accumulator still receives exactly the same sequence of products (k-steps
+// ascending, small terms first), so the results are bit-identical to grid_mlp_mfma16.  Costs 64 more live registers at
+// the layer-2 peak (both tiles' h1 and all four layer-2 accumulators), paid for with a shorter prefetched gather span.
+__device__ __forceinline__ void grid_mlp_mfma16_2t(const uint4 *__restrict__ pk, const uint32_t *__restrict__ slab_hi,
+                                                   const uint32_t *__restrict__ slab_lo, float (&out)[16]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = lane & 31u, hi = lane >> 5;
+    const floatx16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    floatx16 h1[2][2];                                    // [tile][mt]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { h1[t][0] = zero16; h1[t][1] = zero16; }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        uint4 bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t row = (t * 32u + lo) * SLAB_STRIDE + 4u * hi + 8u * st;
+            bh[t] = *reinterpret_cast<const uint4 *>(slab_hi + row);
+            bl[t] = *reinterpret_cast<const uint4 *>(slab_lo + row);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int vec = mt * 2 + st;
+            const uint4 ah = pk[(vec * 2 + 0) * 64 + lane], al = pk[(vec * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) h1[t][mt] = mfma3(ah, al, bh[t], bl[t], h1[t][mt]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    floatx16 h2[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { h2[t][0] = zero16; h2[t][1] = zero16; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint4 bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc_to_b(h1[t][q >> 1], q & 1, bh[t], bl[t]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int vec = 4 + mt * 4 + q;
+            const uint4 ah = pk[(vec * 2 + 0) * 64 + lane], al = pk[(vec * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) h2[t][mt] = mfma3(ah, al, bh[t], bl[t], h2[t][mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                // one k-step at a time: h1 dies in halves behind this loop
+    }
+    floatx16 o3[2] = {zero16, zero16};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint4 bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc_to_b(h2[t][q >> 1], q & 1, bh[t], bl[t]);
+        const int vec = 12 + q;
+        const uint4 ah = pk[(vec * 2 + 0) * 64 + lane], al = pk[(vec * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o3[t] = mfma3(ah, al, bh[t], bl[t], o3[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(o3[0][r]), __float_as_uint(o3[1][r]), false, false);
         const int base = (r & 3) + 8 * (r >> 2);
         out[base] = __uint_as_float(rr[0]);
         out[base + 4] = __uint_as_float(rr[1]);
@@ -1261,11 +1386,20 @@ __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, c
 }
 
 enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
+#ifndef SN_FINAL_2T
+#define SN_FINAL_2T 0        // final stage (FinalLv path): both tiles of the wave share every weight read (grid_mlp_mfma16_2t)
+#endif
+#ifndef SN_RS_SPANS_H
+#define SN_RS_SPANS_H 6      // role-split producers, fp16 tables: 6 spans like fp32 tables, or 4 spans of 4 levels
+#endif
+#ifndef SN_FINAL_WAVES
+#define SN_FINAL_WAVES 2     // waves per SIMD k_final_stage is compiled for (register budget); experiments only
+#endif
 
 // AUX: the instantiation that also serves the feature stage (weights -> scratch) and the opt-in early termination;
 // the plain one carries neither (one spilled register less in the march of the headline configuration)
 template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false>
-__global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(FinalArgs a) {
+__global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_final_stage(FinalArgs a) {
     constexpr bool MFMA = MODE != MLP_VALU;
     constexpr int IN = L * C;
     constexpr int GEO = NOUT - 1;
@@ -1348,18 +1482,21 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
     float rb_prev = real_bin(rs, bprev);
     if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
     // software pipeline (MLP_F16X3): group 0 of sample j+1 is issued before the matrix-core phase of sample j
-    constexpr int PG = 4;                                   // levels per gather group
-    GroupRegs<TT, 2, PG> g0;
+    constexpr int PG = 4;                                   // levels per gather group (generic instantiations)
+    constexpr bool LV = SN_FINAL_LV && MODE == MLP_F16X3 && K >= PG && K <= 8;   // FinalLv path; the prefetched span is all dense
+    using SP = FinalSpans<LV ? SN_FINAL_SPANS : 0>;         // FinalLv path: gather spans (span 0 crosses the matrix-core phase)
+    constexpr int G0 = LV ? SP::B[1] : PG;
+    static_assert(!LV || (L == 16 && SP::B[SP::N] == L && G0 <= K), "spans cover the 16 levels; span 0 is dense");
+    GroupRegs<TT, 2, G0> g0;
     float bnext_n = bin_at(1);
     float rb_next_n = real_bin(rs, bnext_n);
     float tmid_n = (rb_next_n + rb_prev) / 2.0f;
     float p_n[3], x01_n[3];
     sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-    constexpr bool LV = SN_FINAL_LV && MODE == MLP_F16X3 && K >= PG && K <= 8;   // FinalLv path; the prefetched group 0 is all dense
     bool fast_n = false;
     if constexpr (LV) {
         fast_n = all_interior(a.lv, x01_n);
-        issue_group_lv<TT, PG, K, 0, false>(a.lv, x01_n, g0);
+        issue_span_lv<TT, 0, G0, K, false>(a.lv, x01_n, g0);
         __builtin_amdgcn_sched_barrier(0);
     } else if constexpr (MODE == MLP_F16X3) {
         issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
@@ -1380,7 +1517,8 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 row_hi[l] = ph;
                 row_lo[l] = pl;
             };
-            blend_group<TT, 2, PG, K, 0>(g0, emit);
+            if constexpr (LV) blend_span<TT, 0, G0, K>(g0, emit);
+            else blend_group<TT, 2, PG, K, 0>(g0, emit);
             __builtin_amdgcn_sched_barrier(0);
             auto zero_oob = [&]() {
                 const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
@@ -1391,12 +1529,12 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
             if constexpr (LV) {
                 auto rest = [&](auto fast_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
-                    static_for<1, L / PG>([&](auto gg) {
-                        constexpr int GRP = decltype(gg)::value;
-                        GroupRegs<TT, 2, PG> gr;
-                        issue_group_lv<TT, PG, K, GRP, FAST>(a.lv, x01, gr);
+                    static_for<1, SP::N>([&](auto gg) {
+                        constexpr int SPAN = decltype(gg)::value, L0 = SP::B[SPAN], G = SP::B[SPAN + 1] - L0;
+                        GroupRegs<TT, 2, G> gr;
+                        issue_span_lv<TT, L0, G, K, FAST>(a.lv, x01, gr);
                         __builtin_amdgcn_sched_barrier(0);
-                        blend_group<TT, 2, PG, K, GRP>(gr, emit);
+                        blend_span<TT, L0, G, K>(gr, emit);
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 };
@@ -1422,14 +1560,21 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
                 sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
                 if constexpr (LV) {
                     fast_n = all_interior(a.lv, x01_n);
-                    issue_group_lv<TT, PG, K, 0, false>(a.lv, x01_n, g0);
+                    issue_span_lv<TT, 0, G0, K, false>(a.lv, x01_n, g0);
                 } else {
                     issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_wave_barrier();
+#if SN_FINAL_ABLATE & 1
+            for (int k = 0; k < NOUT; ++k) h[k] = __uint_as_float(row_hi[k] ^ row_lo[k]);
+#elif SN_FINAL_2T
+            if constexpr (LV) grid_mlp_mfma16_2t(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+            else grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+#else
             grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+#endif
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (MODE == MLP_F32) {
             encode_levels_lds<TT, L, C, 2, K>(table, a.g, x01, fe, fstride);
@@ -1525,6 +1670,398 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : 2) void k_final_stage(F
         if (a.dbg_fimg) {
 #pragma unroll
             for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// final stage, role-split waves (k_final_stage_rs; SN_RENDER_RS)
+// ------------------------------------------------------------------------------------------
+// In k_final_stage every wave alternates between two very different phases: the gather / blend phase (vector ALU + texture
+// path, bound by memory round trips: ~1.4 us each, four per sample, in-flight data limited by the registers the MLP holds) and
+// the matrix-core phase (accumulators + operand images that are dead weight during the gathers).  Here the two phases run in
+// different waves of one 768-thread workgroup (one per CU):
+//   * producer waves 0-7 own an 8x8-pixel tile each (the workgroup a 32x16 tile).  They do geometry, gathers and blends only,
+//     keep TWO gather spans in flight (issue span s+1, then blend span s -- no matrix-core registers to hold back), and hand
+//     the 32 features of every sample to a consumer through LDS in two 8-level halves;
+//   * consumer waves 8-11 (one per SIMD) each serve two producers: fp16 hi / lo split, the 32-64-64-16 MLP on the matrix cores,
+//     exp, ordered compositing (they hold the per-ray state of both producers' rays) and, at the end, the per-ray colour head.
+// Hand-over without workgroup barriers: per producer a ring of three half-sample images (64 rows x 16 floats, unpadded, 16-byte
+// blocks XOR-swizzled by (row >> 2) & 3: conflict-free for the consumers' ds_read_b128) and two monotonic counters in LDS --
+// halves published by the producer, halves taken by the consumer.  LDS serves one wave's instructions in order, so "data writes,
+// then counter write" / "data reads, then counter write" need no further fence; the waiting side polls with s_sleep.  A producer
+// runs up to 1.5 samples ahead of its consumer.  Arithmetic and its order are those of k_final_stage: bit-identical outputs.
+constexpr int RS_PROD = 8, RS_CONS = 4, RS_THREADS = (RS_PROD + RS_CONS) * 64;
+constexpr int RS_HALF = 64 * 16;                      // floats per half-sample image
+constexpr int RS_RING = 3;
+constexpr int RS_EXTRA = 2 * 128;                     // (delta[64], t_mid[64]) of two samples
+constexpr int RS_VIEW_W = 32 * 32 + 32 * 32 + 3 * 32; // padded view_mlp rows (31 -> 32)
+constexpr int RS_PER_PROD = RS_RING * RS_HALF + RS_EXTRA;
+constexpr int RS_OFF_VIEW = PACK_FLOATS;
+constexpr int RS_OFF_PROD = RS_OFF_VIEW + RS_VIEW_W;
+constexpr int RS_OFF_CNT = RS_OFF_PROD + RS_PROD * RS_PER_PROD;
+constexpr int RS_LDS_FLOATS = RS_OFF_CNT + 2 * RS_PROD;
+
+// gather spans of a producer: an even number, a boundary at level 8 (the half-sample images), span 0 dense
+#ifndef SN_RS_SPANS
+#define SN_RS_SPANS 8
+#endif
+#if SN_RS_SPANS == 6
+template <typename T> struct RsSpans { static constexpr int N = 6; static constexpr int B[7] = {0, 2, 5, 8, 11, 14, 16}; static constexpr int MG = 3; };
+#elif SN_RS_SPANS == 8
+template <typename T> struct RsSpans { static constexpr int N = 8; static constexpr int B[9] = {0, 2, 4, 6, 8, 10, 12, 14, 16}; static constexpr int MG = 2; };
+#else
+template <typename T> struct RsSpans { static constexpr int N = 4; static constexpr int B[5] = {0, 4, 8, 12, 16}; static constexpr int MG = 4; };
+#endif
+
+typedef __attribute__((address_space(3))) uint32_t rs_lds_u32;     // counters are LDS words: ds_read / ds_write, never flat accesses
+__device__ __forceinline__ uint32_t rs_lds_load(const uint32_t *p) {
+    return __builtin_amdgcn_readfirstlane(*(const volatile rs_lds_u32 *)p);
+}
+// wait until the counter at p (monotonic, written by ONE other wave of the workgroup) has reached `target`
+__device__ __forceinline__ void rs_wait_ge(const uint32_t *p, uint32_t target) {
+    while ((int32_t)(rs_lds_load(p) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void rs_publish(uint32_t *p, uint32_t v) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63u) == 0u) *(volatile rs_lds_u32 *)p = v;
+    asm volatile("" ::: "memory");
+}
+
+// workgroup tile -> ray of a producer lane.  Tile mode: workgroup = 32x16 pixels, producer wave pw = 8x8 pixels at
+// ((pw & 3) * 8, (pw >> 2) * 8).  `col` = the ray's column in the proposal stages' [T][Npad] scratch (their 16x16 tiling).
+__device__ __forceinline__ bool rs_ray_of_lane(const RayCommon &rc, uint32_t wg, uint32_t pw, uint32_t lane, uint32_t &n, uint32_t &col) {
+    if (rc.W) {
+        const uint32_t tiles_x = (rc.W + 31u) >> 5;
+        const uint32_t by = wg / tiles_x, bx = wg - by * tiles_x;
+        const uint32_t py = by * 16u + (pw >> 2) * 8u + (lane >> 3);
+        const uint32_t px = bx * 32u + (pw & 3u) * 8u + (lane & 7u);
+        const bool ok = px < rc.W && py < rc.rows;
+        n = ok ? py * rc.W + px : 0u;
+        const uint32_t tiles_x16 = (rc.W + 15u) >> 4;
+        col = ok ? ((py >> 4) * tiles_x16 + (px >> 4)) * 256u + (((py >> 3) & 1u) * 2u + ((px >> 3) & 1u)) * 64u + (py & 7u) * 8u + (px & 7u) : 0u;
+        return ok;
+    }
+    n = wg * (uint32_t)(RS_PROD * 64) + pw * 64u + lane;
+    const bool ok = n < rc.N;
+    if (!ok) n = 0;
+    col = n;
+    return ok;
+}
+
+// the 32-64-64-16 MLP of one wave-sample with the first layer's B operands already in registers ([tile][k-step]);
+// otherwise grid_mlp_mfma16 (same products, same order)
+__device__ __forceinline__ void grid_mlp_mfma16_regs(const uint4 *__restrict__ pk, const uint4 (&b1h)[2][2], const uint4 (&b1l)[2][2], float (&out)[16]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    float res[2][8];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        floatx16 h1[2], h2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int vec = mt * 2 + st;
+                acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], b1h[tile][st], b1l[tile][st], acc);
+            }
+            h1[mt] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 bh, bl;
+                acc_to_b(h1[q >> 1], q & 1, bh, bl);
+                const int vec = 4 + mt * 4 + q;
+                acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+            }
+            h2[mt] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 bh, bl;
+            acc_to_b(h2[q >> 1], q & 1, bh, bl);
+            const int vec = 12 + q;
+            acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) res[tile][r] = acc[r];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(res[0][r]), __float_as_uint(res[1][r]), false, false);
+        const int base = (r & 3) + 8 * (r >> 2);
+        out[base] = __uint_as_float(rr[0]);
+        out[base + 4] = __uint_as_float(rr[1]);
+    }
+}
+
+template <typename T, int L0, int G, int K, bool FAST, int MG>
+__device__ __forceinline__ void issue_span_into(const FinalLv &lv, const float (&x01)[3], GroupRegs<T, 2, MG> &r) {
+    static_for<0, G>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int l = L0 + k;
+        constexpr bool DENSE = l < K;
+        issue_level_lv<T, DENSE, FAST, xswap_level<T, DENSE ? 0 : 1, l>(), l>(lv, x01, r.pos[k], r.cv[k]);
+    });
+}
+template <typename T, int L0, int G, int K, int MG, typename Emit>
+__device__ __forceinline__ void blend_span_from(const GroupRegs<T, 2, MG> &r, Emit emit) {
+    static_for<0, G>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int l = L0 + k;
+        constexpr int KIND = l < K ? 0 : 1;
+        float acc[2];
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        emit(std::integral_constant<int, l>{}, acc);
+    });
+}
+
+#ifndef SN_RS_ABLATE
+#define SN_RS_ABLATE 0       // timing experiments (wrong results): 1 = consumers skip the MLP, 2 = producers skip gathers and blends
+#endif
+#ifndef SN_RS_BOUNDS
+#define SN_RS_BOUNDS RS_THREADS
+#endif
+#ifndef SN_RS_ONLY
+#define SN_RS_ONLY 0         // register diagnostics: 1 = producer code only, 2 = consumer code only
+#endif
+template <typename TT, int K>
+__global__ __launch_bounds__(SN_RS_BOUNDS, 1) void k_final_stage_rs(FinalArgs a) {
+    constexpr int GEO = 15, NSH = 16, NCOL = GEO + NSH, VH = 32;
+    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;
+    static_assert(VW0 + VW1 + 3 * PadIn<VH>::value == RS_VIEW_W, "view weight image");
+    using SP = RsSpans<TT>;
+    static_assert(SP::N % 2 == 0 && SP::B[SP::N] == 16 && SP::B[1] <= K, "spans: even count, 16 levels, span 0 dense");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += (uint32_t)RS_THREADS)
+        reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
+    float *lds_vw = lds + RS_OFF_VIEW;
+    stage_weights<NCOL, VH>(lds_vw, a.vw[0]);
+    stage_weights<VH, VH>(lds_vw + VW0, a.vw[1]);
+    stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds + RS_OFF_CNT);      // [0..7] halves published, [8..15] halves taken
+    if (threadIdx.x < 2u * RS_PROD) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    clock_probe(0);
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t wg = tile_id(a.rc);
+    const uint32_t T = a.T, Npad = a.rc.Npad;
+
+    if (SN_RS_ONLY != 2 && wave < (uint32_t)RS_PROD) {
+        // =============================== producer ===============================
+        const uint32_t pw = wave;
+        float *ring = lds + RS_OFF_PROD + pw * RS_PER_PROD;
+        float *extra = ring + RS_RING * RS_HALF;
+        uint32_t *published = cnt + pw;
+        const uint32_t *taken = cnt + RS_PROD + pw;
+        uint32_t n, col;
+        rs_ray_of_lane(a.rc, wg, pw, lane, n, col);
+        RaySetup rs;
+        setup_ray(a.rc, n, rs);
+        const float b0step = 1.0f / (float)T;
+        auto bin_at = [&](uint32_t j) -> float {
+            if (a.bins_in) return a.bins_in[(size_t)j * Npad + col];
+            if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
+            return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+        };
+        // this lane's row in a half image: 16 floats, 16-byte blocks swizzled by (row >> 2) & 3
+        const uint32_t row_off = lane * 16u, sw = (lane >> 2) & 3u;
+
+        float rb_prev = real_bin(rs, bin_at(0));
+        float rb_next_n = real_bin(rs, bin_at(1));
+        float tmid_n = (rb_next_n + rb_prev) / 2.0f;
+        float p_n[3], x01_n[3];
+        sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+        bool fast_n = all_interior(a.lv, x01_n);
+        GroupRegs<TT, 2, SP::MG> buf[2];
+        issue_span_into<TT, 0, SP::B[1], K, false>(a.lv, x01_n, buf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t slot = 0;                                  // ring slot of the half being written (= half number mod 3)
+        for (uint32_t j = 0; j < T; ++j) {
+            const float rb_next = rb_next_n, tmid = tmid_n;
+            const float delta = rb_next - rb_prev;
+            const float x01[3] = {x01_n[0], x01_n[1], x01_n[2]};
+            auto sample = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                bool oob = false;
+                if constexpr (!FAST) oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+                static_for<0, SP::N>([&](auto ss) {
+                    constexpr int s = decltype(ss)::value, L0 = SP::B[s], G = SP::B[s + 1] - L0;
+                    if constexpr (s + 1 < SP::N) {
+                        issue_span_into<TT, SP::B[s + 1], SP::B[s + 2] - SP::B[s + 1], K, FAST>(a.lv, x01, buf[(s + 1) & 1]);
+                    } else {   // geometry of sample j+1 (the last iteration re-issues its own sample: in bounds, unused) and its span 0
+                        const uint32_t jn = j + 2u <= T ? j + 2u : T;
+                        rb_next_n = real_bin(rs, bin_at(jn));
+                        const float rbp = j + 2u <= T ? rb_next : rb_prev;
+                        tmid_n = (rb_next_n + rbp) / 2.0f;
+                        sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+                        fast_n = all_interior(a.lv, x01_n);
+                        issue_span_into<TT, 0, SP::B[1], K, false>(a.lv, x01_n, buf[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (L0 == 0 || L0 == 8) {
+                        // half number h = 2j + (L0 == 8) overwrites half h - 3: taken once the consumer's count reached h - 2
+                        rs_wait_ge(taken, 2u * j + (L0 == 8 ? 1u : 0u) - 2u);
+                        if constexpr (L0 == 0) { extra[(j & 1u) * 128u + lane] = delta; extra[(j & 1u) * 128u + 64u + lane] = tmid; }
+                    }
+                    float *half = ring + slot * RS_HALF + row_off;
+                    blend_span_from<TT, L0, G, K>(buf[s & 1], [&](auto ll, const float (&acc)[2]) {
+                        constexpr int l8 = decltype(ll)::value & 7;
+                        float2 v = make_float2(acc[0], acc[1]);
+                        if constexpr (!FAST) { if (oob) v = make_float2(0.0f, 0.0f); }      // gridencoder.cu:105-130: zeros outside [0,1]
+                        *reinterpret_cast<float2 *>(half + (((uint32_t)(l8 >> 1) ^ sw) * 4u) + 2u * (l8 & 1)) = v;
+                    });
+                    if constexpr (SP::B[s + 1] == 8 || SP::B[s + 1] == 16) {
+                        rs_publish(published, 2u * j + (SP::B[s + 1] == 16 ? 2u : 1u));
+                        slot = slot == (uint32_t)(RS_RING - 1) ? 0u : slot + 1u;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+#if SN_RS_ABLATE & 2
+            {   // timing experiment: no gathers, no blends -- geometry, hand-over and the consumer side only
+                for (int hf = 0; hf < 2; ++hf) {
+                    rs_wait_ge(taken, 2u * j + (uint32_t)hf - 2u);
+                    if (hf == 0) { extra[(j & 1u) * 128u + lane] = delta; extra[(j & 1u) * 128u + 64u + lane] = tmid; }
+                    float *half = ring + slot * RS_HALF + row_off;
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(half + 4 * q) = make_float4(x01[0], x01[1], x01[2], tmid);
+                    rs_publish(published, 2u * j + (uint32_t)hf + 1u);
+                    slot = slot == (uint32_t)(RS_RING - 1) ? 0u : slot + 1u;
+                }
+                const uint32_t jn = j + 2u <= T ? j + 2u : T;
+                rb_next_n = real_bin(rs, bin_at(jn));
+                const float rbp = j + 2u <= T ? rb_next : rb_prev;
+                tmid_n = (rb_next_n + rbp) / 2.0f;
+                sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
+            }
+#else
+            if (__builtin_expect(fast_n, 1)) sample(std::true_type{});      // fast_n here: decided for THIS sample one iteration ago
+            else sample(std::false_type{});
+#endif
+            rb_prev = rb_next;
+        }
+        clock_probe(1);                 // (thread 0 is a producer: its exit, a little before the consumers' colour head)
+        return;
+    }
+
+    // =============================== consumer ===============================
+    if (SN_RS_ONLY == 1) return;
+    const uint32_t cw = wave - (uint32_t)RS_PROD;
+    const uint32_t lo = lane & 31u, hi = lane >> 5;
+    float fimg[2][GEO];
+    float dep[2] = {0.0f, 0.0f};
+    double cum[2] = {0.0, 0.0}, wsum[2] = {0.0, 0.0};
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int c = 0; c < GEO; ++c) fimg[pp][c] = 0.0f;
+    uint32_t slot = 0;
+    for (uint32_t j = 0; j < T; ++j) {
+        const uint32_t slot1 = slot == (uint32_t)(RS_RING - 1) ? 0u : slot + 1u;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const uint32_t pw = cw + 4u * (uint32_t)pp;
+            const float *ring = lds + RS_OFF_PROD + pw * RS_PER_PROD;
+            const float *extra = ring + RS_RING * RS_HALF;
+            rs_wait_ge(cnt + pw, 2u * j + 2u);
+            uint4 b1h[2][2], b1l[2][2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float *half = ring + (st ? slot1 : slot) * RS_HALF;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t row = (uint32_t)t * 32u + lo, sw = (row >> 2) & 3u;
+                    const float4 u = *reinterpret_cast<const float4 *>(half + row * 16u + (((2u * hi) ^ sw) * 4u));
+                    const float4 v = *reinterpret_cast<const float4 *>(half + row * 16u + (((2u * hi + 1u) ^ sw) * 4u));
+                    split2(u.x, u.y, b1h[t][st].x, b1l[t][st].x); split2(u.z, u.w, b1h[t][st].y, b1l[t][st].y);
+                    split2(v.x, v.y, b1h[t][st].z, b1l[t][st].z); split2(v.z, v.w, b1h[t][st].w, b1l[t][st].w);
+                }
+            }
+            const float delta = extra[(j & 1u) * 128u + lane], tmid = extra[(j & 1u) * 128u + 64u + lane];
+            rs_publish(cnt + RS_PROD + pw, 2u * j + 2u);
+            float h[16];
+#if SN_RS_ABLATE & 1
+            for (int k = 0; k < 16; ++k) h[k] = __uint_as_float((b1h[k & 1][(k >> 1) & 1].x ^ b1l[k & 1][(k >> 1) & 1].y) & 0x3fffffffu);
+#else
+            grid_mlp_mfma16_regs(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), b1h, b1l, h);
+#endif
+            // network.py:151, renderer.py:308-325 -- the statements of k_final_stage, in its order
+            const float sigma = expf_det(h[0]);
+            float ds = delta * sigma;
+            if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+            const float alpha = 1.0f - expf_det(-ds);
+            const float tr = expf_det(-(float)cum[pp]);
+            float w = alpha * tr;
+            if (w != w) w = 0.0f;
+            cum[pp] += (double)ds;
+            wsum[pp] += (double)w;
+            dep[pp] = __builtin_fmaf(w, tmid, dep[pp]);
+#pragma unroll
+            for (int c = 0; c < GEO; ++c) fimg[pp][c] = __builtin_fmaf(w, h[1 + c], fimg[pp][c]);
+        }
+        slot = slot1 == (uint32_t)(RS_RING - 1) ? 0u : slot1 + 1u;
+    }
+    // ---- per-ray colour head of both producers' rays (renderer.py:340-357); the producers are done with their rings ----
+#pragma unroll 1
+    for (int pp = 0; pp < 2; ++pp) {
+        const uint32_t pw = cw + 4u * (uint32_t)pp;
+        float *fe = lds + RS_OFF_PROD + pw * RS_PER_PROD + lane;
+        constexpr uint32_t fstride = 64u;
+        uint32_t n, col;
+        const bool ok = rs_ray_of_lane(a.rc, wg, pw, lane, n, col);
+        float dirn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dirn[k] = a.rc.rays_d[(size_t)n * 3 + k];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {      // normalised twice like the reference (renderer.py:294, sphere_harmonics.py:82)
+            const float aa = dirn[0] * dirn[0], bb = dirn[1] * dirn[1], cc = dirn[2] * dirn[2];
+            const float nrm = sqrtf((aa + bb) + cc);
+            dirn[0] = dirn[0] / nrm; dirn[1] = dirn[1] / nrm; dirn[2] = dirn[2] / nrm;
+        }
+        const float ws = (float)(pp ? wsum[1] : wsum[0]);
+        float col31[NCOL];
+#pragma unroll
+        for (int c = 0; c < GEO; ++c) col31[c] = pp ? fimg[1][c] : fimg[0][c];
+        {
+            float sh[NSH];
+            sh_degree4(dirn[0], dirn[1], dirn[2], sh);
+#pragma unroll
+            for (int c = 0; c < NSH; ++c) col31[GEO + c] = sh[c] * ws;
+        }
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) fe[c * fstride] = col31[c];
+        dense_ldsw_col<NCOL, VH, 1>(lds_vw, fe, fe, fstride);
+        dense_ldsw_col<VH, VH, 1>(lds_vw + VW0, fe, fe, fstride);
+        float rgb[3];
+        {
+            float v2[VH];
+#pragma unroll
+            for (int k = 0; k < VH; ++k) v2[k] = fe[k * fstride];
+            dense_ldsw<VH, 3, 0>(lds_vw + VW0 + VW1, v2, rgb);
+        }
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float sg = 1.0f / (1.0f + expf_det(-rgb[c]));
+                const float bgm = (1.0f - ws) * a.rc.bg;
+                a.image[(size_t)n * 3 + c] = sg + bgm;
+            }
+            a.depth[n] = pp ? dep[1] : dep[0];
+            a.wsum[n] = ws;
+            if (a.dbg_fimg) {
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = col31[c];
+            }
         }
     }
 }
@@ -2192,6 +2729,12 @@ static uint32_t final_sp_max_rays() {
     return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u;
 }
 
+// SN_RENDER_RS=1: the role-split final stage (k_final_stage_rs) where it applies
+static bool rs_enabled() {
+    const char *e = getenv("SN_RENDER_RS");
+    return e && e[0] == '1';
+}
+
 static uint32_t blocks_for(uint32_t n, uint32_t W) {
     if (W) { const uint32_t rows = (n + W - 1) / W; return ((W + 15u) >> 4) * ((rows + 15u) >> 4); }
     return div_up(n, 256);
@@ -2577,6 +3120,17 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             } else {
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_cmp<float, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL((k_final_stage_cmp<float, 5>), dim3(nblk), dim3(256), lds_bytes, st, fa);
+            }
+        } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !aux && !per_sample_out && rs_enabled()) {
+            // role-split waves (k_final_stage_rs): 768-thread workgroups over 32x16-pixel tiles (512 rays in linear order)
+            const uint32_t nblk_rs = W ? ((W + 31u) >> 5) * ((rc.rows + 15u) >> 4) : div_up(n, (uint32_t)(RS_PROD * 64));
+            const size_t lds_bytes = (size_t)RS_LDS_FLOATS * sizeof(float);
+            if (f16) {
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_rs<__half, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL((k_final_stage_rs<__half, 5>), dim3(nblk_rs), dim3(RS_THREADS), lds_bytes, st, fa);
+            } else {
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_rs<float, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL((k_final_stage_rs<float, 5>), dim3(nblk_rs), dim3(RS_THREADS), lds_bytes, st, fa);
             }
         } else if (mlp_mode == MLP_F16X3) {
             if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense

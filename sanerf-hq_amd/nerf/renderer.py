@@ -172,7 +172,7 @@ class NeRFRenderer(nn.Module):
                                        compact_live=bool(getattr(self.opt, "compact_live", False)))
             self._plan_key = key
         elif not getattr(self, "render_tables_static", False):
-            self._plan.refresh_tables()        # also re-checks the fp16 range guard when parameters changed
+            self._plan.refresh_tables()        # (the fp16 range guard is re-checked by render_rays before a final-stage launch)
         ab = rm._host_values(self.aabb_train if self.training else self.aabb_infer)
         for i in range(6):
             self._plan.cfg.aabb[i] = ab[i]

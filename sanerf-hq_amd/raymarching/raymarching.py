@@ -500,22 +500,29 @@ class RenderPlan:
         table values, so |feature| <= max|table|; a ReLU layer's outputs are bounded by the largest row L1 norm of its
         weight times the bound of its inputs.  If features, hidden activations or weights could reach the fp16 range the
         plan switches the kernel to the exact fp32 matrix-core path (cfg.mlp_exact_fp32, ~2.2x slower final stage) instead
-        of risking inf / NaN.  Re-evaluated when a parameter's version counter moved (one small reduction + sync)."""
+        of risking inf / NaN.  Re-evaluated when a parameter's version counter moved (device reductions + ONE sync); called by
+        render_rays right before a launch that runs the final stage -- never for skip_final calls, whose proposal stages use
+        fp32 vector arithmetic only (a training step that takes its sample positions from the fused proposal stages stays free
+        of host synchronisation).  sanerf_hq_amd.optim.Adam bumps the version counters of the tensors it updates."""
         m = self._range_model
         tensors = [m.grid.embeddings] + [lin.weight for lin in m.grid_mlp.net]
         versions = tuple((t.data_ptr(), t._version) for t in tensors)
         if versions == self._range_versions:
             return
         self._range_versions = versions
-        bound = float(m.grid.embeddings.detach().abs().max())
-        worst = bound
-        wmax = 0.0
-        for lin in list(m.grid_mlp.net)[:-1]:                          # the last layer's outputs stay fp32 accumulators
-            w = lin.weight.detach().float()
-            bound = float(w.abs().sum(dim=1).max()) * bound
+        layers = list(m.grid_mlp.net)
+        # every reduction stays on the device; ONE host transfer (= one sync) fetches them all
+        stats = [m.grid.embeddings.detach().abs().max().float()]
+        stats += [lin.weight.detach().float().abs().sum(dim=1).max() for lin in layers[:-1]]   # the last layer's outputs stay fp32 accumulators
+        stats += [lin.weight.detach().abs().max().float() for lin in layers]
+        vals = torch.stack(stats).tolist()
+        bound = worst = vals[0]
+        for row_l1 in vals[1:len(layers)]:
+            bound = row_l1 * bound
             worst = max(worst, bound)
-        for lin in m.grid_mlp.net:
-            wmax = max(wmax, float(lin.weight.detach().abs().max()))
+        wmax = max(vals[len(layers):]) if layers else 0.0
+        if any(v != v for v in vals):
+            worst = float("nan")
         self.activation_bound = max(worst, wmax)
         exact = not (self.activation_bound < FP16_SPLIT_LIMIT)          # also catches NaN
         if exact and not self.cfg.mlp_exact_fp32:
@@ -526,10 +533,10 @@ class RenderPlan:
     @torch.no_grad()
     def refresh_tables(self) -> None:
         """Re-convert the table copies (render_table_dtype != the parameters' dtype) from the live parameters, in place:
-        the plan's device pointers stay valid.  A plan over fp32 tables holds no copies and this is a no-op."""
+        the plan's device pointers stay valid.  A plan over fp32 tables holds no copies and this is a no-op.  (The fp16 range
+        guard is evaluated by render_rays, see check_range.)"""
         for src, copy in self.copies:
             copy.copy_(src.detach())
-        self.check_range()
 
     def workspace(self, N: int, tile_w: int, device) -> torch.Tensor:
         need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(self.cfg), N, tile_w))
@@ -591,6 +598,7 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         want = set()
         io.bins[S - 1] = buf(f"bins{S - 1}", (N, plan.num_steps[S - 1] + 1)).data_ptr()
     else:
+        plan.check_range()           # fp16 range guard of the final stage's MLP: a no-op unless a parameter version moved
         io.image = _lib.dev(buf("image", (N, 3)), "image")
         io.depth = _lib.dev(buf("depth", (N,)), "depth")
         io.weights_sum = _lib.dev(buf("weights_sum", (N,)), "weights_sum")
