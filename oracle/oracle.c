@@ -146,6 +146,11 @@ static inline uint32_t grid_row(uint32_t gridtype, uint32_t hashmap_size, uint32
     return index % hashmap_size;
 }
 
+/* exposed for tools/check_reference_text.py: the row index alone, against a mechanical transliteration of the reference's text */
+uint32_t orc_grid_row(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution, const uint32_t *pos_grid, uint32_t D) {
+    return grid_row(gridtype, hashmap_size, resolution, pos_grid, D);
+}
+
 static inline float smoothstep_f(float v) { return v * v * (3.0f - 2.0f * v); }
 static inline float smoothstep_d(float v) { return 6 * v * (1.0f - v); }
 

@@ -28,6 +28,8 @@ float    orc_half_to_float(uint16_t h);
 uint16_t orc_float_to_half(float f);
 /* gridencoder.cu:133 — kernel-side level resolution, fp32 recipe */
 uint32_t orc_level_resolution(uint32_t level, float S, uint32_t H);
+/* gridencoder.cu:45-79 — table row of one grid vertex (dense walk while the stride fits, else the coherent hash; % size) */
+uint32_t orc_grid_row(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution, const uint32_t *pos_grid, uint32_t D);
 
 /* ---- gridencoder (gridencoder.cu) --------------------------------------
  * table_dtype: 0 = float32, 1 = float16 storage (arithmetic is fp32 either way)

@@ -135,7 +135,15 @@ def lib():
         _lib.orc_level_resolution.restype = C.c_uint32
         _lib.orc_level_resolution.argtypes = [C.c_uint32, C.c_float, C.c_uint32]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_grid_row.restype = C.c_uint32
+        _lib.orc_grid_row.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
     return _lib
+
+
+def grid_row(gridtype: int, hashmap_size: int, resolution: int, pos_grid) -> int:
+    """Table row of one grid vertex (gridencoder.cu:45-79)."""
+    pg = (C.c_uint32 * len(pos_grid))(*[int(v) & 0xFFFFFFFF for v in pos_grid])
+    return int(lib().orc_grid_row(int(gridtype), int(hashmap_size), int(resolution), pg, len(pos_grid)))
 
 
 def _f32(a) -> np.ndarray:

@@ -2852,6 +2852,12 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     SN_REQUIRE(cfg->sh_degree == 4, "render_rays: fused path is built for SH degree 4 (network.py:97), got %u", cfg->sh_degree);
     if (io->N == 0) return SN_OK;
     if (io->tile_w) SN_REQUIRE(io->N % io->tile_w == 0, "render_rays: N=%u is not a multiple of tile_w=%u", io->N, io->tile_w);
+    // per-ray tables: a row holds T+1 values (sanerf_hip.h); a shorter stride would read past the caller's rows
+    SN_REQUIRE(io->bins0_ray_stride == 0 || (io->bins0_table && io->bins0_ray_stride >= cfg->num_steps[0] + 1u),
+               "render_rays: bins0_ray_stride=%u needs bins0_table and at least num_steps[0]+1=%u values per ray", io->bins0_ray_stride, cfg->num_steps[0] + 1u);
+    for (uint32_t k = 1; k < S; ++k)
+        SN_REQUIRE(io->u_ray_stride[k] == 0 || (io->u_table[k] && io->u_ray_stride[k] >= cfg->num_steps[k] + 1u),
+                   "render_rays: u_ray_stride[%u]=%u needs u_table[%u] and at least num_steps[%u]+1=%u values per ray", k, io->u_ray_stride[k], k, k, cfg->num_steps[k] + 1u);
     hipStream_t st = (hipStream_t)stream;
 
     // ---- which kernel instantiations does this configuration map to? ----
@@ -2963,6 +2969,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     if (cfg->compact_live && mlp_mode == MLP_F16X3 && !cfg->with_feat && !io->xyzs_last && !io->geo_feat_last && !io->skip_final &&
         io->bins0_ray_stride == 0) {
         bool any_dbg = false;
+        for (uint32_t k = 1; k < S; ++k) any_dbg = any_dbg || io->u_ray_stride[k] != 0;      // per-ray jitter tables: the default kernels
         for (uint32_t k = 0; k < S; ++k) any_dbg = any_dbg || io->bins[k] || io->weights[k] || io->sigmas[k] || io->inds[k];
         FinalLv probe;
         use_cmp = !any_dbg && dense_prefix(gl_main) == 5 &&

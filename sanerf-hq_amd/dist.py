@@ -47,11 +47,12 @@ def all_shards(H: int, world_size: int, align: int = TILE_ROWS) -> List[Tuple[in
 
 
 def gather_image(local: torch.Tensor, H: int, W: int, group: Optional[dist.ProcessGroup] = None,
-                 align: int = TILE_ROWS) -> torch.Tensor:
+                 align: int = TILE_ROWS, force_collective: bool = False) -> torch.Tensor:
     """local: [(rows_of_this_rank)*W, K] -> [H*W, K] on every rank (one all_gather, equal counts:
-    bands are padded to the largest band)."""
+    bands are padded to the largest band).  force_collective: run the all-gather even in a one-rank group (the
+    single-GPU self-test of the RCCL path, tools/rccl_selftest.py)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local
     rank = dist.get_rank(group)
     bands = all_shards(H, world, align)
@@ -72,7 +73,7 @@ def gather_image(local: torch.Tensor, H: int, W: int, group: Optional[dist.Proce
 
 
 def render_image_sharded(render_rows: Callable[[int, int], torch.Tensor], H: int, W: int,
-                         group: Optional[dist.ProcessGroup] = None, gather: bool = True) -> torch.Tensor:
+                         group: Optional[dist.ProcessGroup] = None, gather: bool = True, force_collective: bool = False) -> torch.Tensor:
     """render_rows(row_begin, row_end) -> [(row_end-row_begin)*W, K] for this rank's band.
     Returns the full [H*W, K] image on every rank (or the local band if gather=False)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -82,11 +83,11 @@ def render_image_sharded(render_rows: Callable[[int, int], torch.Tensor], H: int
     local = render_rows(b, e) if e > b else None
     if local is None:
         raise RuntimeError(f"rank {rank} received an empty band: image height {H} has fewer than {world} row tiles")
-    return gather_image(local, H, W, group, align) if gather else local
+    return gather_image(local, H, W, group, align, force_collective) if gather else local
 
 
 def render_model_sharded(model, pose, intrinsics, H: int, W: int, group: Optional[dist.ProcessGroup] = None,
-                         gather: bool = True, ray_fn: Optional[Callable] = None) -> torch.Tensor:
+                         gather: bool = True, ray_fn: Optional[Callable] = None, force_collective: bool = False) -> torch.Tensor:
     """Whole-image render of a NeRFNetwork replica: [H*W, 5] = rgb | depth | weights_sum on every rank.
     Each rank generates the rays of its own band on its own device (nothing but the final image crosses xGMI).
     ray_fn(pose, intrinsics, H, W, device, row_begin, row_end) -> (rays_o, rays_d): defaults to the HIP
@@ -104,7 +105,7 @@ def render_model_sharded(model, pose, intrinsics, H: int, W: int, group: Optiona
         out = model.render(rays_o, rays_d, staged=False, perturb=False, tile_w=W)
         return torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
 
-    return render_image_sharded(rows, H, W, group, gather)
+    return render_image_sharded(rows, H, W, group, gather, force_collective)
 
 
 class PipelinedGather:

@@ -129,7 +129,8 @@ def collate_rays(poses, intrinsics, H, W, num_rays, index=None, images=None, mas
         li_exp = li[:, None].expand(-1, local_patch_size * local_patch_size).reshape(-1)
         parts = []
         for k in range(num_local_sample):    # one patch per drawn image (the reference's single call draws one centre for all)
-            parts.append(get_rays(poses[li[k:k + 1]].expand(local_patch_size * local_patch_size, 4, 4), cam_intr[:1], H, W, 1, device=dev,
+            intr_k = intr_all[li[k:k + 1]] if intr_all.shape[0] == M else intr_all[:1]      # the patch's own camera model
+            parts.append(get_rays(poses[li[k:k + 1]].expand(local_patch_size * local_patch_size, 4, 4), intr_k, H, W, 1, device=dev,
                                   patch_size=local_patch_size, incoherent_mask=None if error_map is None else error_map[li[k:k + 1]],
                                   include_incoherent_region=error_map is not None, incoherent_mask_size=error_map_size, random_sample=False))
         loc = {k_: torch.cat([p_[k_] for p_ in parts], 0) for k_ in ("rays_o", "rays_d", "i", "j")}

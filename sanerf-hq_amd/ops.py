@@ -488,12 +488,12 @@ class _wide_mlp_train(Function):
 
 def wide_mlp_fusable(x: torch.Tensor, layers, skip_layers) -> bool:
     """Training-time route of a SkipConnMLP / MLP through _wide_mlp_train: CUDA fp32, autograd on, many rows, no bias, no
-    skip layers, hidden width 256, at most 256 outputs."""
+    skip layers, hidden width 256, at most 256 inputs and at most 256 outputs (wider inputs take the torch layers)."""
     rows = x.numel() // max(x.shape[-1], 1)
     return (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and rows >= WIDE_MLP_BACKWARD_MIN_ROWS
             and not skip_layers and len(layers) >= 2 and all(l.bias is None and l.weight.dtype == torch.float32 for l in layers)
             and all(l.weight.shape[0] == 256 for l in layers[:-1]) and layers[-1].weight.shape[0] <= 256
-            and all(l.weight.shape[1] == 256 for l in layers[1:]) and layers[0].weight.shape[1] <= 1024
+            and all(l.weight.shape[1] == 256 for l in layers[1:]) and layers[0].weight.shape[1] <= 256   # the backward plans the transposed MLP: its last width is dim_in
             and any(l.weight.requires_grad for l in layers)
             and os.environ.get("SN_WIDE_MLP_BACKWARD", "fused") != "torch")
 

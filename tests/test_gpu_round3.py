@@ -1,0 +1,229 @@
+"""GPU tests added in round 3: full-size checks of both table precisions and both schedules, the role-split final stage,
+the cold torch-formulated routes of the training path, guards of the C ABI, the RCCL leg on one GPU."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import camera_rays, oracle_cfg, product_model, synthetic_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("steps,f16", [([128], False), ([128], True), ([128, 64, 32], True)])
+def test_full_size_both_table_precisions_and_schedules(gpu, orc, steps, f16):
+    """800x800 (BASELINE configs[1]: 128 samples per ray, fp16 tables) at full size: determinism, partition of unity, linear
+    lane mapping == tiled, and 512 pseudo-random pixels against the oracle on the same (fp16-rounded) tables, RGB <= 1e-5."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    params = synthetic_params(steps, seed=19)
+    model = product_model(params, steps, False, gpu)
+    H = W = 800
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    plan = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32)
+    a = rm.render_rays(plan, ro, rd, tile_w=W)
+    img = a["image"].clone(); dep = a["depth"].clone(); ws = a["weights_sum"].clone()
+    assert torch.isfinite(img).all() and torch.isfinite(dep).all()
+    np.testing.assert_allclose(ws.cpu().numpy(), 1.0, atol=3e-6)
+    b = rm.render_rays(plan, ro, rd, tile_w=W)
+    assert torch.equal(b["image"], img) and torch.equal(b["depth"], dep)
+    c = rm.render_rays(plan, ro, rd, tile_w=0, out={})
+    assert torch.equal(c["image"], img)
+    idx = (synth.hash_u01(512, 11) * (H * W)).astype(np.int64)
+    want = orc.render(oracle_cfg(orc, params, steps, table_f16=f16), ro[idx].cpu().numpy(), rd[idx].cpu().numpy())
+    np.testing.assert_allclose(img[idx].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(dep[idx].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("steps", [[128], [128, 64, 32], [7], [33, 17, 9]])
+def test_role_split_final_stage_is_bit_identical(gpu, orc, steps, monkeypatch):
+    """k_final_stage_rs (SN_RENDER_RS=1: producer waves gather and blend, consumer waves run the matrix-core MLP and composite,
+    hand-over through LDS rings) performs the arithmetic of k_final_stage in its order: every output must be equal bit for bit,
+    for ragged image shapes, tiled and linear lane mapping and both table precisions."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    params = synthetic_params(steps, seed=23)
+    model = product_model(params, steps, False, gpu)
+    pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    for tdt in (torch.float32, torch.float16):
+        plan = rm.RenderPlan(model, steps, tdt)
+        for (H, W) in ((64, 64), (48, 80), (200, 104), (16, 32), (40, 24)):
+            intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
+            ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
+            for tile in (W, 0):
+                monkeypatch.setenv("SN_RENDER_RS", "0")
+                a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",)).items()}
+                monkeypatch.setenv("SN_RENDER_RS", "1")
+                b = rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",))
+                for k in ("image", "depth", "weights_sum", "f_image"):
+                    assert torch.equal(a[k], b[k]), (steps, tdt, H, W, tile, k, float((a[k] - b[k]).abs().max()))
+    # against the oracle directly as well (one shape)
+    monkeypatch.setenv("SN_RENDER_RS", "1")
+    _, _, ro, rd = camera_rays(orc, 32, 32)
+    plan = rm.RenderPlan(model, steps)
+    got = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32)
+    want = orc.render(oracle_cfg(orc, params, steps), ro, rd)
+    np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+
+
+def test_range_guard_follows_the_packages_own_adam_and_skips_proposal_only_calls(gpu, orc):
+    """sn_adam_step writes parameters through raw pointers; the optimiser now bumps their version counters, so
+    the fp16 range guard of a cached plan sees weights that grew past the split-fp16 bound.  And a skip_final call (proposal
+    stages only: fp32 vector arithmetic) must not evaluate the guard at all (no host synchronisation in such a step)."""
+    import warnings
+    from sanerf_hq_amd import optim, raymarching as rm
+    steps = [32, 16]
+    model = product_model(synthetic_params(steps, seed=21), steps, False, gpu)
+    _, _, ro, rd = camera_rays(orc, 16, 16)
+    ro, rd = T(ro, gpu), T(rd, gpu)
+    with torch.no_grad():
+        model.render(ro, rd)
+    assert model._plan.cfg.mlp_exact_fp32 == 0
+    w = model.grid_mlp.net[0].weight
+    w.requires_grad_(True)
+    opt = optim.Adam([w], lr=3.0e4, eps=1e-15)                     # one step moves every weight by ~lr
+    v0 = w._version
+    w.grad = torch.ones_like(w)
+    opt.step()
+    assert w._version > v0, "sn_adam_step must bump the version counter of the tensor it rewrote"
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = model.render(ro, rd)
+    assert model._plan.cfg.mlp_exact_fp32 == 1 and torch.isfinite(out["image"]).all()
+    # proposal-only call: the guard is not consulted
+    plan = model._plan
+    called = []
+    orig = plan.check_range
+    plan.check_range = lambda: called.append(1) or orig()
+    rm.render_rays(plan, ro, rd, skip_final=True)
+    assert not called
+    rm.render_rays(plan, ro, rd)
+    assert called
+
+
+def test_wide_mlp_training_route_needs_at_most_256_inputs(gpu):
+    """the fused backward plans the transposed MLP, whose last width is the forward's dim_in (<= 256); a bias-free
+    skip-free SkipConnMLP with 300 inputs must take the torch layers (and train) instead of failing in backward."""
+    from sanerf_hq_amd import ops
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(0)
+    for dim_in, fusable in ((143, True), (256, True), (300, False)):
+        mlp = SkipConnMLP(dim_in, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+        x = torch.randn(ops.WIDE_MLP_BACKWARD_MIN_ROWS, dim_in, device=gpu)
+        assert ops.wide_mlp_fusable(x, list(mlp.net), []) == fusable, dim_in
+        y = mlp(x)
+        y.square().mean().backward()
+        g = mlp.net[0].weight.grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+def test_render_rays_validates_per_ray_table_strides(gpu, orc):
+    """a direct C caller passing a per-ray stride shorter than T+1 must get SN_ERR_INVALID, not out-of-bounds reads."""
+    from sanerf_hq_amd import _lib, raymarching as rm
+    steps = [32, 16]
+    model = product_model(synthetic_params(steps, seed=5), steps, False, gpu)
+    plan = rm.RenderPlan(model, steps)
+    N = 64
+    ro = torch.zeros(N, 3, device=gpu); rd = torch.ones(N, 3, device=gpu)
+    img = torch.empty(N, 3, device=gpu); dep = torch.empty(N, device=gpu); ws = torch.empty(N, device=gpu)
+    work = plan.workspace(N, 0, gpu)
+    tab = torch.zeros(N, 40, device=gpu)
+
+    def call(**fields):
+        io = _lib.RenderIO()
+        io.rays_o, io.rays_d, io.N = ro.data_ptr(), rd.data_ptr(), N
+        io.image, io.depth, io.weights_sum = img.data_ptr(), dep.data_ptr(), ws.data_ptr()
+        io.workspace, io.workspace_bytes = work.data_ptr(), work.numel()
+        for k, v in fields.items():
+            if k == "u1":
+                io.u_table[1] = v
+            elif k == "u1_stride":
+                io.u_ray_stride[1] = v
+            else:
+                setattr(io, k, v)
+        return _lib.lib().sn_rm_render_rays(C.byref(plan.cfg), C.byref(io), _lib.stream())
+
+    assert call() == 0
+    assert call(bins0_table=tab.data_ptr(), bins0_ray_stride=40) == 0
+    for bad in (dict(bins0_table=tab.data_ptr(), bins0_ray_stride=32), dict(bins0_ray_stride=40),
+                dict(u1=tab.data_ptr(), u1_stride=16), dict(u1_stride=40)):
+        rc = call(**bad)
+        assert rc != 0 and b"stride" in _lib.lib().sn_last_error(), (bad, rc)
+    torch.cuda.synchronize()
+
+
+def test_torch_formulated_routes_of_the_training_path(gpu, monkeypatch):
+    """Shapes beyond a kernel's limit take the reference's own torch formulation on the GPU (longer rays than the kernels hold
+    in registers: T > 256 for the weights backward, > 512 / 2048 for the loss kernels; head MLPs that are not 256 wide).  Each
+    such route is pinned here against the kernel route on shapes both can run, values and gradients."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.raymarching import raymarching as rmm
+    from sanerf_hq_amd.nerf import renderer as R
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(1)
+    N, Tn = 257, 48
+    bins = torch.sort(torch.rand(N, Tn + 1, device=gpu), dim=-1).values
+    sig = (torch.rand(N, Tn, device=gpu) * 8).requires_grad_(True)
+
+    def grads(fn):
+        sig.grad = None
+        out = fn()
+        (out * torch.linspace(0.5, 1.5, out.numel(), device=gpu).reshape(out.shape)).sum().backward()
+        return out.detach().clone(), sig.grad.clone()
+
+    w_k, g_k = grads(lambda: rm.weights_from_sigma(bins, sig, True))
+    monkeypatch.setattr(rmm, "WEIGHTS_BACKWARD_MAX_T", 8)
+    w_t, g_t = grads(lambda: rm.weights_from_sigma(bins, sig, True))
+    monkeypatch.undo()
+    np.testing.assert_allclose(w_t.cpu().numpy(), w_k.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(g_t.cpu().numpy(), g_k.cpu().numpy(), rtol=2e-4, atol=2e-6)
+    with torch.no_grad():                                             # a 300-sample ray through the torch chain == the forward kernel
+        b3 = torch.sort(torch.rand(33, 301, device=gpu), dim=-1).values
+        s3 = torch.rand(33, 300, device=gpu) * 5
+    s3g = s3.clone().requires_grad_(True)
+    np.testing.assert_allclose(rm.weights_from_sigma(b3, s3g, True).detach().cpu().numpy(), rm.weights_from_sigma(b3, s3, True).cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+    # losses: kernel vs torch route
+    wts = torch.softmax(torch.randn(N, Tn, device=gpu), dim=-1).requires_grad_(True)
+    ref_b = torch.sort(torch.rand(N, 25, device=gpu), dim=-1).values
+    ref_w = torch.softmax(torch.randn(N, 24, device=gpu), dim=-1)
+
+    def loss_and_grad(fn):
+        wts.grad = None
+        v = fn()
+        v.backward()
+        return float(v), wts.grad.clone()
+
+    lk, gk = loss_and_grad(lambda: R.proposal_loss([bins, ref_b], [wts, ref_w]))
+    monkeypatch.setattr(rm, "PROPOSAL_LOSS_MAX_T", 0)
+    lt, gt = loss_and_grad(lambda: R.proposal_loss([bins, ref_b], [wts, ref_w]))
+    monkeypatch.undo()
+    assert abs(lk - lt) <= 1e-5 * max(1.0, abs(lt))
+    np.testing.assert_allclose(gk.cpu().numpy(), gt.cpu().numpy(), rtol=1e-3, atol=1e-7)
+    dk, gdk = loss_and_grad(lambda: R.distort_loss(bins, wts))
+    monkeypatch.setattr(rm, "DISTORT_LOSS_MAX_T", 0)
+    dt, gdt = loss_and_grad(lambda: R.distort_loss(bins, wts))
+    monkeypatch.undo()
+    assert abs(dk - dt) <= 1e-5 * max(1.0, abs(dt))
+    np.testing.assert_allclose(gdk.cpu().numpy(), gdt.cpu().numpy(), rtol=1e-3, atol=1e-7)
+
+    # a head MLP that the matrix-core kernel does not instantiate (hidden width 128) runs as the torch module, same numbers
+    mlp = torch.nn.Sequential(SkipConnMLP(40, 3, 128, 3, skip_layers=[], bias=True)).to(gpu)
+    x = torch.randn(1000, 40, device=gpu)
+    with torch.no_grad():
+        assert torch.equal(R.NeRFRenderer._head_mlp(mlp, x), mlp(x))
+
+
+def test_rccl_leg_on_one_gpu():
+    """One-rank "nccl" (= RCCL) process group in a fresh process: init, all_reduce, the band render with the all-gather forced,
+    PipelinedGather over 5 frames -- all equal to the plain render (tools/rccl_selftest.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selftest.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl selftest OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

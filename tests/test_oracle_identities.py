@@ -292,3 +292,17 @@ def test_sh_gradient_include_is_what_the_generator_emits(tmp_path, monkeypatch):
     monkeypatch.undo()
     assert len(table) == 192
     assert (tmp_path / "sh_grad.inc").read_text() == committed
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference's source text (build container only)")
+def test_oracle_matches_the_reference_source_text():
+    """tools/check_reference_text.py: the reference's CUDA cannot run here, so its TEXT is the pin -- the hash / dense index
+    functions of gridencoder.cu:45-79 are transliterated mechanically and executed against the oracle's grid_row, and the 64
+    forward SH polynomials of shencoder.cu:50-120 are compared coefficient by coefficient with the oracle's and the device's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_reference_text", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_reference_text.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check_grid_index(trials=20000) == 20000
+    worst = mod.check_sh_forward()
+    assert worst["oracle"] < 1e-12 and worst["device"] < 2e-7

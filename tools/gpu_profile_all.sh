@@ -22,14 +22,16 @@ stats train_mask python $root/tools/train_profile.py mask
 stats mask_head python $root/tools/mask_profile.py mask
 stats compact_live python $root/tools/mask_profile.py compact
 rm -f $out/*_under_rocprof.log
-# PMC passes (primary configuration of each schedule, fp32 tables)
-for sch in flat128 ref; do
-  rm -f $out/pmc_$sch.txt
+# PMC passes (both schedules with fp32 tables, the headline schedule with fp16 tables as well)
+for cfg in "flat128 f32" "ref f32" "flat128 f16"; do
+  set -- $cfg; sch=$1; tb=$2
+  pf=$out/pmc_$sch.txt; [ $tb = f16 ] && pf=$out/pmc_${sch}_f16.txt
+  rm -f $pf
   while read -r c; do
     [ -z "$c" ] && continue
-    rm -rf $out/_p; rocprofv3 --pmc $c --kernel-trace -d $out/_p -o pmc -- python $root/bench.py --steps 2 --warmup 1 --schedule $sch --no-cpu-baseline --primary-only > /dev/null 2>&1
-    echo "== pass: $c" >> $out/pmc_$sch.txt
-    python $root/tools/rocpd_summary.py pmc $out/_p/pmc_results.db | grep -v k_pack >> $out/pmc_$sch.txt 2>&1
+    rm -rf $out/_p; rocprofv3 --pmc $c --kernel-trace -d $out/_p -o pmc -- python $root/bench.py --steps 2 --warmup 1 --schedule $sch --tables $tb --no-cpu-baseline --primary-only > /dev/null 2>&1
+    echo "== pass: $c" >> $pf
+    python $root/tools/rocpd_summary.py pmc $out/_p/pmc_results.db | grep -v k_pack >> $pf 2>&1
     rm -rf $out/_p
   done <<LIST
 MfmaUtil VALUBusy
@@ -45,7 +47,8 @@ done
 python $root/tools/traffic_from_pmc.py $out > $out/latest_traffic.json
 cp $out/latest_traffic.json $root/profiles/latest_traffic.json      # the un-profiled bench line at the end of this script reads it (same sources: fingerprint matches)
 # micro-benchmarks
-[ -x $root/tools/ubench/gathers_ub ] && timeout 300 $root/tools/ubench/gathers_ub > $out/ubench_gathers.txt 2>&1
+[ -x $root/tools/ubench/gathers_ub ] && timeout 300 $root/tools/ubench/gathers_ub > $out/ubench_gathers.txt 2>&1 && \
+  python $root/tools/ubench_to_json.py $out/ubench_gathers.txt > $out/latest_ubench.json && cp $out/latest_ubench.json $root/profiles/latest_ubench.json
 [ -x $root/tools/ubench/valu_rate_ub ] && timeout 120 $root/tools/ubench/valu_rate_ub > $out/ubench_valu_rate.txt 2>&1
 python $root/tools/mlp_bench.py > $out/ubench_head_mlp.txt 2>&1
 python $root/tools/wgrad_bench.py 2>/dev/null | tail -1 > $out/ubench_wgrad.json
