@@ -513,6 +513,18 @@ __device__ __forceinline__ void blend_span(const GroupRegs<T, 2, G> &r, Emit emi
 #ifndef SN_FINAL_SPANS
 #define SN_FINAL_SPANS 0
 #endif
+#ifndef SN_LT_TWO_PASS
+#define SN_LT_TWO_PASS 0     // linear tail, fp32 tables: 1 = composite tile by tile, 0 = one compositing pass (tile 0's activations held across tile 1's matrix phase)
+#endif
+#ifndef SN_LT_TWO_PASS_H
+#define SN_LT_TWO_PASS_H 0   // the same for fp16 tables (same-box: [128] 6.37 ms tile by tile, 6.31 ms in one pass; per-sample form 6.61 ms)
+#endif
+#ifndef SN_FINAL_SPANS_LT_H
+#define SN_FINAL_SPANS_LT_H 4  // the same for fp16 tables
+#endif
+#ifndef SN_FINAL_SPANS_LT
+#define SN_FINAL_SPANS_LT 4    // linear-tail instantiation: 64 weight-accumulated hidden values per lane live through the march -> short span 0
+#endif
 template <int CFG> struct FinalSpans;
 template <> struct FinalSpans<0> { static constexpr int N = 4; static constexpr int B[5] = {0, 4, 8, 12, 16}; };
 template <> struct FinalSpans<1> { static constexpr int N = 4; static constexpr int B[5] = {0, 2, 6, 11, 16}; };
@@ -1339,6 +1351,77 @@ __device__ __forceinline__ void grid_mlp_mfma16_2t(const uint4 *__restrict__ pk,
     }
 }
 
+// "Linear tail" form of the final stage (k_final_stage<..., LT = true>).  The third layer has no activation behind it and the
+// compositing is linear in what it produces, so for the 15 geometry channels
+//     sum_j w_j * (W3[1:16] relu(h2_j))  =  W3[1:16] * (sum_j w_j relu(h2_j)),
+// (renderer.py:332-336 composites `color`, network.py:175-186 forms it from grid_mlp's outputs 1..15): only the density row of
+// the third layer is needed per sample -- one 64-term dot product, in true fp32 on the vector ALU -- while the geometry rows are
+// applied ONCE per ray to the weight-accumulated hidden vector.  That takes the third layer off the matrix cores: 72 instead
+// of 96 MFMAs per wave-sample and 48 instead of 64 KiB of LDS weight reads, which matters because the kernel runs at the
+// clock the power management allows (the matrix-core MLP costs ~4 % in cycles and ~14 % in clock).
+// A documented re-association like SH(d) * sum_j w_j; fp32 round-off class, not bit-identical to the
+// per-sample form the other final-stage kernels (and per-sample geometry outputs) keep.
+//
+// layers 1 and 2 of ONE tile (32 samples): x[mt * 16 + r] = relu(h2) of hidden row mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ void grid_mlp_mfma16_l12(const uint4 *__restrict__ pk, const uint32_t *__restrict__ slab_hi,
+                                                    const uint32_t *__restrict__ slab_lo, int tile, float (&x)[32]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = lane & 31u, hi = lane >> 5;
+    const uint32_t row = ((uint32_t)tile * 32u + lo) * SLAB_STRIDE + 4u * hi;
+    floatx16 h1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const uint4 bh = *reinterpret_cast<const uint4 *>(slab_hi + row + 8 * st);
+            const uint4 bl = *reinterpret_cast<const uint4 *>(slab_lo + row + 8 * st);
+            const int vec = mt * 2 + st;
+            acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+        }
+        h1[mt] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 bh, bl;
+            acc_to_b(h1[q >> 1], q & 1, bh, bl);
+            const int vec = 4 + mt * 4 + q;
+            acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[mt * 16 + r] = relu_bits(acc[r]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// W3 re-ordered for the linear tail: w3p[half][o][i] = W3[o][mt*32 + (r&3) + 8*(r>>2) + 4*half], i = mt*16 + r -- the hidden
+// rows a lane of that half-wave holds, in its register order (o = 0: density row, 1..15: geometry rows)
+constexpr int W3P_FLOATS = 2 * 16 * 32;
+constexpr int W3P_OFFSET = (12 * 2) * 64 * 4;            // floats: the packed layer-3 operands' place in the LDS weight image (unused here)
+static_assert(W3P_OFFSET + W3P_FLOATS <= PACK_FLOATS, "the re-ordered W3 fits where the packed layer-3 operands were");
+__device__ __forceinline__ void stage_w3p(float *__restrict__ dst, const float *__restrict__ w3) {
+    for (uint32_t t = threadIdx.x; t < (uint32_t)W3P_FLOATS; t += blockDim.x) {
+        const uint32_t i = t & 31u, o = (t >> 5) & 15u, half = t >> 9;
+        const uint32_t mt = i >> 4, r = i & 15u;
+        dst[t] = w3[o * 64u + mt * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half];
+    }
+}
+// sum_i w[i] * x[i] over the lane's 32 hidden rows: four interleaved ascending fmaf chains, combined (s0 + s1) + (s2 + s3)
+__device__ __forceinline__ float dot32_lds(const float *__restrict__ w, const float (&x)[32]) {
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i4 = 0; i4 < 8; ++i4) {
+        const float4 ww = *reinterpret_cast<const float4 *>(w + 4 * i4);
+        s[0] = __builtin_fmaf(ww.x, x[4 * i4 + 0], s[0]); s[1] = __builtin_fmaf(ww.y, x[4 * i4 + 1], s[1]);
+        s[2] = __builtin_fmaf(ww.z, x[4 * i4 + 2], s[2]); s[3] = __builtin_fmaf(ww.w, x[4 * i4 + 3], s[3]);
+    }
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
 // hash-grid features of one position, split into f16 hi / lo and written to this lane's slab rows
 // (dword l = the level's two features as a half2).
 template <typename T, int L, int GROUP, int K>
@@ -1398,8 +1481,9 @@ enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 
 // AUX: the instantiation that also serves the feature stage (weights -> scratch) and the opt-in early termination;
 // the plain one carries neither (one spilled register less in the march of the headline configuration)
-template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false>
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false, bool LT = false>
 __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_final_stage(FinalArgs a) {
+    static_assert(!LT || (MODE == MLP_F16X3 && K >= 4 && K <= 8), "linear tail: split-fp16 MLP on the FinalLv path");
     constexpr bool MFMA = MODE != MLP_VALU;
     constexpr int IN = L * C;
     constexpr int GEO = NOUT - 1;
@@ -1420,6 +1504,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         static_assert(PACK16_U4 * 4 == PACK_FLOATS, "both packings fill the same 32 KiB");
         for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += 256u)
             reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
+        if constexpr (LT) { __syncthreads(); stage_w3p(lds + W3P_OFFSET, a.w[2]); }     // over the (unused) packed layer-3 operands
         constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;   // dwords: hi image + lo image
         float *wave_base = lds + PACK_FLOATS + (threadIdx.x >> 6) * WAVE_SLAB;
         slab_hi = reinterpret_cast<uint32_t *>(wave_base);
@@ -1477,6 +1562,15 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     float dep = 0.0f;
     double cum = 0.0, wsum = 0.0;
     const TT *table = reinterpret_cast<const TT *>(a.table);
+    // linear tail: sum_j w_j relu(h2_j) of the lane's 32 hidden rows, for the tile-0 and the tile-1 sample it shares
+    float hacc[LT ? 2 : 1][LT ? 32 : 1];
+    if constexpr (LT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) hacc[t][i] = 0.0f;
+    }
+    const float *w3p = lds + W3P_OFFSET + (threadIdx.x & 32u) * 16u;          // this half-wave's rows: [o][32]
 
     float bprev = bin_at(0);
     float rb_prev = real_bin(rs, bprev);
@@ -1484,7 +1578,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     // software pipeline (MLP_F16X3): group 0 of sample j+1 is issued before the matrix-core phase of sample j
     constexpr int PG = 4;                                   // levels per gather group (generic instantiations)
     constexpr bool LV = SN_FINAL_LV && MODE == MLP_F16X3 && K >= PG && K <= 8;   // FinalLv path; the prefetched span is all dense
-    using SP = FinalSpans<LV ? SN_FINAL_SPANS : 0>;         // FinalLv path: gather spans (span 0 crosses the matrix-core phase)
+    using SP = FinalSpans<LV ? (LT ? (sizeof(TT) == 2 ? SN_FINAL_SPANS_LT_H : SN_FINAL_SPANS_LT) : SN_FINAL_SPANS) : 0>;   // FinalLv path: gather spans (span 0 crosses the matrix-core phase)
     constexpr int G0 = LV ? SP::B[1] : PG;
     static_assert(!LV || (L == 16 && SP::B[SP::N] == L && G0 <= K), "spans cover the 16 levels; span 0 is dense");
     GroupRegs<TT, 2, G0> g0;
@@ -1573,7 +1667,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
             if constexpr (LV) grid_mlp_mfma16_2t(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
             else grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
 #else
-            grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
+            if constexpr (!LT) grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
 #endif
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (MODE == MLP_F32) {
@@ -1590,6 +1684,60 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
 #pragma unroll
             for (int k = 0; k < NOUT; ++k) h[k] = actB[k * fstride];
         }
+        if constexpr (LT && (sizeof(TT) == 2 ? SN_LT_TWO_PASS_H : SN_LT_TWO_PASS)) {
+            // tile by tile: layers 1-2, density dot, the compositing step of that tile's home lanes, the accumulator update -- the
+            // 32 activations of tile 0 are dead before tile 1's matrix phase begins (one compositing pass over both tiles would hold
+            // them across it: 32 registers the kernel does not have)
+            const float delta = rb_next - rb_prev;
+            const uint32_t oz = opaque_zero();
+            const uint32_t my_half = (threadIdx.x >> 5) & 1u;
+            static_for<0, 2>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                float x[32];
+                grid_mlp_mfma16_l12(reinterpret_cast<const uint4 *>(lds) + oz, slab_hi, slab_lo, t, x);
+                const float part = dot32_lds(w3p + oz, x);                            // this half's share of the density row
+                auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                const float h0 = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);     // half 0's share + half 1's share, in every lane
+                float wv = 0.0f;
+                if (my_half == (uint32_t)t) {                                         // home lanes of this tile's samples
+                    const float sigma = expf_det(h0);                                 // network.py:151
+                    float ds = delta * sigma;
+                    if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+                    const float alpha = 1.0f - expf_det(-ds);
+                    const float tr = expf_det(-(float)cum);
+                    float w = alpha * tr;
+                    if (w != w) w = 0.0f;
+                    cum += (double)ds;
+                    wsum += (double)w;
+                    dep = __builtin_fmaf(w, tmid, dep);
+                    if constexpr (AUX) { if (a.w_out) a.w_out[(size_t)j * Npad + r] = w; }
+                    wv = w;
+                }
+                // every lane holds 32 hidden rows of this tile's sample (lane & 31): its weight comes from the home lane
+                auto ww = __builtin_amdgcn_permlane32_swap(__float_as_uint(wv), __float_as_uint(wv), false, false);
+                const float wt = __uint_as_float(ww[t]);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) hacc[t][i] = __builtin_fmaf(wt, x[i], hacc[t][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (AUX) { if (a.stop_cum > 0.0f && __all((float)cum > a.stop_cum)) break; }
+            rb_prev = rb_next;
+            continue;
+        }
+        float xh[LT ? 2 : 1][LT ? 32 : 1];
+        if constexpr (LT) {
+            const uint32_t oz = opaque_zero();
+            float part[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                grid_mlp_mfma16_l12(reinterpret_cast<const uint4 *>(lds) + oz, slab_hi, slab_lo, t, xh[t]);
+                part[t] = dot32_lds(w3p + oz, xh[t]);                                  // this half's share of the density row
+            }
+            __builtin_amdgcn_wave_barrier();
+            // lanes 0-31 are the home of the tile-0 samples, lanes 32-63 of the tile-1 samples: half 0's share + half 1's share
+            auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[1]), false, false);
+            h[0] = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);
+        }
         const float sigma = expf_det(h[0]);                  // network.py:151
         const float delta = rb_next - rb_prev;
         float ds = delta * sigma;
@@ -1601,10 +1749,18 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         cum += (double)ds;
         wsum += (double)w;
         dep = __builtin_fmaf(w, tmid, dep);
+        if constexpr (LT) {
+            // every lane needs the weights of BOTH samples whose hidden rows it holds: w of ray (lane & 31) and of ray 32 + (lane & 31)
+            auto ww = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+            const float w0 = __uint_as_float(ww[0]), w1 = __uint_as_float(ww[1]);
 #pragma unroll
-        for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, h[1 + c], fimg[c]);
+            for (int i = 0; i < 32; ++i) { hacc[0][i] = __builtin_fmaf(w0, xh[0][i], hacc[0][i]); hacc[1][i] = __builtin_fmaf(w1, xh[1][i], hacc[1][i]); }
+        } else {
+#pragma unroll
+            for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, h[1 + c], fimg[c]);
+        }
         if constexpr (AUX) { if (a.w_out) a.w_out[(size_t)j * Npad + r] = w; }
-        if (ok) {
+        if constexpr (!LT) if (ok) {                         // (the linear-tail instantiation is not chosen when per-sample tensors are wanted)
             if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
             if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
             if (a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
@@ -1627,6 +1783,24 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     }
 
     clock_probe(1);
+    if constexpr (LT) {
+        // geometry channels, once per ray: W3[1 + c] . (sum_j w_j relu(h2_j)); both tiles' shares, then the half-wave exchange
+#pragma unroll 1
+        for (int c = 0; c < GEO; ++c) {
+            const float *wr = w3p + (1 + c) * 32;
+            const float q0 = dot32_lds(wr, hacc[0]), q1 = dot32_lds(wr, hacc[1]);
+            auto qq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q0), __float_as_uint(q1), false, false);
+            const float v = __uint_as_float(qq[0]) + __uint_as_float(qq[1]);
+            // (runtime c: keeps the loop rolled; fimg is indexed statically below)
+            switch (c) {
+#define SN_FIMG_CASE(I) case I: fimg[I] = v; break;
+                SN_FIMG_CASE(0) SN_FIMG_CASE(1) SN_FIMG_CASE(2) SN_FIMG_CASE(3) SN_FIMG_CASE(4) SN_FIMG_CASE(5) SN_FIMG_CASE(6) SN_FIMG_CASE(7)
+                SN_FIMG_CASE(8) SN_FIMG_CASE(9) SN_FIMG_CASE(10) SN_FIMG_CASE(11) SN_FIMG_CASE(12) SN_FIMG_CASE(13) SN_FIMG_CASE(14)
+#undef SN_FIMG_CASE
+                default: break;
+            }
+        }
+    }
     // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
     static_assert(VH <= IN && NCOL <= IN && IN * 64 <= 2 * 64 * SLAB_STRIDE, "view MLP activations reuse the feature column / slab");
     if constexpr (MFMA) {
@@ -2729,6 +2903,14 @@ static uint32_t final_sp_max_rays() {
     return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u;
 }
 
+// the linear-tail form of the default final stage (third layer's geometry rows applied once per ray) is used wherever no
+// per-sample tensor leaves the kernel; SN_RENDER_LT=0 keeps the per-sample form (bit-identical to the compacting / several-lanes-
+// per-ray / role-split kernels, which all evaluate the third layer per sample)
+static bool lt_enabled() {
+    const char *e = getenv("SN_RENDER_LT");
+    return !(e && e[0] == '0');
+}
+
 // SN_RENDER_RS=1: the role-split final stage (k_final_stage_rs) where it applies
 static bool rs_enabled() {
     const char *e = getenv("SN_RENDER_RS");
@@ -3139,6 +3321,18 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_rs<float, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL((k_final_stage_rs<float, 5>), dim3(nblk_rs), dim3(RS_THREADS), lds_bytes, st, fa);
             }
+        } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !(fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo) && lt_enabled()) {
+            // linear tail: layer 3 off the matrix cores (per-sample geometry features are not available in this form)
+#define SN_LAUNCH_FINAL_LT(TT_, AUX_)                                                                                          \
+            do {                                                                                                             \
+                const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);                   \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
+                hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+            } while (0)
+            if (aux) { if (f16) SN_LAUNCH_FINAL_LT(__half, true); else SN_LAUNCH_FINAL_LT(float, true); }
+            else { if (f16) SN_LAUNCH_FINAL_LT(__half, false); else SN_LAUNCH_FINAL_LT(float, false); }
+#undef SN_LAUNCH_FINAL_LT
         } else if (mlp_mode == MLP_F16X3) {
             if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
             else SN_LAUNCH_FINAL_AUX(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);

@@ -31,3 +31,13 @@ def gpu():
     assert os.path.exists(_lib.LIB_PATH), f"{_lib.LIB_PATH} missing on the GPU box"
     assert _lib.lib().sn_device_count() >= 1, _lib.lib().sn_last_error()
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def per_sample_form(monkeypatch):
+    """The default final stage applies the third MLP layer's geometry rows once per ray to the weight-accumulated hidden vector
+    (the "linear tail", render.hip / DESIGN.md section 5) wherever no per-sample tensor leaves the kernel.  The other final-stage
+    kernels (several lanes per ray, live-sample compaction, role-split waves) and every call that exports per-sample tensors keep
+    the per-sample form; their BIT identity with the default kernel is a statement about that form, so tests that assert it pin
+    the default kernel to it.  (test_linear_tail_form_* bounds the difference between the two forms: fp32 round-off.)"""
+    monkeypatch.setenv("SN_RENDER_LT", "0")

@@ -107,7 +107,7 @@ def test_mlp_paths_agree(gpu, orc):
         os.environ.pop("SN_RENDER_MLP", None)
 
 
-def test_model_render_api_and_staging(gpu, orc):
+def test_model_render_api_and_staging(gpu, orc, per_sample_form):
     """NeRFRenderer.render: result keys, chunk neutrality (renderer.py:185-219), tile mapping neutrality,
     cam_near_far and tensor backgrounds."""
     params = synthetic_params([128, 64, 32], seed=5)
@@ -614,7 +614,7 @@ def test_unsupported_configurations_fail_loudly(gpu, orc):
         rm.render_rays(rm.RenderPlan(model, [128, 64, 32]), torch.rand(8, 3), torch.rand(8, 3))
 
 
-def test_feature_stage_equals_grid_composite(gpu, orc):
+def test_feature_stage_equals_grid_composite(gpu, orc, per_sample_form):
     """The in-render feature stage (f_sam of renderer.py:301-302 + 361) == sn_rm_grid_composite on the last stage's
     exported weights / positions, bit for bit (same position code, same accumulation order), for both schedules."""
     from sanerf_hq_amd import raymarching as rm
@@ -641,7 +641,7 @@ def test_feature_stage_equals_grid_composite(gpu, orc):
         assert float((out16["f_feat"] - out["f_feat"]).abs().max()) < 2e-2 * float(out["f_feat"].abs().max())
 
 
-def test_early_stop_is_opt_in_and_bounded(gpu, orc):
+def test_early_stop_is_opt_in_and_bounded(gpu, orc, per_sample_form):
     """SURVEY 8f-1: transmittance early-out of the last stage.  Off by default (bit-identical to the plain plan);
     switched on, what is dropped is the tail of the ray whose total weight is below eps: weights_sum moves by < eps
     and every composited feature by < eps * max|feature|."""
@@ -665,7 +665,7 @@ def test_early_stop_is_opt_in_and_bounded(gpu, orc):
     assert torch.equal(full["image"], base["image"])
 
 
-def test_compact_live_is_bit_identical_when_nothing_is_skipped(gpu, orc):
+def test_compact_live_is_bit_identical_when_nothing_is_skipped(gpu, orc, per_sample_form):
     """SURVEY 8f-1 / north_star "wavefront prefix-scan compaction of live samples": k_final_stage_cmp deals a wave's 64
     evaluation slots out to the rays still live.  On the contracted scene no ray misses and, without an eps, none
     terminates: slot s is ray s and every output must equal the default kernel's bit for bit -- image tiles (incl. a
@@ -685,7 +685,7 @@ def test_compact_live_is_bit_identical_when_nothing_is_skipped(gpu, orc):
                     assert torch.equal(a[k], b[k]), (steps, H, W, tile, dt, k, float((a[k] - b[k]).abs().max()))
 
 
-def test_compact_live_per_ray_termination_is_bounded(gpu, orc):
+def test_compact_live_per_ray_termination_is_bounded(gpu, orc, per_sample_form):
     """Per-ray transmittance termination on top of the compaction: a ray stops taking samples once exp(-optical depth)
     < eps, so what is dropped weighs less than eps in total -- the same bound as the wave-granular early-out, per ray."""
     from sanerf_hq_amd import raymarching as rm
@@ -709,7 +709,7 @@ def test_compact_live_per_ray_termination_is_bounded(gpu, orc):
     assert torch.equal(full["image"], base["image"])
 
 
-def test_compact_live_skips_rays_that_miss_the_aabb(gpu, orc):
+def test_compact_live_skips_rays_that_miss_the_aabb(gpu, orc, per_sample_form):
     """renderer.py:133-135: a ray that misses the aabb gets near = far = 1e9.  The reference (and the default kernel, and
     the oracle) still march it -- through infinite distances; with a single stage every delta is inf - inf, every weight
     NaN -> 0, so the pixel is the background colour.  k_final_stage_cmp never assigns such a ray a slot: same image and
@@ -828,7 +828,7 @@ def test_sam_distillation_step_vs_reference_fixture(gpu, orc):
 
 
 @pytest.mark.parametrize("case", range(6))
-def test_randomised_shapes_vs_oracle(gpu, orc, case):
+def test_randomised_shapes_vs_oracle(gpu, orc, case, per_sample_form):
     """Seeded sweep over schedules, odd image sizes (partial 16x16 tiles, partial waves), per-ray near/far clamps and
     table precisions: sample indices bit-exact, image / depth within the fp32 contract, tiled == linear lane mapping."""
     from sanerf_hq_amd import raymarching as rm
@@ -857,7 +857,7 @@ def test_randomised_shapes_vs_oracle(gpu, orc, case):
 
 @pytest.mark.parametrize("steps,f16", [([128, 64, 32], False), ([33, 17, 9], True), ([20, 40, 10], False), ([128, 128], True),
                                         ([128], False), ([200], True), ([7], False)])
-def test_sample_parallel_stages_are_bit_identical(gpu, orc, steps, f16, monkeypatch):
+def test_sample_parallel_stages_are_bit_identical(gpu, orc, steps, f16, monkeypatch, per_sample_form):
     """Small linear-order batches (training steps) run every stage with several lanes per ray (k_prop_stage_sp,
     k_final_stage_sp); every tensor must equal the one-lane-per-ray kernels' bit for bit, and the sample indices the
     oracle's.  Ray counts that are not multiples of 32 / 256 exercise the padding columns, step counts that are not
@@ -886,7 +886,7 @@ def test_sample_parallel_stages_are_bit_identical(gpu, orc, steps, f16, monkeypa
     np.testing.assert_allclose(sp["image"].cpu().numpy(), ref["image"], rtol=0, atol=1e-5)
 
 
-def test_sample_parallel_final_stage_feeds_the_feature_stage(gpu, orc, monkeypatch):
+def test_sample_parallel_final_stage_feeds_the_feature_stage(gpu, orc, monkeypatch, per_sample_form):
     """The SAM feature stage reads the final stage's weights from scratch: same f_feat from either final-stage kernel."""
     from sanerf_hq_amd import raymarching as rm
     steps = [64, 32]

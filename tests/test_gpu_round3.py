@@ -44,7 +44,7 @@ def test_full_size_both_table_precisions_and_schedules(gpu, orc, steps, f16):
 
 
 @pytest.mark.parametrize("steps", [[128], [128, 64, 32], [7], [33, 17, 9]])
-def test_role_split_final_stage_is_bit_identical(gpu, orc, steps, monkeypatch):
+def test_role_split_final_stage_is_bit_identical(gpu, orc, steps, monkeypatch, per_sample_form):
     """k_final_stage_rs (SN_RENDER_RS=1: producer waves gather and blend, consumer waves run the matrix-core MLP and composite,
     hand-over through LDS rings) performs the arithmetic of k_final_stage in its order: every output must be equal bit for bit,
     for ragged image shapes, tiled and linear lane mapping and both table precisions."""
@@ -66,6 +66,7 @@ def test_role_split_final_stage_is_bit_identical(gpu, orc, steps, monkeypatch):
                     assert torch.equal(a[k], b[k]), (steps, tdt, H, W, tile, k, float((a[k] - b[k]).abs().max()))
     # against the oracle directly as well (one shape)
     monkeypatch.setenv("SN_RENDER_RS", "1")
+    monkeypatch.setenv("SN_RENDER_LT", "0")
     _, _, ro, rd = camera_rays(orc, 32, 32)
     plan = rm.RenderPlan(model, steps)
     got = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32)
@@ -227,3 +228,55 @@ def test_rccl_leg_on_one_gpu():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selftest.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl selftest OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("steps", [[128], [128, 64, 32], [7]])
+def test_linear_tail_form_vs_per_sample_form_and_oracle(gpu, orc, steps, monkeypatch):
+    """The default final stage (no per-sample outputs) takes the third layer off the matrix cores: density row per sample as an
+    fp32 dot product, geometry rows once per ray on sum_j w_j relu(h2_j).  A re-association (like SH(d) * sum_j w_j): it must stay
+    in the fp32 round-off class -- against the per-sample form (SN_RENDER_LT=0) and against the oracle -- for ragged shapes, both
+    lane mappings and both table precisions, with and without the feature stage."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    params = synthetic_params(steps, heads=True, seed=29)
+    model = product_model(params, steps, True, gpu)
+    pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    for tdt in (torch.float32, torch.float16):
+        for feat in (None, model.s_grid):
+            plan = rm.RenderPlan(model, steps, tdt, feat_encoder=feat)
+            for (H, W) in ((64, 64), (40, 24)):
+                intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
+                ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
+                monkeypatch.setenv("SN_RENDER_LT", "0")
+                a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={}).items()}
+                monkeypatch.setenv("SN_RENDER_LT", "1")
+                b = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
+                assert float((a["image"] - b["image"]).abs().max()) <= 4e-6
+                assert float((a["weights_sum"] - b["weights_sum"]).abs().max()) <= 1e-6
+                np.testing.assert_allclose(b["depth"].cpu().numpy(), a["depth"].cpu().numpy(), rtol=2e-6, atol=2e-6)
+                fmax = float(a["f_image"].abs().max())
+                assert float((a["f_image"] - b["f_image"]).abs().max()) <= 2e-6 * max(fmax, 1.0)
+                if feat is not None:
+                    assert float((a["f_feat"] - b["f_feat"]).abs().max()) <= 2e-6 * max(float(a["f_feat"].abs().max()), 1.0)
+                else:
+                    want = orc.render(oracle_cfg(orc, params, steps, table_f16=(tdt == torch.float16)), ro.cpu().numpy(), rd.cpu().numpy())
+                    np.testing.assert_allclose(b["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+                    np.testing.assert_allclose(b["depth"].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
+
+
+def test_linear_tail_form_vs_reference_fixtures(gpu, orc, monkeypatch):
+    """The reference's own outputs (tests/golden/render_sref.npz, render_flat128.npz) through the default call without per-sample
+    tensors, i.e. the linear-tail kernel (the several-lanes-per-ray kernels that small batches normally take are switched off):
+    RGB within the north-star tolerance 1e-4, depth / weights_sum within 1e-4."""
+    from helpers import golden, params_from_spec, spec_of
+    from sanerf_hq_amd import raymarching as rm
+    monkeypatch.setenv("SN_FINAL_SP_MAX", "0")
+    monkeypatch.setenv("SN_PROP_SP_MAX", "0")
+    for name, steps in (("render_sref", [128, 64, 32]), ("render_flat128", [128])):
+        g = golden(name)
+        model = product_model(params_from_spec(spec_of(g)), steps, False, gpu)
+        u_tables = {k: T(g[f"u{k}"], gpu) for k in range(1, len(steps))} if len(steps) > 1 else None
+        plan = rm.RenderPlan(model, steps)
+        out = rm.render_rays(plan, T(g["rays_o"], gpu), T(g["rays_d"], gpu), u_tables=u_tables)
+        np.testing.assert_allclose(out["image"].cpu().numpy(), g["image"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out["depth"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), g["weights_sum"], rtol=0, atol=1e-4)
