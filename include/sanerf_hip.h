@@ -337,9 +337,15 @@ int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uin
  * exp_avg_sq = beta2 * exp_avg_sq + (1-beta2) g^2; param -= lr / (1-beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1-beta2^step) + eps)
  * -- with 16-byte accesses, 4 streams read and 3 written.  Same dense semantics (untouched rows keep moving by their
  * momentum); elements whose gradient and both moments are exactly zero are skipped (their update is exactly zero).
- * Hyper-parameters are doubles like the Python floats torch derives its scalars from.  step counts from 1.  zero_grad != 0: the gradient is cleared in the same pass (for callers that accumulate in place). */
+ * Hyper-parameters are doubles like the Python floats torch derives its scalars from.  step counts from 1.
+ * flags: SN_ADAM_ZERO_GRAD -- the gradient is cleared in the same pass (for callers that accumulate in place);
+ *        SN_ADAM_LAZY -- opt-in touched-elements-only update (NOT the reference's optimiser): an element whose gradient
+ *        is exactly zero in this step is skipped altogether (moments do not decay, the parameter does not move) -- the semantics of
+ *        torch.optim.SparseAdam with the non-zeros of the dense gradient as the sparse pattern; requires weight_decay = 0. */
+#define SN_ADAM_ZERO_GRAD 1
+#define SN_ADAM_LAZY 2
 int sn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, double lr, double beta1, double beta2,
-                 double eps, double weight_decay, uint32_t step, int maximize, int zero_grad, sn_stream_t stream);
+                 double eps, double weight_decay, uint32_t step, int maximize, int flags, sn_stream_t stream);
 
 /* Measurement hook (bench.py): bracket every kernel sn_rm_render_rays launches with hipEvents on the
  * caller's stream.  Classes: 0 weight pack, 1..3 proposal stage k, 4 final stage.  profile_read

@@ -8,6 +8,12 @@
 // single-tensor recipe of torch/optim/adam.py (_single_tensor_adam) applied once per element with 16-byte accesses:
 // 4 streams read (param, grad, exp_avg, exp_avg_sq), 3 written.  Elements whose gradient and both moments are exactly
 // zero -- table rows no sample has reached yet -- are left untouched (their update is exactly 0): no stores for them.
+//
+// Opt-in LAZY mode (flags & SN_ADAM_LAZY; SURVEY 8 f2 "fused Adam over touched table rows only"): elements whose gradient is
+// exactly zero in THIS step are skipped altogether -- moments do not decay, the parameter does not coast on its momentum -- the
+// semantics of torch.optim.SparseAdam with the dense gradient's non-zeros as the sparse pattern.  A different optimiser from
+// the reference's (hence opt-in): a hash table of which a 4096-ray batch touches a few percent then costs a read of the
+// gradient stream plus the touched elements instead of seven full streams.
 #include "sn_common.h"
 
 namespace sn {
@@ -16,13 +22,13 @@ struct AdamArgs {
     float *p, *g, *m, *v;
     uint64_t n;
     float one_minus_beta1, beta2, one_minus_beta2, step_size, inv_bc2_sqrt, eps, weight_decay;
-    int zero_grad, maximize;
+    int zero_grad, maximize, lazy;
 };
 
 __device__ __forceinline__ bool adam_one(float &p, float g, float &m, float &v, const AdamArgs &a) {
     if (a.maximize) g = -g;
     if (a.weight_decay != 0.0f) g = g + a.weight_decay * p;              // grad.add(param, alpha=weight_decay)
-    if (g == 0.0f && m == 0.0f && v == 0.0f) return false;               // update is exactly zero
+    if (g == 0.0f && (a.lazy || (m == 0.0f && v == 0.0f))) return false; // update is exactly zero -- or, lazy: element not touched this step
     m = m + a.one_minus_beta1 * (g - m);                                 // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
     const float gg = g * g;
     v = v * a.beta2 + a.one_minus_beta2 * gg;                            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 using namespace sn;
 
 extern "C" int sn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, double lr, double beta1, double beta2,
-                            double eps, double weight_decay, uint32_t step, int maximize, int zero_grad, sn_stream_t stream) {
+                            double eps, double weight_decay, uint32_t step, int maximize, int flags, sn_stream_t stream) {
     if (n == 0) return SN_OK;
     SN_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam_step: param/grad/exp_avg/exp_avg_sq must be device pointers");
     SN_REQUIRE(table_aligned(param) && table_aligned(grad) && table_aligned(exp_avg) && table_aligned(exp_avg_sq), "adam_step: tensors must be 16-byte aligned");
@@ -78,7 +84,9 @@ extern "C" int sn_adam_step(float *param, float *grad, float *exp_avg, float *ex
     a.one_minus_beta2 = (float)(1.0 - beta2);
     a.step_size = (float)(lr / bc1);
     a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    a.eps = (float)eps; a.weight_decay = (float)weight_decay; a.zero_grad = zero_grad; a.maximize = maximize;
+    a.eps = (float)eps; a.weight_decay = (float)weight_decay; a.zero_grad = flags & SN_ADAM_ZERO_GRAD; a.maximize = maximize;
+    a.lazy = (flags & SN_ADAM_LAZY) ? 1 : 0;
+    SN_REQUIRE(!(a.lazy && weight_decay != 0.0), "adam_step: lazy mode is defined for weight_decay = 0 (a decayed zero gradient is not a skipped element)");
     const uint64_t nq = n >> 2;
     uint64_t blocks = (nq + 255) / 256;
     if (blocks > 256u * 16u) blocks = 256u * 16u;                         // 16 workgroups per CU, grid-stride beyond

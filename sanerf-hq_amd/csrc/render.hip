@@ -531,6 +531,11 @@ template <> struct FinalSpans<1> { static constexpr int N = 4; static constexpr 
 template <> struct FinalSpans<2> { static constexpr int N = 4; static constexpr int B[5] = {0, 3, 7, 12, 16}; };
 template <> struct FinalSpans<3> { static constexpr int N = 4; static constexpr int B[5] = {0, 1, 6, 11, 16}; };
 template <> struct FinalSpans<4> { static constexpr int N = 5; static constexpr int B[6] = {0, 2, 5, 9, 13, 16}; };
+template <> struct FinalSpans<5> { static constexpr int N = 5; static constexpr int B[6] = {0, 1, 4, 8, 12, 16}; };
+template <> struct FinalSpans<6> { static constexpr int N = 5; static constexpr int B[6] = {0, 2, 4, 8, 12, 16}; };
+template <> struct FinalSpans<7> { static constexpr int N = 5; static constexpr int B[6] = {0, 3, 6, 9, 13, 16}; };
+template <> struct FinalSpans<8> { static constexpr int N = 5; static constexpr int B[6] = {0, 4, 7, 10, 13, 16}; };
+template <> struct FinalSpans<9> { static constexpr int N = 6; static constexpr int B[7] = {0, 2, 5, 8, 11, 14, 16}; };
 
 // FAST test of one sample (see FinalLv): wave-uniform
 __device__ __forceinline__ bool all_interior(const FinalLv &lv, const float (&x01)[3]) {
@@ -1351,6 +1356,46 @@ __device__ __forceinline__ void grid_mlp_mfma16_2t(const uint4 *__restrict__ pk,
     }
 }
 
+// Slab row addressing.  Padded form: 20 dwords per sample row.  Swizzled form (SW): 16 dwords per row, the four 16-byte blocks
+// of a row XOR-ed with (row >> 2) & 3 -- conflict-free for the ds_read_b128 of the B operands without the 4 padding dwords,
+// which frees 8 KiB per workgroup for the LDS-resident coarse level below.
+template <bool SW>
+__device__ __forceinline__ uint32_t slab_dword(uint32_t row, uint32_t d) {
+    if constexpr (SW) return row * 16u + ((((d >> 2) ^ (row >> 2)) & 3u) << 2) + (d & 3u);
+    else return row * (uint32_t)SLAB_STRIDE + d;
+}
+
+// LDS-resident level 0 (north_star: "LDS staging of per-tile grid voxels"; the reference's only gesture at table locality is its
+// level-major launch, gridencoder.cu:383-399).  The coarsest level of the main grid is 16^3 vertices = 16 KiB of fp16 rows: every
+// workgroup stages it once and its 2 x 128 samples per lane read their 8 corners with ds_read_b32 instead of two 16-byte gathers
+// through the texture path (98 -> 96 gather instructions per wave-sample).  Arithmetic as issue_level_lv's dense branch.
+constexpr int L0_MAX_ROWS = 4096;
+template <int l>
+__device__ __forceinline__ void issue_level0_lds(const FinalLv &lv, const uint32_t *__restrict__ l0tab, const float (&x01)[3], float (&pos)[3],
+                                                 Corner<__half, 2> (&cv)[8]) {
+    static_assert(l == 0, "level 0 only");
+    const float rf = lv.res_f[0];
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = __builtin_fmaf(x01[d], rf, -0.5f);
+        p = __builtin_amdgcn_fmed3f(p, 0.0f, lv.top_f[0]);
+        cell[d] = (uint32_t)p;
+        pos[d] = __builtin_amdgcn_fractf(p);
+    }
+    // vertex index in dwords: x + res * y + res^2 * z (the quad-row strides of FinalLv are 16 bytes per vertex: >> 4)
+    const uint32_t sy = lv.d_sy[0] >> 4, sz = lv.d_sz[0] >> 4, top = (uint32_t)lv.top_f[0];
+    const uint32_t X0 = cell[0], X1 = umin(X0 + 1u, top);
+    const uint32_t Y0 = __umul24(cell[1], sy), Y1 = umin(Y0 + sy, lv.d_ylim[0] >> 4);
+    const uint32_t Z0 = __umul24(cell[2], sz), Z1 = umin(Z0 + sz, lv.d_zlim[0] >> 4);
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t w = l0tab[((i & 1u) ? X1 : X0) + ((i & 2u) ? Y1 : Y0) + ((i & 4u) ? Z1 : Z0)];
+        const __half2 h = *reinterpret_cast<const __half2 *>(&w);
+        cv[i].v[0] = __low2float(h); cv[i].v[1] = __high2float(h);
+    }
+}
+
 // "Linear tail" form of the final stage (k_final_stage<..., LT = true>).  The third layer has no activation behind it and the
 // compositing is linear in what it produces, so for the 15 geometry channels
 //     sum_j w_j * (W3[1:16] relu(h2_j))  =  W3[1:16] * (sum_j w_j relu(h2_j)),
@@ -1363,19 +1408,21 @@ __device__ __forceinline__ void grid_mlp_mfma16_2t(const uint4 *__restrict__ pk,
 // per-sample form the other final-stage kernels (and per-sample geometry outputs) keep.
 //
 // layers 1 and 2 of ONE tile (32 samples): x[mt * 16 + r] = relu(h2) of hidden row mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <bool SW = false>
 __device__ __forceinline__ void grid_mlp_mfma16_l12(const uint4 *__restrict__ pk, const uint32_t *__restrict__ slab_hi,
                                                     const uint32_t *__restrict__ slab_lo, int tile, float (&x)[32]) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lo = lane & 31u, hi = lane >> 5;
-    const uint32_t row = ((uint32_t)tile * 32u + lo) * SLAB_STRIDE + 4u * hi;
+    const uint32_t srow = (uint32_t)tile * 32u + lo;
     floatx16 h1[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const uint4 bh = *reinterpret_cast<const uint4 *>(slab_hi + row + 8 * st);
-            const uint4 bl = *reinterpret_cast<const uint4 *>(slab_lo + row + 8 * st);
+            const uint32_t off = slab_dword<SW>(srow, 4u * hi + 8u * (uint32_t)st);
+            const uint4 bh = *reinterpret_cast<const uint4 *>(slab_hi + off);
+            const uint4 bl = *reinterpret_cast<const uint4 *>(slab_lo + off);
             const int vec = mt * 2 + st;
             acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
         }
@@ -1481,9 +1528,11 @@ enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 
 // AUX: the instantiation that also serves the feature stage (weights -> scratch) and the opt-in early termination;
 // the plain one carries neither (one spilled register less in the march of the headline configuration)
-template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false, bool LT = false>
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false, bool LT = false, bool L0L = false>
 __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_final_stage(FinalArgs a) {
     static_assert(!LT || (MODE == MLP_F16X3 && K >= 4 && K <= 8), "linear tail: split-fp16 MLP on the FinalLv path");
+    static_assert(!L0L || (LT && sizeof(TT) == 2), "LDS-resident level 0: fp16 tables, linear-tail instantiation (80 KiB: 32 packed weights + 4 x 8 swizzled slabs + 16 level 0)");
+    constexpr int SLAB_DW = L0L ? 16 : SLAB_STRIDE;       // dwords per slab row
     constexpr bool MFMA = MODE != MLP_VALU;
     constexpr int IN = L * C;
     constexpr int GEO = NOUT - 1;
@@ -1505,10 +1554,16 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += 256u)
             reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
         if constexpr (LT) { __syncthreads(); stage_w3p(lds + W3P_OFFSET, a.w[2]); }     // over the (unused) packed layer-3 operands
-        constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;   // dwords: hi image + lo image
+        constexpr int WAVE_SLAB = 2 * 64 * SLAB_DW;       // dwords: hi image + lo image
         float *wave_base = lds + PACK_FLOATS + (threadIdx.x >> 6) * WAVE_SLAB;
         slab_hi = reinterpret_cast<uint32_t *>(wave_base);
-        slab_lo = slab_hi + 64 * SLAB_STRIDE;
+        slab_lo = slab_hi + 64 * SLAB_DW;
+        if constexpr (L0L) {                              // level 0 of the main grid, rows as stored (half2 = one dword per vertex)
+            uint32_t *l0w = reinterpret_cast<uint32_t *>(lds + PACK_FLOATS + 4 * WAVE_SLAB);
+            const uint32_t rows0 = a.g.res[0] * a.g.res[0] * a.g.res[0];
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.table) + a.g.off[0];
+            for (uint32_t i = threadIdx.x; i < rows0; i += 256u) l0w[i] = src[i];
+        }
         fe = wave_base + (threadIdx.x & 63u);             // after the march the slab is reused as fp32 columns
         fstride = 64u;
         lds_vw = lds;                                     // overlays the packed weights once the march is over
@@ -1531,6 +1586,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     }
     __syncthreads();
     clock_probe(0);
+    const uint32_t *l0tab = reinterpret_cast<const uint32_t *>(lds + PACK_FLOATS + 4 * 2 * 64 * SLAB_DW);   // L0L: level 0 of the main grid
 
     uint32_t n;
     const uint32_t wg = tile_id(a.rc);
@@ -1590,7 +1646,10 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     bool fast_n = false;
     if constexpr (LV) {
         fast_n = all_interior(a.lv, x01_n);
-        issue_span_lv<TT, 0, G0, K, false>(a.lv, x01_n, g0);
+        if constexpr (L0L) {
+            issue_level0_lds<0>(a.lv, l0tab, x01_n, g0.pos[0], g0.cv[0]);             // level 0 from LDS, the rest of span 0 through the texture path
+            static_for<1, G0>([&](auto kk) { constexpr int k = decltype(kk)::value; issue_level_lv<TT, true, false, false, k>(a.lv, x01_n, g0.pos[k], g0.cv[k]); });
+        } else issue_span_lv<TT, 0, G0, K, false>(a.lv, x01_n, g0);
         __builtin_amdgcn_sched_barrier(0);
     } else if constexpr (MODE == MLP_F16X3) {
         issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
@@ -1608,8 +1667,8 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
             auto emit = [&](int l, const float (&acc)[2]) {
                 uint32_t ph, pl;
                 split2(acc[0], acc[1], ph, pl);
-                row_hi[l] = ph;
-                row_lo[l] = pl;
+                if constexpr (L0L) { const uint32_t o = slab_dword<true>(lane, (uint32_t)l); slab_hi[o] = ph; slab_lo[o] = pl; }
+                else { row_hi[l] = ph; row_lo[l] = pl; }
             };
             if constexpr (LV) blend_span<TT, 0, G0, K>(g0, emit);
             else blend_group<TT, 2, PG, K, 0>(g0, emit);
@@ -1617,7 +1676,10 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
             auto zero_oob = [&]() {
                 const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
                 if (__builtin_expect(__any(oob), 0)) {      // gridencoder.cu:105-130: zeros outside [0,1]
-                    if (oob) for (int l = 0; l < L; ++l) { row_hi[l] = 0u; row_lo[l] = 0u; }
+                    if (oob) for (int l = 0; l < L; ++l) {
+                        if constexpr (L0L) { const uint32_t o = slab_dword<true>(lane, (uint32_t)l); slab_hi[o] = 0u; slab_lo[o] = 0u; }
+                        else { row_hi[l] = 0u; row_lo[l] = 0u; }
+                    }
                 }
             };
             if constexpr (LV) {
@@ -1654,7 +1716,10 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
                 sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
                 if constexpr (LV) {
                     fast_n = all_interior(a.lv, x01_n);
-                    issue_span_lv<TT, 0, G0, K, false>(a.lv, x01_n, g0);
+                    if constexpr (L0L) {
+                        issue_level0_lds<0>(a.lv, l0tab, x01_n, g0.pos[0], g0.cv[0]);             // level 0 from LDS, the rest of span 0 through the texture path
+                        static_for<1, G0>([&](auto kk) { constexpr int k = decltype(kk)::value; issue_level_lv<TT, true, false, false, k>(a.lv, x01_n, g0.pos[k], g0.cv[k]); });
+                    } else issue_span_lv<TT, 0, G0, K, false>(a.lv, x01_n, g0);
                 } else {
                     issue_group<TT, 2, PG, K, 0>(table, a.g, x01_n, g0, a.pairs);
                 }
@@ -1694,7 +1759,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
             static_for<0, 2>([&](auto tt) {
                 constexpr int t = decltype(tt)::value;
                 float x[32];
-                grid_mlp_mfma16_l12(reinterpret_cast<const uint4 *>(lds) + oz, slab_hi, slab_lo, t, x);
+                grid_mlp_mfma16_l12<L0L>(reinterpret_cast<const uint4 *>(lds) + oz, slab_hi, slab_lo, t, x);
                 const float part = dot32_lds(w3p + oz, x);                            // this half's share of the density row
                 auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
                 const float h0 = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);     // half 0's share + half 1's share, in every lane
@@ -1730,7 +1795,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
             float part[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                grid_mlp_mfma16_l12(reinterpret_cast<const uint4 *>(lds) + oz, slab_hi, slab_lo, t, xh[t]);
+                grid_mlp_mfma16_l12<L0L>(reinterpret_cast<const uint4 *>(lds) + oz, slab_hi, slab_lo, t, xh[t]);
                 part[t] = dot32_lds(w3p + oz, xh[t]);                                  // this half's share of the density row
             }
             __builtin_amdgcn_wave_barrier();
@@ -1802,7 +1867,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         }
     }
     // ---- per-ray colour head: view_mlp(f_image) -> sigmoid -> + (1 - wsum) * bg (renderer.py:340-357) ----
-    static_assert(VH <= IN && NCOL <= IN && IN * 64 <= 2 * 64 * SLAB_STRIDE, "view MLP activations reuse the feature column / slab");
+    static_assert(VH <= IN && NCOL <= IN && IN * 64 <= 2 * 64 * SLAB_DW, "view MLP activations reuse the feature column / slab");
     if constexpr (MFMA) {
         // every wave marches the same T steps: once all are done the 32 KiB of packed MLP weights are dead and
         // the view-MLP weights take their place (keeps the workgroup under 80 KiB of LDS = 2 workgroups per CU)
@@ -3330,8 +3395,23 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
                 hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
             } while (0)
-            if (aux) { if (f16) SN_LAUNCH_FINAL_LT(__half, true); else SN_LAUNCH_FINAL_LT(float, true); }
+            // SN_RENDER_L0=1 (opt-in): fp16 tables whose level 0 fits 16 KiB keep that level LDS-resident.  Bit-identical and measured
+            // SLOWER than the texture path (800x800 [128]: 6.44 -> 6.58 ms, profiles/r03/ab_round3_experiments.txt): with fp16 tables the
+            // kernel is not bound by the texture addressers, and the 8 ds_read_b32 + swizzled slab addressing cost more than 2 gathers save
+            const uint64_t rows0 = (uint64_t)gl_main.res[0] * gl_main.res[0] * gl_main.res[0];
+            const char *l0e = getenv("SN_RENDER_L0");
+            const bool l0 = f16 && rows0 <= (uint64_t)L0_MAX_ROWS && (l0e && l0e[0] == '1');
+#define SN_LAUNCH_FINAL_LT_L0(AUX_)                                                                                            \
+            do {                                                                                                             \
+                const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * 16 + L0_MAX_ROWS) * sizeof(float);              \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, true>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
+                hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, true>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+            } while (0)
+            if (l0) { if (aux) SN_LAUNCH_FINAL_LT_L0(true); else SN_LAUNCH_FINAL_LT_L0(false); }
+            else if (aux) { if (f16) SN_LAUNCH_FINAL_LT(__half, true); else SN_LAUNCH_FINAL_LT(float, true); }
             else { if (f16) SN_LAUNCH_FINAL_LT(__half, false); else SN_LAUNCH_FINAL_LT(float, false); }
+#undef SN_LAUNCH_FINAL_LT_L0
 #undef SN_LAUNCH_FINAL_LT
         } else if (mlp_mode == MLP_F16X3) {
             if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense

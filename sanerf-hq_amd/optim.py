@@ -5,6 +5,11 @@ same constructor arguments, same `state_dict` layout (`step`, `exp_avg`, `exp_av
 rule -- every element moves each step by its decaying momentum, touched by a sample or not.  torch's default foreach
 implementation walks the 160 MiB state of a head grid in ~20 multi-tensor kernels; this is one pass per tensor.
 CUDA fp32 contiguous parameters only; anything else raises (no silent fallback).
+
+`lazy=True` (per parameter group, opt-in) switches that group to a touched-elements-only update: an element whose
+gradient is exactly zero in a step is skipped altogether (moments do not decay, the parameter does not coast on its momentum) --
+torch.optim.SparseAdam's semantics with the non-zeros of the dense gradient as the sparse pattern.  Not the reference's
+optimiser: meant for the hash tables, of which a 4096-ray batch touches a few percent of the rows.
 """
 from __future__ import annotations
 
@@ -14,12 +19,12 @@ from . import _lib
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False, lazy=False):
         if amsgrad:
             raise ValueError("sanerf_hq_amd.optim.Adam: amsgrad is not implemented (the reference does not use it)")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0.0:
             raise ValueError("invalid Adam hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize, lazy=bool(lazy)))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -47,7 +52,7 @@ class Adam(torch.optim.Optimizer):
                 lr = group["lr"]
                 _lib.check(lib.sn_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                                             float(lr), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                            int(st["step"].item()), int(bool(group["maximize"])), 0, _lib.stream()), "sn_adam_step")
+                                            int(st["step"].item()), int(bool(group["maximize"])), 2 if group.get("lazy", False) else 0, _lib.stream()), "sn_adam_step")
                 # the kernel wrote through the raw pointer: tell autograd / version-keyed caches (RenderPlan.check_range's fp16
                 # range guard, memoised host copies) that the tensor changed, as an in-place torch op would have
                 torch.autograd.graph.increment_version(p)

@@ -280,3 +280,62 @@ def test_linear_tail_form_vs_reference_fixtures(gpu, orc, monkeypatch):
         np.testing.assert_allclose(out["image"].cpu().numpy(), g["image"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(out["depth"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), g["weights_sum"], rtol=0, atol=1e-4)
+
+
+def test_lazy_adam_updates_touched_elements_only(gpu):
+    """SURVEY 8 f2 (opt-in, not the reference's optimiser): sanerf_hq_amd.optim.Adam(lazy=True) skips every element whose gradient is
+    exactly zero in a step -- moments do not decay, the parameter does not move -- and applies the dense recipe (global step count
+    in the bias corrections, as torch.optim.SparseAdam does) to the others.  Checked against that rule written in torch."""
+    from sanerf_hq_amd.optim import Adam
+    n, lr, b1, b2, eps = 4096 * 9 + 2, 1e-2, 0.9, 0.999, 1e-15
+    rng = np.random.default_rng(3)
+    p0 = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(gpu)
+    pa = torch.nn.Parameter(p0.clone())
+    opt = Adam([dict(params=[pa], lr=lr, lazy=True)], eps=eps)
+    p = p0.clone().double(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    never = torch.ones(n, dtype=torch.bool, device=gpu)
+    for step in range(1, 7):
+        g = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(gpu)
+        mask = torch.from_numpy(rng.uniform(size=n) < 0.15).to(gpu)
+        g = g * mask
+        never &= ~mask
+        before = pa.detach().clone()
+        pa.grad = g.clone()
+        opt.step()
+        gd = g.double()
+        m_new = m + (1 - b1) * (gd - m); v_new = v * b2 + (1 - b2) * gd * gd
+        denom = v_new.sqrt() / (1 - b2 ** step) ** 0.5 + eps
+        p_new = p - lr / (1 - b1 ** step) * m_new / denom
+        m, v, p = torch.where(mask, m_new, m), torch.where(mask, v_new, v), torch.where(mask, p_new, p)
+        assert torch.equal(pa.detach()[~mask], before[~mask]), "untouched elements must not move"
+        assert float((pa.detach().double() - p).abs().max()) <= 2e-6 * float(p.abs().max()), step
+    st = opt.state[pa]
+    assert float((st["exp_avg"].double() - m).abs().max()) <= 1e-6 * float(m.abs().max())
+    assert float((st["exp_avg_sq"].double() - v).abs().max()) <= 1e-6 * float(v.abs().max())
+    assert torch.equal(pa.detach()[never], p0[never]) and never.any()
+    with pytest.raises(RuntimeError, match="lazy"):
+        bad = Adam([dict(params=[torch.nn.Parameter(p0.clone())], lr=lr, lazy=True)], eps=eps, weight_decay=1e-3)
+        bad.param_groups[0]["params"][0].grad = torch.ones(n, device=gpu)
+        bad.step()
+
+
+def test_lds_resident_level0_is_bit_identical(gpu, orc, monkeypatch):
+    """SN_RENDER_L0=1 (opt-in; north_star "LDS staging of per-tile grid voxels"): with fp16 tables the coarsest level of the main
+    grid (16^3 vertices, 16 KiB) is staged in LDS by every workgroup and read with ds_read_b32 instead of gathers; same arithmetic
+    as the texture-path form, so every output is equal bit for bit (feature slabs move to their unpadded XOR-swizzled layout)."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    for steps in ([128], [128, 64, 32], [7]):
+        params = synthetic_params(steps, heads=True, seed=31)
+        model = product_model(params, steps, True, gpu)
+        for feat in (None, model.s_grid):
+            plan = rm.RenderPlan(model, steps, torch.float16, feat_encoder=feat)
+            for (H, W) in ((64, 64), (48, 80), (40, 24)):
+                intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
+                ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
+                monkeypatch.setenv("SN_RENDER_L0", "0")
+                a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={}).items()}
+                monkeypatch.setenv("SN_RENDER_L0", "1")
+                b = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
+                for k in a:
+                    assert torch.equal(a[k], b[k]), (steps, feat is not None, H, W, k)
