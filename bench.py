@@ -8,7 +8,7 @@ stand-alone, in which case this script re-launches itself as N ranks (one per GP
 if fewer than N devices are visible.
 
 Workload, random-init (hash-generated) weights, synthetic orbit camera, rays resident in HBM:
-  N = 1 (default)  BASELINE configs[1]: 800x800 rays, hashgrid L=16 T=2^19 F=2, 32-64-64-16 + 31-32-32-3 MLPs,
+  N = 1 (default)  BASELINE configs[1]: 800x800 rays, hashgrid L=16 T=2^19 F=2, 32-64-64-16 + 31-32-32-3 MLPs, fp16 tables (--tables),
                    --schedule flat128 = num_steps [128] (the literal "128 samples/ray through the L=16 grid"),
                    --schedule ref     = [128,64,32] with both proposal grids (the reference's default).
   N > 1 (default)  BASELINE configs[3], STRONG scaling: one fixed 1600x1600 image, contiguous row bands
@@ -57,7 +57,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
                     help="auto: N=1 -> configs[1] (800x800); N>1 -> strong scaling on the fixed 1600x1600 image of configs[3]")
     ap.add_argument("--hw", type=int, default=0, help="image side (default 800; 1600 for strong scaling)")
-    ap.add_argument("--tables", choices=["f32", "f16"], default="f32")
+    ap.add_argument("--tables", choices=["f32", "f16"], default="f16",
+                    help="hash-table storage: f16 = what BASELINE configs[1] names (the reference's fp16 mode keeps its tables in half), f32 = the "
+                         "model's own parameters; arithmetic is fp32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="world size 1 only: still go through RCCL (init, all-gather pipeline, barriers)")
@@ -352,9 +354,9 @@ def main():
         H4 = 1600
         ro4, rd4 = rm.generate_rays(pose, synth.pinhole_intrinsics(H4, H4), H4, H4, device=dev)
         for sch in ("flat128", "ref"):
-            r = measure(sch, "f32", 3, 1, rays=(ro4, rd4, H4, H4 * H4))
-            also[f"c4_1600x1600_{sch}_f32"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
-                                               "num_steps": r["steps"], "tables": "f32", "rays": H4 * H4}
+            r = measure(sch, args.tables, 3, 1, rays=(ro4, rd4, H4, H4 * H4))
+            also[f"c4_1600x1600_{sch}_{args.tables}"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
+                                                         "num_steps": r["steps"], "tables": args.tables, "rays": H4 * H4}
         del ro4, rd4
         # opt-in live-sample compaction (not reference behaviour, off in every line above): a scene whose aabb
         # two thirds of the rays miss (renderer.py:133-135), default kernels vs k_final_stage_cmp; images are bit-equal
@@ -402,9 +404,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "median_ms_per_step": round(m["median_ms"], 4),
             "higher_is_better": True, "scaling": "weak" if scaling == "weak" else "strong", "vs_baseline": None,
-            "dtype": args.tables, "data": "synthetic",
-            "dtype_note": f"{args.tables} hash tables; positions, interpolation, compositing in fp32; the 32-64-64-16 MLP multiplies fp16 hi/lo "
-                          "splits of fp32 operands on the matrix cores with fp32 accumulation (2^-22 per product, RGB within 1e-5 of the fp32 oracle)",
+            "dtype": "f32", "tables": args.tables, "data": "synthetic",
+            "dtype_note": f"arithmetic fp32 (positions, interpolation, compositing; the 32-64-64-16 MLP multiplies fp16 hi/lo splits of fp32 operands "
+                          f"on the matrix cores with fp32 accumulation: 2^-22 per product); hash tables stored as {args.tables}"
+                          + (" -- BASELINE configs[1] is the fp16 configuration: tables in half like the reference's fp16 mode (grid.py:43-49), "
+                             "results equal the fp32 oracle run on the same rounded tables to 1e-5 (also.flat128_f32: fp32 tables)" if args.tables == "f16" else ""),
             "rccl_ranks": rccl_ranks,
             "config": {"workload": f"{cfg_name}: {W}x{H} image, {n_local} rays on this GPU, hashgrid L=16 T=2^19 F=2, "
                                    f"32-64-64-16 + 31-32-32-3 MLPs, num_steps={steps} ({args.schedule}), tables {args.tables}, "

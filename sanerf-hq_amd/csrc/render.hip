@@ -133,6 +133,30 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <typename T, int C>
 struct Corner { float v[C]; };
 
+// fp16 tables, C = 2: a fetched row stays PACKED (its half2 bit pattern in v[0]) and the blend multiplies it with
+// v_fma_mix_f32, which widens an f16 operand on the fly -- the same fp32 fma on the same exactly-converted value as
+// v_cvt_f32_f16 + v_fma_f32, so results are bit-identical, but the 16 conversions per level (256 of ~1500 vector
+// instructions per sample of the final stage, 80 of ~700 in a proposal stage) disappear.  SN_HALF_MIX=0: A/B switch.
+#ifndef SN_HALF_MIX
+#define SN_HALF_MIX 1
+#endif
+template <typename T, int C>
+__device__ __forceinline__ void corner_set_half2(Corner<T, C> &c, uint32_t bits) {
+    static_assert(C == 2 && sizeof(T) == 2, "packed rows: fp16 tables with two features per level");
+    if constexpr (SN_HALF_MIX) { c.v[0] = __uint_as_float(bits); c.v[1] = 0.0f; }
+    else { const __half2 h = *reinterpret_cast<const __half2 *>(&bits); c.v[0] = __low2float(h); c.v[1] = __high2float(h); }
+}
+__device__ __forceinline__ float fma_mix_lo(float w, uint32_t packed, float acc) {      // fmaf(w, (float)packed.lo, acc)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(packed), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float w, uint32_t packed, float acc) {      // fmaf(w, (float)packed.hi, acc)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(packed), "v"(acc));
+    return d;
+}
+
 // XSWAP (hashed fine levels of the final stage): the two x-corners of a cell sit in the same 128-byte line 15 times
 // out of 16 (index = x ^ y*P1 ^ z*P2: x and x+1 differ in the low bits only), but as two instructions each line is
 // looked up twice and a fine-level instruction already touches ~40 distinct lines (its cost).
@@ -204,10 +228,7 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
             const uint4 t = *reinterpret_cast<const uint4 *>(pbase + base_off + (zi ? Z1 : Z0));
             const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                   // q = x + 2 y -> corner index x + 2 y + 4 z
-                const __half2 h = *reinterpret_cast<const __half2 *>(&w[q]);
-                cv[4 * zi + q].v[0] = __low2float(h); cv[4 * zi + q].v[1] = __high2float(h);
-            }
+            for (int q = 0; q < 4; ++q) corner_set_half2(cv[4 * zi + q], w[q]);   // q = x + 2 y -> corner index x + 2 y + 4 z
         }
         return;
     }
@@ -225,9 +246,7 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
                 cv[2 * i].v[0] = t.x; cv[2 * i].v[1] = t.y; cv[2 * i + 1].v[0] = t.z; cv[2 * i + 1].v[1] = t.w;
             } else {
                 const uint2 t = *reinterpret_cast<const uint2 *>(pbase + off);
-                const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
-                cv[2 * i].v[0] = __low2float(a); cv[2 * i].v[1] = __high2float(a);
-                cv[2 * i + 1].v[0] = __low2float(b); cv[2 * i + 1].v[1] = __high2float(b);
+                corner_set_half2(cv[2 * i], t.x); corner_set_half2(cv[2 * i + 1], t.y);
             }
         }
         return;
@@ -248,8 +267,7 @@ __device__ __forceinline__ void issue_level(const T *__restrict__ table, const G
                 cv[i].v[0] = __uint_as_float(*reinterpret_cast<const uint32_t *>(row));
                 cv[i].v[1] = 0.0f;
             } else {
-                const __half2 t = *reinterpret_cast<const __half2 *>(row);
-                cv[i].v[0] = __low2float(t); cv[i].v[1] = __high2float(t);
+                corner_set_half2(cv[i], *reinterpret_cast<const uint32_t *>(row));
             }
         } else {
 #pragma unroll
@@ -265,6 +283,18 @@ template <typename T, int C, bool PKW = false>
 __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<T, C> (&cv)[8], float (&acc)[C]) {
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    if constexpr (SN_HALF_MIX && C == 2 && sizeof(T) == 2) {   // packed fp16 rows (corner_set_half2): widening fma, same order
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; ++idx) {
+            float w = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
+            const uint32_t bits = __float_as_uint(cv[idx].v[0]);
+            acc[0] = fma_mix_lo(w, bits, acc[0]);
+            acc[1] = fma_mix_hi(w, bits, acc[1]);
+        }
+        return;
+    }
     if constexpr (PKW && C == 2) {
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 wx = {1.0f - pos[0], pos[0]};
@@ -297,9 +327,7 @@ __device__ __forceinline__ void blend_level_x(const float (&pos)[3], const Corne
         for (int p = 0; p < 4; ++p) {
             uint32_t a = __float_as_uint(cv[2 * p].v[0]), b = __float_as_uint(cv[2 * p + 1].v[0]);
             half_wave_swap(a, b);
-            const __half2 ha = *reinterpret_cast<const __half2 *>(&a), hb = *reinterpret_cast<const __half2 *>(&b);
-            own[2 * p].v[0] = __low2float(ha); own[2 * p].v[1] = __high2float(ha);
-            own[2 * p + 1].v[0] = __low2float(hb); own[2 * p + 1].v[1] = __high2float(hb);
+            corner_set_half2(own[2 * p], a); corner_set_half2(own[2 * p + 1], b);
         }
         blend_level<T, C, PKW>(pos, own, acc);
         return;
@@ -435,10 +463,7 @@ __device__ __forceinline__ void issue_level_lv(const FinalLv &lv, const float (&
                 const uint4 t = *reinterpret_cast<const uint4 *>(lv.pair_base + (X0 + Y0 + (zi ? Z1 : Z0)));
                 const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const __half2 h = *reinterpret_cast<const __half2 *>(&w[q]);
-                    cv[4 * zi + q].v[0] = __low2float(h); cv[4 * zi + q].v[1] = __high2float(h);
-                }
+                for (int q = 0; q < 4; ++q) corner_set_half2(cv[4 * zi + q], w[q]);
             }
         } else {                                 // pair rows: (x, x+1)
 #pragma unroll
@@ -474,8 +499,7 @@ __device__ __forceinline__ void issue_level_lv(const FinalLv &lv, const float (&
             } else if constexpr (XSWAP) {
                 cv[i].v[0] = __uint_as_float(*reinterpret_cast<const uint32_t *>(row)); cv[i].v[1] = 0.0f;
             } else {
-                const __half2 t = *reinterpret_cast<const __half2 *>(row);
-                cv[i].v[0] = __low2float(t); cv[i].v[1] = __high2float(t);
+                corner_set_half2(cv[i], *reinterpret_cast<const uint32_t *>(row));
             }
         }
     }
@@ -536,6 +560,12 @@ template <> struct FinalSpans<6> { static constexpr int N = 5; static constexpr 
 template <> struct FinalSpans<7> { static constexpr int N = 5; static constexpr int B[6] = {0, 3, 6, 9, 13, 16}; };
 template <> struct FinalSpans<8> { static constexpr int N = 5; static constexpr int B[6] = {0, 4, 7, 10, 13, 16}; };
 template <> struct FinalSpans<9> { static constexpr int N = 6; static constexpr int B[7] = {0, 2, 5, 8, 11, 14, 16}; };
+template <> struct FinalSpans<10> { static constexpr int N = 3; static constexpr int B[4] = {0, 2, 9, 16}; };
+template <> struct FinalSpans<11> { static constexpr int N = 4; static constexpr int B[5] = {0, 2, 7, 12, 16}; };
+template <> struct FinalSpans<12> { static constexpr int N = 3; static constexpr int B[4] = {0, 4, 10, 16}; };
+template <> struct FinalSpans<13> { static constexpr int N = 3; static constexpr int B[4] = {0, 1, 8, 16}; };
+template <> struct FinalSpans<14> { static constexpr int N = 2; static constexpr int B[3] = {0, 5, 16}; };
+template <> struct FinalSpans<15> { static constexpr int N = 3; static constexpr int B[4] = {0, 3, 9, 16}; };
 
 // FAST test of one sample (see FinalLv): wave-uniform
 __device__ __forceinline__ bool all_interior(const FinalLv &lv, const float (&x01)[3]) {
@@ -1390,9 +1420,7 @@ __device__ __forceinline__ void issue_level0_lds(const FinalLv &lv, const uint32
     const uint32_t Z0 = __umul24(cell[2], sz), Z1 = umin(Z0 + sz, lv.d_zlim[0] >> 4);
 #pragma unroll
     for (uint32_t i = 0; i < 8; ++i) {
-        const uint32_t w = l0tab[((i & 1u) ? X1 : X0) + ((i & 2u) ? Y1 : Y0) + ((i & 4u) ? Z1 : Z0)];
-        const __half2 h = *reinterpret_cast<const __half2 *>(&w);
-        cv[i].v[0] = __low2float(h); cv[i].v[1] = __high2float(h);
+        corner_set_half2(cv[i], l0tab[((i & 1u) ? X1 : X0) + ((i & 2u) ? Y1 : Y0) + ((i & 4u) ? Z1 : Z0)]);
     }
 }
 
