@@ -368,7 +368,9 @@ def main():
             also[f"compact_live_small_aabb_{sch}_f32"] = {
                 "ms_default_kernels": round(r0["ms_per_step"], 4), "ms_compact_live": round(r1["ms_per_step"], 4),
                 "rays_missing_the_aabb": round(float((r1["out"]["weights_sum"] == 0).float().mean()), 4),
-                "image_bit_equal": bool(torch.equal(img0, r1["out"]["image"])), "num_steps": r1["steps"]}
+                # (the compacting kernel keeps the per-sample third layer, the default kernel applies its geometry rows once per ray:
+                #  equal up to fp32 round-off, bit-equal with SN_RENDER_LT=0 -- tests/test_gpu_render.py)
+                "image_max_abs_diff": float((img0 - r1["out"]["image"]).abs().max()), "num_steps": r1["steps"]}
         out = m["out"]
 
     cpu_baseline = None
