@@ -34,6 +34,15 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #ifndef SN_WIDE_DMA_EARLY
 #define SN_WIDE_DMA_EARLY 1  // the 4 LDS-DMA pieces of chunk g+3 right after the barrier instead of one per tile pair: 0.465 -> 0.450 ms (SAM head MLP, 160 000 rows)
 #endif
+#ifndef SN_WIDE_INTERLEAVE
+#define SN_WIDE_INTERLEAVE 1 // MFMAs of the two tiles of a pair alternate (1) or run tile by tile (0): A/B switch
+#endif
+#ifndef SN_WIDE_TILESEQ
+#define SN_WIDE_TILESEQ 1    // a tile's three MFMAs back to back on one accumulator (1) or two tiles' MFMAs alternating (0)
+#endif
+#ifndef SN_WIDE_PIPE
+#define SN_WIDE_PIPE 1       // synchronisation + first operand reads of chunk g+1 issued under the last tile pair of chunk g (A/B switch)
+#endif
 #ifndef SN_WIDE_ABLATE
 #define SN_WIDE_ABLATE 0     // timing experiments only (wrong results): 1 = no per-chunk barrier, 2 = no weight DMA after the prologue, 3 = both
 #endif
@@ -96,6 +105,17 @@ __device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t
 }
 
 __device__ int g_wide_overflow = 0;      // sticky: a k_mlp_wide launch produced a non-finite output row (see the epilogue)
+#ifndef SN_WIDE_TRACE
+#define SN_WIDE_TRACE 0      // diagnostics build: workgroup 0 / wave 0 records the shader-cycle counter at every chunk (sn_mlp_wide_debug_trace)
+#endif
+#if SN_WIDE_TRACE
+__device__ unsigned long long g_wide_trace[256];
+__device__ __forceinline__ void wide_trace(uint32_t slot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && slot < 256u) g_wide_trace[slot] = __builtin_readcyclecounter();
+}
+#else
+__device__ __forceinline__ void wide_trace(uint32_t) {}
+#endif
 
 
 // one thread per (layer, k-step, output tile, lane): 8 weights -> (hi, lo) uint4
@@ -269,7 +289,148 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     // one chunk = one k-step x 8 output tiles; the B operand is supplied by the caller
     // npairs: output-tile pairs the layer really has (a narrow last layer -- the mask head's 256 -> n_inst -- skips the
     // padded tiles: wave-uniform)
+#if SN_WIDE_PIPE
+    // Software pipeline ACROSS chunks (round 3; cycle trace of workgroup 0 in profiles/r03/ab_round3_experiments.txt: a chunk took 1150
+    // shader cycles against 768 of matrix-pipe time -- every chunk began with "wait for the DMA, workgroup barrier, read the first tile
+    // pair's operands from LDS" fully exposed).  Now the synchronisation for chunk g+1 and the LDS reads of its first tile pair are issued
+    // before the LAST pair's MFMAs of chunk g (192 cycles of matrix pipe cover the LDS latency), so a chunk starts with its operands
+    // in registers.  Buffer (g+4) % 4 == g % 4 is refilled by DMA only after every wave has waited for its own LDS reads of chunk g
+    // (lgkmcnt(0)) and passed that barrier.
+    uint4 pah[2], pal[2];                  // (hi, lo) A operands of the first tile pair of the chunk about to start
+    auto sync_and_prefetch = [&](uint32_t gn) {        // make chunk gn readable and refill the buffer that is now free
+        const uint32_t later = total_chunks - 1u - gn;  // chunks issued after gn: their pieces may stay in flight
+        if (later >= 2u) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : : : "memory");
+        else if (later == 1u) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
+        static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
+#if !(SN_WIDE_ABLATE & 1)
+        __syncthreads();                   // every wave's pieces of chunk gn are in LDS; buffer (gn+3)%4 (chunk gn-1) has been read by all
+#endif
+        if (gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
+            const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+            const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+        }
+    };
+    auto prefetch_first_pair = [&](uint32_t gn) {      // (reads a ring buffer even past the last chunk: harmless, never used)
+        const uint4 *buf = lds_w + (gn % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        pah[0] = buf[0]; pal[0] = buf[64]; pah[1] = buf[128]; pal[1] = buf[192];
+    };
+    sync_and_prefetch(0u);
+    prefetch_first_pair(0u);
+#if SN_WIDE_TILESEQ
+    // tile by tile: the three products of a tile issue back to back on ONE accumulator (the matrix pipe forwards it: no accumulator
+    // read / write-back between them), the next tile's two operand reads ride between them
+    auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t /*npairs*/) {
+        wide_trace(g);
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+        uint4 ah[2], al[2];
+        ah[0] = pah[0]; al[0] = pal[0]; ah[1] = pah[1]; al[1] = pal[1];     // tiles 0 and 1 were fetched under the previous chunk
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt) {
+            const int cur = mt & 1;
+            const half8_t Ah = __builtin_bit_cast(half8_t, ah[cur]), Al = __builtin_bit_cast(half8_t, al[cur]);
+            floatx16 c = acc[mt];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);   // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
+            acc[mt] = c;
+            if (mt + 2 < WIDE_MT) { ah[cur] = buf[(mt + 2) * 128]; al[cur] = buf[(mt + 2) * 128 + 64]; }
+            else if (mt + 2 == WIDE_MT) {
+                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch_first_pair(g + 1u);
+            }
+            if (mt + 2 == WIDE_MT) {       // four reads (the next chunk's first two tiles) ride on this tile's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++g;
+    };
+#else
+    auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t /*npairs*/) {
+        wide_trace(g);
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
+        uint4 ah[2][2], al[2][2];
+        ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
+        // ONE wave per SIMD issues in order: whatever sits between two MFMAs longer than one MFMA's 32 cycles leaves the matrix pipe idle
+        // (cycle trace: 4 ds_read_b128 + waits + a branch between tile pairs cost ~55 cycles per pair, 1000 instead of 768 cycles per chunk
+        // even with no LDS traffic at all).  So: straight-line code -- all four tile pairs always run (tiles beyond a narrower layer are
+        // zero padding from the packer, their results are never read) -- and the next pair's four operand reads are dealt out one per MFMA.
+#pragma unroll
+        for (int pr = 0; pr < WIDE_MT / 2; ++pr) {
+            const int cur = pr & 1, nxt = cur ^ 1;
+            const bool sync_here = pr + 1 == WIDE_MT / 2;
+            if (sync_here) {
+                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch_first_pair(g + 1u);               // same basic block as this pair's MFMAs: dealt out between them like the others
+            } else {
+                ah[nxt][0] = buf[(2 * pr + 2) * 128]; al[nxt][0] = buf[(2 * pr + 2) * 128 + 64];
+                ah[nxt][1] = buf[(2 * pr + 3) * 128]; al[nxt][1] = buf[(2 * pr + 3) * 128 + 64];
+            }
+            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cur][0]), A0l = __builtin_bit_cast(half8_t, al[cur][0]);
+            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cur][1]), A1l = __builtin_bit_cast(half8_t, al[cur][1]);
+            floatx16 c0 = acc[2 * pr], c1 = acc[2 * pr + 1];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+            acc[2 * pr] = c0; acc[2 * pr + 1] = c1;
+            // issue order inside the pair: MFMA, LDS read, MFMA, LDS read, MFMA, LDS read, MFMA, LDS read, MFMA, MFMA
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++g;
+    };
+#endif
+    auto run_chunk4 = [&](const uint4 (&bh)[4], const uint4 (&bl)[4]) {
+        wide_trace(g);
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        floatx16 c0 = acc[0], c1 = acc[1];
+        uint4 ah[2][2], al[2][2];
+        ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int cur = sl & 1, nxt = cur ^ 1;
+            if (sl < 3) {
+                ah[nxt][0] = buf[(sl + 1) * 256]; al[nxt][0] = buf[(sl + 1) * 256 + 64];
+                ah[nxt][1] = buf[(sl + 1) * 256 + 128]; al[nxt][1] = buf[(sl + 1) * 256 + 192];
+            } else {
+                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch_first_pair(g + 1u);
+            }
+            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cur][0]), A0l = __builtin_bit_cast(half8_t, al[cur][0]);
+            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cur][1]), A1l = __builtin_bit_cast(half8_t, al[cur][1]);
+            const half8_t Bh = __builtin_bit_cast(half8_t, bh[sl]), Bl = __builtin_bit_cast(half8_t, bl[sl]);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first, as in run_chunk
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[0] = c0; acc[1] = c1;
+        ++g;
+    };
+#else
     auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t npairs) {
+        wide_trace(g);
         // chunk g has landed when at most the pieces of the chunks issued after it are still in flight
         const uint32_t later = total_chunks - 1u - g;
         if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
@@ -325,6 +486,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         ++g;
     };
 
+#endif
+
     // XMODE 4: the upstream gradient rows span many orders of magnitude (a sample's weight multiplies its row) and values
     // below 2^-14 would lose their lo half to fp16 subnormals, so every row is scaled by a power of two that brings its
     // largest entry to [1, 2) -- exact -- and the outputs are scaled back, exactly, on the way out
@@ -348,9 +511,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         }
     }
 
+#if !SN_WIDE_PIPE
     // A narrow last layer (the mask head's 256 -> n_inst: one tile pair) would stream 16 chunks of which 7/8 are zero
     // padding -- 39 % of the whole weight stream of that MLP.  Its packed form holds 4 k-steps x 1 pair per chunk instead.
     auto run_chunk4 = [&](const uint4 (&bh)[4], const uint4 (&bl)[4]) {
+        wide_trace(g);
         const uint32_t later = total_chunks - 1u - g;
         if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
         else if (later == 1u) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
@@ -381,6 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         ++g;
     };
 
+#endif
     auto x_operand = [&](uint32_t kx, uint4 &bh, uint4 &bl) {            // x[n][16 kx + 8 half + 0..7], zero padded
         float v[8];
         const uint32_t c0 = 16u * kx + 8u * half;
@@ -460,6 +626,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     const float act_slope = a.leaky ? 0.01f : 0.0f;
     for (uint32_t l = 0; l < a.nl; ++l) {
         const WideLayer L = a.layer[l];
+        wide_trace(128u + l);
         // bias -> accumulator init (register r of this lane is neuron 32 mt + (r&3) + 8 (r>>2) + 4 half)
 #pragma unroll
         for (int mt = 0; mt < WIDE_MT; ++mt) {
@@ -571,6 +738,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(acc[mt][r], 0.0f, chk);
         if (ok && chk != chk) g_wide_overflow = 1;
     }
+    wide_trace(160u);                      // all layers done; what follows is the output epilogue
     if constexpr (XMODE == 3) {
         // renderer.py:384: out[ray, m] = sum_t w[ray, t] * logits[ray, t, m].  Rows are samples in [ray][t] order and T divides
         // 128 or is a multiple of 32 that divides 128 (checked on the host): a ray's samples sit in T consecutive lanes of one
@@ -727,6 +895,14 @@ static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) 
 }  // namespace sn
 
 using namespace sn;
+
+#if SN_WIDE_TRACE
+extern "C" int sn_mlp_wide_debug_trace(unsigned long long *out, int n) {
+    SN_HIP_OK(hipDeviceSynchronize());
+    SN_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_trace), sizeof(unsigned long long) * (size_t)(n < 256 ? n : 256)));
+    return SN_OK;
+}
+#endif
 
 extern "C" int sn_mlp_wide_overflow(int32_t *flag) {
     SN_REQUIRE(flag, "mlp_wide_overflow: NULL output");
