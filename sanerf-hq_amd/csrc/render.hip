@@ -140,6 +140,9 @@ struct Corner { float v[C]; };
 #ifndef SN_HALF_MIX
 #define SN_HALF_MIX 1
 #endif
+#ifndef SN_HALF_MIX_PKW
+#define SN_HALF_MIX_PKW 1    // final stage, fp16 tables: packed corner-weight products in front of the widening fmas
+#endif
 template <typename T, int C>
 __device__ __forceinline__ void corner_set_half2(Corner<T, C> &c, uint32_t bits) {
     static_assert(C == 2 && sizeof(T) == 2, "packed rows: fp16 tables with two features per level");
@@ -285,14 +288,28 @@ __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
     if constexpr (SN_HALF_MIX && C == 2 && sizeof(T) == 2) {   // packed fp16 rows (corner_set_half2): widening fma, same order
+        float w[8];
+        if constexpr (SN_HALF_MIX_PKW && PKW) {                // the 8 corner weights as 6 packed multiplies: every weight still (wx * wy) * wz
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 wx = {1.0f - pos[0], pos[0]};
+            const float wy0 = 1.0f - pos[1], wz0 = 1.0f - pos[2];
+            const f2 xy0 = wx * f2{wy0, wy0}, xy1 = wx * f2{pos[1], pos[1]};
+            const f2 w01 = xy0 * f2{wz0, wz0}, w23 = xy1 * f2{wz0, wz0}, w45 = xy0 * f2{pos[2], pos[2]}, w67 = xy1 * f2{pos[2], pos[2]};
+            w[0] = w01.x; w[1] = w01.y; w[2] = w23.x; w[3] = w23.y; w[4] = w45.x; w[5] = w45.y; w[6] = w67.x; w[7] = w67.y;
+        } else {
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; ++idx) {
+                float t = 1.0f;
+#pragma unroll
+                for (uint32_t d = 0; d < 3; ++d) t *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
+                w[idx] = t;
+            }
+        }
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; ++idx) {
-            float w = 1.0f;
-#pragma unroll
-            for (uint32_t d = 0; d < 3; ++d) w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
             const uint32_t bits = __float_as_uint(cv[idx].v[0]);
-            acc[0] = fma_mix_lo(w, bits, acc[0]);
-            acc[1] = fma_mix_hi(w, bits, acc[1]);
+            acc[0] = fma_mix_lo(w[idx], bits, acc[0]);
+            acc[1] = fma_mix_hi(w[idx], bits, acc[1]);
         }
         return;
     }
@@ -410,8 +427,8 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
         float acc[C];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, C, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, C, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
         emit(l, acc);
     });
 }
@@ -528,8 +545,8 @@ __device__ __forceinline__ void blend_span(const GroupRegs<T, 2, G> &r, Emit emi
         constexpr int l = L0 + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
         float acc[2];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
         emit(l, acc);
     });
 }
@@ -1487,7 +1504,22 @@ __device__ __forceinline__ void stage_w3p(float *__restrict__ dst, const float *
     }
 }
 // sum_i w[i] * x[i] over the lane's 32 hidden rows: four interleaved ascending fmaf chains, combined (s0 + s1) + (s2 + s3)
+#ifndef SN_LT_PK
+#define SN_LT_PK 1           // linear tail: the four partial chains of the dot products and the accumulator update as packed fp32 fmas (same
+                             // per-element arithmetic, half the issue slots)
+#endif
+typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot32_lds(const float *__restrict__ w, const float (&x)[32]) {
+#if SN_LT_PK
+    f2v s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+#pragma unroll
+    for (int i4 = 0; i4 < 8; ++i4) {
+        const float4 ww = *reinterpret_cast<const float4 *>(w + 4 * i4);
+        s01 = __builtin_elementwise_fma(f2v{ww.x, ww.y}, f2v{x[4 * i4 + 0], x[4 * i4 + 1]}, s01);
+        s23 = __builtin_elementwise_fma(f2v{ww.z, ww.w}, f2v{x[4 * i4 + 2], x[4 * i4 + 3]}, s23);
+    }
+    return (s01.x + s01.y) + (s23.x + s23.y);
+#else
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i4 = 0; i4 < 8; ++i4) {
@@ -1496,6 +1528,7 @@ __device__ __forceinline__ float dot32_lds(const float *__restrict__ w, const fl
         s[2] = __builtin_fmaf(ww.z, x[4 * i4 + 2], s[2]); s[3] = __builtin_fmaf(ww.w, x[4 * i4 + 3], s[3]);
     }
     return (s[0] + s[1]) + (s[2] + s[3]);
+#endif
 }
 
 // hash-grid features of one position, split into f16 hi / lo and written to this lane's slab rows
@@ -1811,7 +1844,10 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
                 auto ww = __builtin_amdgcn_permlane32_swap(__float_as_uint(wv), __float_as_uint(wv), false, false);
                 const float wt = __uint_as_float(ww[t]);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) hacc[t][i] = __builtin_fmaf(wt, x[i], hacc[t][i]);
+                for (int i = 0; i < 32; i += 2) {
+                    const f2v r = __builtin_elementwise_fma(f2v{wt, wt}, f2v{x[i], x[i + 1]}, f2v{hacc[t][i], hacc[t][i + 1]});
+                    hacc[t][i] = r.x; hacc[t][i + 1] = r.y;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (AUX) { if (a.stop_cum > 0.0f && __all((float)cum > a.stop_cum)) break; }
@@ -1848,7 +1884,11 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
             auto ww = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
             const float w0 = __uint_as_float(ww[0]), w1 = __uint_as_float(ww[1]);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { hacc[0][i] = __builtin_fmaf(w0, xh[0][i], hacc[0][i]); hacc[1][i] = __builtin_fmaf(w1, xh[1][i], hacc[1][i]); }
+            for (int i = 0; i < 32; i += 2) {
+                const f2v r0 = __builtin_elementwise_fma(f2v{w0, w0}, f2v{xh[0][i], xh[0][i + 1]}, f2v{hacc[0][i], hacc[0][i + 1]});
+                const f2v r1 = __builtin_elementwise_fma(f2v{w1, w1}, f2v{xh[1][i], xh[1][i + 1]}, f2v{hacc[1][i], hacc[1][i + 1]});
+                hacc[0][i] = r0.x; hacc[0][i + 1] = r0.y; hacc[1][i] = r1.x; hacc[1][i + 1] = r1.y;
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < GEO; ++c) fimg[c] = __builtin_fmaf(w, h[1 + c], fimg[c]);
@@ -2087,8 +2127,8 @@ __device__ __forceinline__ void blend_span_from(const GroupRegs<T, 2, MG> &r, Em
         constexpr int l = L0 + k;
         constexpr int KIND = l < K ? 0 : 1;
         float acc[2];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, 2, (SN_BLEND_PKW && sizeof(T) == 4)>(r.pos[k], r.cv[k], acc);
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
         emit(std::integral_constant<int, l>{}, acc);
     });
 }
