@@ -770,6 +770,13 @@ __device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &
 #ifndef SN_PROP_PB
 #define SN_PROP_PB 4         // cdf entries per block of the sample_pdf merge (pass 2 of the proposal stage); 8: same, 16: slower (select chains)
 #endif
+#ifndef SN_PROP_MFMA
+#define SN_PROP_MFMA 0       // proposal MLP layer 1 on v_mfma_f32_32x32x2_f32, B operands of both 32-sample tiles from one v_permlane32_swap per
+                             // k-step, no LDS (round 3): bit-identical (sigma / inds tests green), 150 fewer vector instructions per sample, and
+                             // SLOWER -- prop0 1.32 -> 1.60 ms, prop1 0.70 -> 0.83 ms (fp16 tables; 4 waves without spills: 1.62 / 0.86): five
+                             // dependent 64-cycle MFMAs + a 16-step fma chain hopping between the half-waves lengthen the per-wave dependent
+                             // chain that bounds this stage (as the LDS-transposed 16x16x4 attempt of round 2 did)
+#endif
 #ifndef SN_PROP_ABLATE_PASS2
 #define SN_PROP_ABLATE_PASS2 0
 #endif
@@ -810,6 +817,17 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
     double cum = 0.0, wacc = 0.0;
     const TT *table = reinterpret_cast<const TT *>(a.table);
+#if SN_PROP_MFMA
+    // matrix-core operands of the 10-16-1 MLP: this lane's column of W0 per k-step, and W1 at the hidden rows its accumulator registers hold
+    float pa[5], pw1[8];
+    {
+        const uint32_t m = threadIdx.x & 31u, kh = (threadIdx.x >> 5) & 1u;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) pa[s5] = (IN == 10 && m < (uint32_t)HID) ? a.w0[m * (uint32_t)IN + 2u * (uint32_t)s5 + kh] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pw1[q] = a.w1[(uint32_t)(q & 3) + 8u * (uint32_t)(q >> 2) + 4u * kh];
+    }
+#endif
     for (uint32_t j = 0; j < T; ++j) {
         const float bnext = bin_at(j + 1);
         const float rb_next = real_bin(rs, bnext);
@@ -818,10 +836,59 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
         sample_x01(a.rc, rs, tmid, p, x01);
         float feat[L * C];
         encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : SN_PROP_GROUP_H)>(table, a.g, x01, feat, &a.pairs);
-        float h[HID], raw[1];
-        const uint32_t oz = opaque_zero();
-        dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
-        dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, raw);
+        float raw[1];
+#if SN_PROP_MFMA
+        if constexpr (IN == 10 && HID == 16) {
+            // layer 1 (10 -> 16) on v_mfma_f32_32x32x2_f32: D[m][n] += A[m][k] B[k][n], five k-steps of 2.  Lane l supplies A[m = l&31][k = l>>5]
+            // (loop-invariant registers pa[]) and B[k = l>>5][n = l&31]: one v_permlane32_swap per k-step turns the lanes' own features
+            // (2s, 2s+1) into the B operands of BOTH 32-sample tiles.  fp32 MFMA accumulates c + a0*b0 + a1*b1 as an ascending fma chain, i.e.
+            // the oracle's order (asserted bit for bit by the sigma / inds tests).  The vector ALU, which bounds this stage, loses 176 fmas + 44
+            // LDS weight reads and keeps 16 relu + 32 fma + 12 swaps.
+            floatx16 h0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, h1 = h0;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                auto bb = __builtin_amdgcn_permlane32_swap(__float_as_uint(feat[2 * s5]), __float_as_uint(feat[2 * s5 + 1]), false, false);
+                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s5], __uint_as_float(bb[0]), h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s5], __uint_as_float(bb[1]), h1, 0, 0, 0);
+            }
+            // layer 2 (16 -> 1): ONE m-ascending fma chain per sample.  Accumulator register q of a lane is hidden row (q&3) + 8 (q>>2) + 4 (l>>5):
+            // rows 0-3 and 8-11 sit in the low half-wave, 4-7 and 12-15 in the high one, so the running sum hops between the halves three times.
+            float x0[8], x1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { x0[q] = __builtin_fmaxf(h0[q], 0.0f); x1[q] = __builtin_fmaxf(h1[q], 0.0f); }
+            float t0 = 0.0f, t1 = 0.0f;
+            auto seg = [&](int q0) {
+#pragma unroll
+                for (int q = q0; q < q0 + 4; ++q) { t0 = __builtin_fmaf(pw1[q], x0[q], t0); t1 = __builtin_fmaf(pw1[q], x1[q], t1); }
+            };
+            auto up = [&]() {      // low half -> high half (the low half's copies become don't-care)
+                auto u0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t0), false, false);
+                auto u1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1), __float_as_uint(t1), false, false);
+                t0 = __uint_as_float(u0[0]); t1 = __uint_as_float(u1[0]);
+            };
+            auto down = [&]() {    // high half -> low half
+                auto u0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t0), false, false);
+                auto u1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1), __float_as_uint(t1), false, false);
+                t0 = __uint_as_float(u0[1]); t1 = __uint_as_float(u1[1]);
+            };
+            seg(0);                                       // rows 0-3   (valid in the low half)
+            up();
+            { const bool hi_half = (threadIdx.x & 32u) != 0u; t0 = hi_half ? t0 : 0.0f; t1 = hi_half ? t1 : 0.0f; }
+            seg(0);                                       // rows 4-7   (high half continues the chain; the low half restarts from 0: unused)
+            down();
+            seg(4);                                       // rows 8-11  (low half)
+            up();
+            seg(4);                                       // rows 12-15 (high half): the finished sums of BOTH tiles sit in the high half
+            auto fin = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t1), false, false);
+            raw[0] = __uint_as_float(fin[1]);             // lanes 0-31: tile 0 (their own samples), lanes 32-63: tile 1
+        } else
+#endif
+        {
+            float h[HID];
+            const uint32_t oz = opaque_zero();
+            dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
+            dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, raw);
+        }
         const float sigma = expf_det(raw[0]);                // trunc_exp forward (activation.py:9)
         const float delta = rb_next - rb_prev;
         float ds = delta * sigma;
