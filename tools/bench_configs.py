@@ -105,7 +105,7 @@ def main():
         out["compact_live_small_aabb_800x800_" + "_".join(map(str, sch))] = {
             "ms_default_kernel": round(ts[0] * 1e3, 3), "ms_compact": round(ts[1] * 1e3, 3),
             "rays_missing_the_aabb": round(float((o1["weights_sum"] == 0).float().mean()), 4),
-            "image_bit_equal": bool(torch.equal(o0["image"], o1["image"]))}
+            "image_max_abs_diff": float((o0["image"] - o1["image"]).abs().max())}   # (per-sample third layer vs linear tail: fp32 round-off)
         del soft
     # ---- C5 ----
     model = build(False, True, dev).train()
