@@ -2996,17 +2996,19 @@ __global__ void k_pack_pairs(const T *__restrict__ table, GridLevels g, PairTab 
     const uint32_t res = g.res[l], rows = res * res * res;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
-    const uint32_t x = i % res;
-    const uint32_t j = i + (x + 1u < res ? 1u : 0u);                     // gridencoder.cu:182: the +1 neighbour is clamped to res-1
+    // vertex (x, y, z) -> its row through the level's OWN index function (gridencoder.cu:45-79): for a dense level that is i itself;
+    // a hashed level that is "densified" for this render (densify_levels below) is looked up through the hash, once per vertex, here
+    const uint32_t x = i % res, y = (i / res) % res, z = i / (res * res);
+    const uint32_t x1 = x + 1u < res ? x + 1u : x, y1 = y + 1u < res ? y + 1u : y;      // gridencoder.cu:182: the +1 neighbour is clamped to res-1
+    const uint32_t size = g.size[l], mode = g.mode[l];
+    auto row = [&](uint32_t xx, uint32_t yy) { const uint32_t p[3] = {xx, yy, z}; return grid_row<3>(p, res, size, mode); };
     const T *tab = table + (size_t)g.off[l] * 2u;
     if constexpr (sizeof(T) == 4) {
-        const float2 a = reinterpret_cast<const float2 *>(tab)[i], b = reinterpret_cast<const float2 *>(tab)[j];
+        const float2 a = reinterpret_cast<const float2 *>(tab)[row(x, y)], b = reinterpret_cast<const float2 *>(tab)[row(x1, y)];
         reinterpret_cast<float4 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_float4(a.x, a.y, b.x, b.y);
     } else {
-        const uint32_t y = (i / res) % res;
-        const uint32_t iy = i + (y + 1u < res ? res : 0u), jy = j + (y + 1u < res ? res : 0u);       // +1 in y, clamped
         const uint32_t *tw = reinterpret_cast<const uint32_t *>(tab);
-        reinterpret_cast<uint4 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_uint4(tw[i], tw[j], tw[iy], tw[jy]);
+        reinterpret_cast<uint4 *>(const_cast<void *>(pt.base))[pt.off[l] + i] = make_uint4(tw[row(x, y)], tw[row(x1, y)], tw[row(x, y1)], tw[row(x1, y1)]);
     }
 }
 
@@ -3200,17 +3202,42 @@ int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
     return SN_OK;
 }
 
-// floats reserved after the packed MLP weights for the pair / quad rows of one grid's dense levels (16 bytes per
-// vertex for either table type)
-static size_t pair_floats_of(const sn_grid_desc *d) {
+// Densified levels (round 3).  The first hashed levels of the main grid have few enough vertices (102^3, 148^3) to be re-laid out per
+// render call like the dense ones: one 16-byte pair / quad row per VERTEX, fetched through the hash once per vertex by k_pack_pairs
+// instead of once per sample-corner by the march.  The final stage then reads them with 4 (fp32) / 2 (fp16) aligned, spatially coherent
+// gathers instead of 8 scattered ones -- 12 fewer gather instructions per wave-sample of 98 -- at the price of a 69 MB pack per call
+// (~60 us), so only for renders with enough samples to pay for it.  Same values, same arithmetic: bit-identical.
+// SN_RENDER_DENSIFY: unset = automatic, 0 = never, 1 / 2 = force that many levels.
+constexpr uint64_t DENSIFY_MIN_SAMPLES = 40ull << 20;       // rays x samples of the last stage
+constexpr uint64_t DENSIFY_MAX_VERTICES = 6ull << 20;       // 96 MB of 16-byte rows
+static int densify_levels(const GridLevels &g, int K, uint64_t samples, bool f16 = true) {
+    if (K != 5 || g.L != 16 || g.C != 2) return K;           // (the K + 2 = 7 instantiation is built for the main grid's shape)
+    const char *e = getenv("SN_RENDER_DENSIFY");
+    // automatic for fp16 tables only: 800x800 [128] 6.35 -> 6.22 ms incl. the pack; with fp32 tables the K = 7 instantiation spills 14
+    // registers and the call comes out 0.4 % slower (6.957 -> 6.983 ms)
+    int want = (samples >= DENSIFY_MIN_SAMPLES && f16) ? 2 : 0;
+    if (e && e[0] >= '0' && e[0] <= '2') want = e[0] - '0';
+    if (want != 2) return K;                                 // one extra level alone is not instantiated
+    uint64_t v = 0;
+    for (int l = 0; l < K + 2; ++l) {
+        if ((uint64_t)g.res[l] * g.res[l] * 16u >= (1u << 24)) return K;      // dense byte strides go through 24-bit multiplies
+        v += (uint64_t)g.res[l] * g.res[l] * g.res[l];
+    }
+    return v <= DENSIFY_MAX_VERTICES ? K + 2 : K;
+}
+
+// floats reserved after the packed MLP weights for the pair / quad rows of one grid's dense (and densified) levels (16 bytes
+// per vertex for either table type)
+static size_t pair_floats_of(const sn_grid_desc *d, uint64_t densify_samples = 0) {
     GridLevels g;
     if (d->D != 3 || d->C != 2 || build_grid_levels(&g, d->offsets, d->D, d->C, d->L, d->S, d->H, d->gridtype, (int)d->align_corners, d->interp) != SN_OK) return 0;
     if (!levels_fast(g)) return 0;
     uint32_t off[8];
-    return (size_t)pair_layout(g, dense_prefix(g), off) * 4u;
+    const int K = dense_prefix(g);
+    return (size_t)pair_layout(g, densify_samples ? densify_levels(g, K, densify_samples) : K, off) * 4u;
 }
-static size_t pair_region_floats(const sn_render_cfg *cfg) {
-    size_t f = pair_floats_of(&cfg->grid);
+static size_t pair_region_floats(const sn_render_cfg *cfg, uint64_t main_samples) {
+    size_t f = pair_floats_of(&cfg->grid, main_samples);
     for (uint32_t k = 0; k + 1 < cfg->num_stages && k < SN_MAX_STAGES; ++k) f += pair_floats_of(&cfg->prop_grid[k]);
     return f;
 }
@@ -3219,7 +3246,8 @@ size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32
     if (!cfg || N == 0) return (size_t)PACK_FLOATS * sizeof(float);
     const uint32_t nc = chunk_rays(N, tile_w);
     const size_t npad = (size_t)blocks_for(nc, tile_w) * 256u;
-    return (stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS + pair_region_floats(cfg)) * sizeof(float);
+    const uint64_t samples = (uint64_t)N * cfg->num_steps[cfg->num_stages ? cfg->num_stages - 1 : 0];
+    return (stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS + pair_region_floats(cfg, samples)) * sizeof(float);
 }
 
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
@@ -3302,7 +3330,13 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     SN_REQUIRE(io->workspace != nullptr, "render_rays: workspace is NULL");
     SN_REQUIRE(table_aligned(io->workspace), "render_rays: workspace must be 16-byte aligned");
     float *pack = reinterpret_cast<float *>(io->workspace);
-    const size_t pair_floats = pair_region_floats(cfg);
+    const uint64_t main_samples = (uint64_t)io->N * cfg->num_steps[S - 1];
+    const size_t pair_floats = pair_region_floats(cfg, main_samples);       // (as sn_rm_render_workspace_bytes sized it)
+    // will the last stage run as the plain linear-tail kernel?  Only that one has the instantiation that reads densified levels.
+    const bool plain_lt = mlp_mode == MLP_F16X3 && lt_enabled() && !rs_enabled() && !cfg->with_feat && !cfg->compact_live && !io->skip_final &&
+                          !(cfg->early_stop_eps > 0.0f && cfg->early_stop_eps < 1.0f) && dense_prefix(gl_main) == 5 &&
+                          !(io->bins[S - 1] || io->weights[S - 1] || io->sigmas[S - 1] || io->xyzs_last || io->geo_feat_last);
+    const int Kv_main = plain_lt ? densify_levels(gl_main, 5, main_samples, cfg->grid.table_dtype == SN_F16) : dense_prefix(gl_main);
     float *pair_mem = pack + PACK_FLOATS;
     float *scratch = pair_mem + pair_floats;
     const size_t head_floats = (size_t)PACK_FLOATS + pair_floats;
@@ -3323,11 +3357,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     PairTab prop_pairs[SN_MAX_STAGES];
     {
         float *cursor = pair_mem;
-        auto pack_pairs = [&](const sn_grid_desc *d, const GridLevels &gl, PairTab &pt) -> int {
+        auto pack_pairs = [&](const sn_grid_desc *d, const GridLevels &gl, PairTab &pt, int Kp, size_t fl) -> int {
             pt.base = nullptr;
             for (int l = 0; l < 8; ++l) pt.off[l] = 0;
-            const size_t fl = pair_floats_of(d);
-            const int Kp = dense_prefix(gl);
             if (fl == 0 || Kp <= 0) return SN_OK;
             pair_layout(gl, Kp, pt.off);
             pt.base = cursor;
@@ -3341,9 +3373,14 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             return SN_OK;
         };
         ProfScope ps(st, PK_PACK);
-        int rcp = pack_pairs(&cfg->grid, gl_main, pairs);
+        // (the main grid's region is sized for the densified layout whenever the sample count allows it; levels 5-6 are packed only
+        //  when the kernel that reads them will run)
+        int rcp = pack_pairs(&cfg->grid, gl_main, pairs, Kv_main, pair_floats_of(&cfg->grid, main_samples));
         if (rcp) return rcp;
-        for (uint32_t k = 0; k + 1 < S; ++k) { rcp = pack_pairs(&cfg->prop_grid[k], gl_prop[k], prop_pairs[k]); if (rcp) return rcp; }
+        for (uint32_t k = 0; k + 1 < S; ++k) {
+            rcp = pack_pairs(&cfg->prop_grid[k], gl_prop[k], prop_pairs[k], dense_prefix(gl_prop[k]), pair_floats_of(&cfg->prop_grid[k]));
+            if (rcp) return rcp;
+        }
     }
 
     // opt-in compaction: k_final_stage_cmp replaces the last stage when nothing per-sample leaves the call (those tensors
@@ -3544,7 +3581,20 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
                 hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, true>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
             } while (0)
-            if (l0) { if (aux) SN_LAUNCH_FINAL_LT_L0(true); else SN_LAUNCH_FINAL_LT_L0(false); }
+            FinalArgs fa7 = fa;
+            const bool dens = Kv_main == 7 && !aux && !l0 && !final_sp &&
+                              build_final_lv(gl_main, 7, pairs, cfg->grid.embeddings, 2u * (f16 ? 2u : 4u), fa7.lv);
+            if (dens) {     // levels 5 and 6 densified for this call (densify_levels)
+                const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
+                if (f16) {
+                    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                    hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), dim3(nblk), dim3(256), lds_bytes, st, fa7);
+                } else {
+                    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                    hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), dim3(nblk), dim3(256), lds_bytes, st, fa7);
+                }
+            }
+            else if (l0) { if (aux) SN_LAUNCH_FINAL_LT_L0(true); else SN_LAUNCH_FINAL_LT_L0(false); }
             else if (aux) { if (f16) SN_LAUNCH_FINAL_LT(__half, true); else SN_LAUNCH_FINAL_LT(float, true); }
             else { if (f16) SN_LAUNCH_FINAL_LT(__half, false); else SN_LAUNCH_FINAL_LT(float, false); }
 #undef SN_LAUNCH_FINAL_LT_L0

@@ -339,3 +339,34 @@ def test_lds_resident_level0_is_bit_identical(gpu, orc, monkeypatch):
                 b = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
                 for k in a:
                     assert torch.equal(a[k], b[k]), (steps, feat is not None, H, W, k)
+
+
+def test_densified_levels_are_bit_identical(gpu, orc, monkeypatch):
+    """SN_RENDER_DENSIFY (automatic for large fp16-table renders): the first two hashed levels of the main grid (102^3 and 148^3
+    vertices) are re-laid out per call as 16-byte pair / quad rows -- fetched through the hash once per vertex by the pack kernel --
+    and the final stage reads them like dense levels (4 / 2 coherent gathers instead of 8 scattered ones).  Same values, same
+    arithmetic: every output equals the hashed-lookup form bit for bit, both table precisions, tiled and linear lane mapping."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    monkeypatch.setenv("SN_FINAL_SP_MAX", "0")             # small linear batches would take the several-lanes-per-ray kernels
+    monkeypatch.setenv("SN_PROP_SP_MAX", "0")
+    for steps in ([128], [128, 64, 32], [7]):
+        params = synthetic_params(steps, seed=37)
+        model = product_model(params, steps, False, gpu)
+        for tdt in (torch.float32, torch.float16):
+            plan = rm.RenderPlan(model, steps, tdt)
+            for (H, W) in ((64, 64), (48, 80), (40, 24)):
+                intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
+                ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
+                for tile in (W, 0):
+                    monkeypatch.setenv("SN_RENDER_DENSIFY", "0")
+                    a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",), out={}).items()}
+                    monkeypatch.setenv("SN_RENDER_DENSIFY", "2")
+                    b = rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",), out={})
+                    for k in a:
+                        assert torch.equal(a[k], b[k]), (steps, tdt, H, W, tile, k)
+    # and against the oracle, with the switch forced on
+    _, _, ro, rd = camera_rays(orc, 32, 32)
+    got = rm.render_rays(rm.RenderPlan(model, [7], torch.float16), T(ro, gpu), T(rd, gpu), tile_w=32)
+    want = orc.render(oracle_cfg(orc, params, [7], table_f16=True), ro, rd)
+    np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)

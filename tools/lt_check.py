@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--hw", type=int, default=800)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--env", default="SN_RENDER_LT")
+ap.add_argument("--on", default="1", help="value of the switch for the B side (the A side is 0)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 pose = synth.orbit_pose(1.0, 20.0, 30.0)
@@ -28,7 +29,7 @@ for steps in ([128], [128, 64, 32], [7]):
             ro, rd = rm.generate_rays(pose, intr, H, W, device=dev)
             outs = {}
             for v in ("0", "1"):
-                os.environ[args.env] = v
+                os.environ[args.env] = "0" if v == "0" else args.on
                 o = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
                 torch.cuda.synchronize()
                 outs[v] = {k: t.clone() for k, t in o.items()}
@@ -47,7 +48,7 @@ for steps in ([128], [128, 64, 32]):
         plan = rm.RenderPlan(model, steps, tdt)
         res = {}
         for v in (0, 1, 0, 1):
-            os.environ[args.env] = str(v)
+            os.environ[args.env] = "0" if v == 0 else args.on
             out = {}
             for _ in range(5):
                 rm.render_rays(plan, ro, rd, tile_w=W, out=out)
