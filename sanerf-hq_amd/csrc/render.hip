@@ -3208,7 +3208,7 @@ int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
 // gathers instead of 8 scattered ones -- 12 fewer gather instructions per wave-sample of 98 -- at the price of a 69 MB pack per call
 // (~60 us), so only for renders with enough samples to pay for it.  Same values, same arithmetic: bit-identical.
 // SN_RENDER_DENSIFY: unset = automatic, 0 = never, 1 / 2 = force that many levels.
-constexpr uint64_t DENSIFY_MIN_SAMPLES = 40ull << 20;       // rays x samples of the last stage
+constexpr uint64_t DENSIFY_MIN_SAMPLES = 64ull << 20;       // rays x samples of the last stage (the 69 MB pack costs ~55 us more than the plain one and buys 1.6 % of the kernel: break-even near 45 M)
 constexpr uint64_t DENSIFY_MAX_VERTICES = 6ull << 20;       // 96 MB of 16-byte rows
 static int densify_levels(const GridLevels &g, int K, uint64_t samples, bool f16 = true) {
     if (K != 5 || g.L != 16 || g.C != 2) return K;           // (the K + 2 = 7 instantiation is built for the main grid's shape)

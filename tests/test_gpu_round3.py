@@ -370,3 +370,28 @@ def test_densified_levels_are_bit_identical(gpu, orc, monkeypatch):
     got = rm.render_rays(rm.RenderPlan(model, [7], torch.float16), T(ro, gpu), T(rd, gpu), tile_w=32)
     want = orc.render(oracle_cfg(orc, params, [7], table_f16=True), ro, rd)
     np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+
+
+def test_bench_line_schema():
+    """bench.py prints ONE JSON line with the contract's fields; roofline carries bound / achieved / peak / unit / frac / traffic for the
+    dominant kernel, the workload names BASELINE configs[1], the metric names the image rendered."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "rays/s" and d["higher_is_better"] is True
+    assert "800x800" in d["metric"] and "configs[1]" in d["config"]["workload"] and d["vs_baseline"] is None
+    assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "fabric_frac", "avg_kernel_ms", "shader_clock_mhz"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_rgb_diff_vs_gpu"] < 1e-4
+    assert d["also"] and "flat128_f32" in d["also"] and "ref_f16" in d["also"]
