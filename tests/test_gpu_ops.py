@@ -788,7 +788,8 @@ def test_collate_rays_draws_cameras_pixels_and_supervision_on_the_device(gpu):
     torch.manual_seed(0)
     M, H, W, S = 5, 48, 64, 16
     poses = torch.stack([torch.from_numpy(synth.orbit_pose(1.0 + 0.1 * k, 10.0 * k, 40.0 * k)) for k in range(M)]).to(gpu)
-    intr = torch.tensor([list(synth.pinhole_intrinsics(H, W))] * M, device=gpu)
+    fx0, fy0, cx0, cy0 = synth.pinhole_intrinsics(H, W)
+    intr = torch.tensor([[fx0 * (1 + 0.05 * k), fy0 * (1 + 0.03 * k), cx0 + k, cy0 - k] for k in range(M)], device=gpu)   # one camera model per image
     images = torch.randint(0, 256, (M, H, W, 3), dtype=torch.uint8, device=gpu)
     masks = torch.randint(0, 3, (M, H, W, 1), device=gpu)
     emap = torch.rand(M, S * S, device=gpu) + 0.01
@@ -809,6 +810,11 @@ def test_collate_rays_draws_cameras_pixels_and_supervision_on_the_device(gpu):
         assert torch.equal(res["cam_near_far"][:idx.numel()], cnf[idx])                 # [1, 2] in the single-image mode, like the reference
         assert res["rays_o"].shape == (n_total, 3) and res["masks"].shape[0] == n_total
         assert res["cam_near_far"].shape[0] == idx.numel() + (n_total - n_main)
+        # appended local patches: every ray is a ray of ITS image's own camera model (pose and intrinsics), i.e. one of that image's pixels
+        for r in range(n_main, n_total):
+            k = int(torch.nonzero((poses == res["poses"][r]).flatten(1).all(1))[0])
+            hit = (full[k][1] == res["rays_d"][r]).all(-1)
+            assert bool(hit.any()) and torch.equal(res["rays_o"][r], full[k][0][0]), (r, k)
 
     a = collate_rays(poses, intr, H, W, 512, images=images, masks=masks, error_map=emap, cam_near_far=cnf,
                      random_image_batch=True, error_map_size=S)

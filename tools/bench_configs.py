@@ -179,12 +179,12 @@ def main():
         o = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=False)
         torch.nn.functional.mse_loss(o["image"], gt).backward()
     out["RGB_training_step_4096_rays"]["fwd_bwd_without_proposal_update_ms"] = round(timeit(rgb_fwd_bwd_frozen_proposal) * 1e3, 3)
-    opt.lambda_distort = 0.02                                       # the reference's default loss: + distortion term
-    out["RGB_training_step_4096_rays"]["fwd_bwd_with_distort_loss_ms"] = round(timeit(rgb_fwd_bwd) * 1e3, 3)
-    opt.lambda_distort = 0.0
-    # a freshly constructed optimiser allocates its state in its first steps (and the first variant measured after the loss
-    # change above once showed 10+ ms): best of three measurements for each optimiser variant
+    # a changed loss graph / a freshly constructed optimiser allocates in its first steps (the first measurement after such a change
+    # has shown 10-17 ms): best of three measurements for each of these variants
     best = lambda fn: min(timeit(fn) for _ in range(3))            # noqa: E731
+    opt.lambda_distort = 0.02                                       # the reference's default loss: + distortion term
+    out["RGB_training_step_4096_rays"]["fwd_bwd_with_distort_loss_ms"] = round(best(rgb_fwd_bwd) * 1e3, 3)
+    opt.lambda_distort = 0.0
     optim = HipAdam(model.get_params(1e-2), eps=1e-15)             # csrc/optim.hip: one pass per tensor
     out["RGB_training_step_4096_rays"]["fwd_bwd_single_pass_adam_ms"] = round(best(rgb_step) * 1e3, 3)
     try:   # torch's single-kernel Adam (same update rule; the reference constructs the default multi-tensor one)
