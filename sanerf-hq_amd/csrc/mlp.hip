@@ -24,6 +24,7 @@
 #include "sn_common.h"
 #include <string.h>
 #include <type_traits>
+#include <utility>
 
 namespace sn {
 
@@ -111,7 +112,12 @@ __device__ int g_wide_overflow = 0;      // sticky: a k_mlp_wide launch produced
 #if SN_WIDE_TRACE
 __device__ unsigned long long g_wide_trace[256];
 __device__ __forceinline__ void wide_trace(uint32_t slot) {
+    // SN_WIDE_TRACE_MID: a workgroup from the middle of the launch (warm instruction cache, neighbours at work) instead of workgroup 0
+#if defined(SN_WIDE_TRACE_MID)
+    if (blockIdx.x == gridDim.x / 2u && threadIdx.x == 0 && slot < 256u) g_wide_trace[slot] = __builtin_readcyclecounter();
+#else
     if (blockIdx.x == 0 && threadIdx.x == 0 && slot < 256u) g_wide_trace[slot] = __builtin_readcyclecounter();
+#endif
 }
 #else
 __device__ __forceinline__ void wide_trace(uint32_t) {}
@@ -865,6 +871,649 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_mlp_wide_j -- the same computation with every operand made JUST IN TIME (round 3, second half).
+//
+// In k_mlp_wide one in-order wave per SIMD alternates between matrix work and vector work: after a layer's last k-step it
+// turns all 128 accumulators into the next layer's 128 B-operand registers (activation + fp16 hi/lo split, ~640 vector
+// instructions = 5300 cycles per layer change with the matrix pipe idle), an input k-step is read and split in front of its
+// 24 MFMAs, and the fused mask head interpolates a grid level (~300 vector instructions) in front of each of its first nine
+// k-steps (cycle trace: 4500 cycles per gather k-step against 768 of matrix-pipe time).  Here the only thing a layer's LAST
+// k-step does with a finished accumulator tile is move it, raw, into 128 ordinary registers (`prev`: 16 moves per tile, behind
+// the MFMAs of the following tiles), and the B operand of k-step k+1 -- activation + hi/lo split of eight of those values, or
+// eight input values, or a blended grid level -- is produced BETWEEN the MFMAs of k-step k: the vector work rides in the shadow of
+// the matrix pipe, and a layer starts from its bias through the C operand of each tile's first MFMA (no accumulator
+// initialisation).  The arithmetic per output is unchanged (same products, same order): results are bit-identical to k_mlp_wide.
+// (A first version kept two accumulator sets used by alternate layers; the register allocator answered the 256 live accumulators
+// with whole-set copies at every layer boundary: 9-10 thousand cycles per layer change, profiles/r03/ab_round3_experiments.txt.)
+// ------------------------------------------------------------------------------------------
+#ifndef SN_WIDE_JIT
+#define SN_WIDE_JIT 1        // host default: 1 = k_mlp_wide_j for the forward modes; env SN_WIDE_JIT=0/1 overrides at run time
+#endif
+#ifndef SN_WIDE_REFILL_LATE
+#define SN_WIDE_REFILL_LATE 0 // where the four DMA pieces of chunk g+4 are issued: 0 = right after the barrier (tile 6), 1 = behind the last tile's MFMAs,
+#endif                        // 2 = one between / two behind the three MFMAs of the last tile.  Measured per h k-step: 1110 / 1160 / 1260 cycles
+#ifndef SN_WIDE_JV
+#define SN_WIDE_JV 8         // vector instructions the scheduler may place behind each MFMA of a tile
+#endif
+
+template <bool B> struct bool_tag { static constexpr bool value = B; };
+template <int N> struct int_tag { static constexpr int value = N; };
+// compile-time loop: f(int_tag<0>{}) ... f(int_tag<N-1>{}).  (`#pragma unroll` is a request: the 16 k-steps of a layer came back as a
+// loop unrolled by 8 with a run-time index into `prev`, which put the array in scratch memory.)
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(int_tag<Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int XMODE>
+__global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
+    static_assert(XMODE >= 0 && XMODE <= 3, "the backward mode keeps k_mlp_wide");
+    extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];        // WIDE_NBUF x WIDE_CHUNK_U4, then floats
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t half = lane >> 5;
+    const uint32_t n = blockIdx.x * WIDE_ROWS + wave * 32u + (lane & 31u);
+    const bool ok = n < a.N;
+    const float *xrow = a.x + (size_t)(ok ? n : 0u) * a.din;
+    float *lds_bias = reinterpret_cast<float *>(lds_w + WIDE_NBUF * WIDE_CHUNK_U4);      // [nl][WIDE], zero where absent
+    float *lds_x = lds_bias + SN_MAX_LAYERS * WIDE;                               // [128][xs]
+    const uint32_t xs = a.xs;
+    for (uint32_t i = tid; i < a.nl * (uint32_t)WIDE; i += 256u) {
+        const uint32_t l = i / (uint32_t)WIDE, m = i % (uint32_t)WIDE;
+        const float *b = a.bias[l];
+        lds_bias[i] = (b != nullptr && m < a.layer[l].out) ? b[m] : 0.0f;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    if constexpr (XMODE == 2) {          // see k_mlp_wide
+        const uint32_t tile_bytes = (uint32_t)WIDE_ROWS * a.din * 4u;
+        const uint64_t arr_bytes = (uint64_t)a.N * a.din * 4u;
+        const uint64_t tile0 = (uint64_t)blockIdx.x * tile_bytes;
+        const uint32_t lds_x_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_x);
+        for (uint32_t piece = wave; piece * 1024u < tile_bytes; piece += 4u) {
+            uint64_t off = tile0 + (uint64_t)piece * 1024u + lane * 16u;
+            off = off + 16u <= arr_bytes ? off : arr_bytes - 16u;
+            dma16(reinterpret_cast<const char *>(a.x) + off, lds_x_off + piece * 1024u);
+        }
+    }
+    if constexpr (XMODE == 1) {
+        const uint32_t row0 = blockIdx.x * WIDE_ROWS + wave * 32u;
+        for (uint32_t c = lane; c < xs; c += 64u) {
+#pragma unroll
+            for (uint32_t rb = 0; rb < 32u; rb += 8u) {
+                float t[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const uint32_t r = row0 + rb + k;
+                    const uint32_t rr = r < a.N ? r : a.N - 1u, cc = c < a.din ? c : a.din - 1u;
+                    const float v = a.x[(size_t)rr * a.din + cc];
+                    t[k] = (r < a.N && c < a.din) ? v : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) lds_x[(wave * 32u + rb + k) * xs + c] = t[k];
+            }
+        }
+        if (tid < 32u) lds_x[(uint32_t)WIDE_ROWS * xs + tid] = 0.0f;
+    }
+    uint32_t *lds_lv = reinterpret_cast<uint32_t *>(lds_x);             // XMODE 3: [4][SN_MAX_LEVELS]: res, size, mode, off
+    float x01[3] = {0.0f, 0.0f, 0.0f};
+    bool x_oob = false;
+    float ev[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // XMODE 3: this lane's 8 appended channels (one load per row, up front)
+    if constexpr (XMODE == 3) {
+        if (tid < (uint32_t)SN_MAX_LEVELS) {
+            lds_lv[tid] = a.g.res[tid]; lds_lv[SN_MAX_LEVELS + tid] = a.g.size[tid];
+            lds_lv[2 * SN_MAX_LEVELS + tid] = a.g.mode[tid]; lds_lv[3 * SN_MAX_LEVELS + tid] = a.g.off[tid];
+        }
+        const float *p = a.xyz + (size_t)(ok ? n : a.N - 1u) * 3u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {   // grid.py:156
+            const float t = p[d] + a.bound;
+            x01[d] = a.inv_den != 0.0f ? t * a.inv_den : t / (2.0f * a.bound);
+            x_oob = x_oob || x01[d] < 0.0f || x01[d] > 1.0f;                // gridencoder.cu:105-130: zeros outside [0,1]
+        }
+        if (a.E) {
+            const float *row = a.extra + (size_t)(ok ? n : a.N - 1u) * a.E;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t c = 8u * half + i;
+                const float t = row[c < a.E ? c : a.E - 1u];
+                ev[i] = c < a.E ? t : 0.0f;
+            }
+        }
+    }
+
+    floatx16 acc[WIDE_MT];
+    float prev[16 * WIDE_MT];              // the previous layer's outputs before the activation: prev[16 t + r] = register r of its tile t
+    uint32_t g = 0;                        // chunks consumed so far
+    const uint32_t total_chunks = a.total_chunks;
+    const uint32_t lds_w_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_w) + wave * 1024u;
+    constexpr uint32_t CHUNK_BYTES = WIDE_CHUNK_U4 * sizeof(uint4);
+    constexpr int PIECES = WIDE_CHUNK_U4 / 256;
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)WIDE_NBUF - 1u; ++c) {
+        if (c < total_chunks) {
+            const uint4 *src = a.pack + (size_t)c * WIDE_CHUNK_U4 + tid;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(src + i * 256, lds_w_off + c * CHUNK_BYTES + (uint32_t)i * 4096u);
+        }
+    }
+    if constexpr (XMODE == 2) {          // the input tile's pieces were issued first and the counter retires in order (k_mlp_wide)
+        if (total_chunks >= (uint32_t)WIDE_NBUF - 1u) asm volatile("s_waitcnt vmcnt(12)" : : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        static_assert(PIECES * (WIDE_NBUF - 1) == 12, "vmcnt immediate = weight pieces in flight");
+    }
+    __syncthreads();                       // publishes lds_bias / lds_x / lds_lv
+
+    // ---- weight ring: as k_mlp_wide (SN_WIDE_PIPE form).  `EXTRA` = loads of this wave that were issued after the DMA pieces of
+    //      chunk gn and may stay in flight across the wait (the 16 grid gathers of the fused mask head): the counter retires
+    //      in order, so they are simply allowed for in the immediate ----
+    uint4 pah[2], pal[2];
+    auto sync_and_prefetch = [&](uint32_t gn, auto extra_tag) {
+        constexpr int EXTRA = decltype(extra_tag)::value;
+        static_assert(EXTRA == 0 || EXTRA == 16, "vmcnt immediates are spelled out below");
+        const uint32_t later = total_chunks - 1u - gn;
+        if constexpr (EXTRA == 0) {
+            if (later >= 2u) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : : : "memory");
+            else if (later == 1u) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
+        } else {
+            if (later >= 2u) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" : : : "memory");
+            else if (later == 1u) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" : : : "memory");
+            else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" : : : "memory");
+        }
+        static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
+#if !(SN_WIDE_ABLATE & 1)
+        __syncthreads();
+#endif
+#if SN_WIDE_REFILL_LATE == 0
+        if (gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
+            const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+            const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+        }
+#endif
+    };
+    // refill the buffer chunk gn-1 was read from (every wave passed the barrier above after its last read of it) with chunk gn+3.
+    // Issued BEHIND the last tile's MFMAs: the four pieces cost ~100 cycles of address / m0 set-up that used to sit between two tiles
+    auto refill_piece = [&](uint32_t gn, int i) {
+        const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+        const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+        dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+    };
+    auto refill = [&](uint32_t gn) {
+        if (SN_WIDE_REFILL_LATE == 1 && gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
+            const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+            const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+        }
+    };
+    auto prefetch_first_pair = [&](uint32_t gn) {
+        const uint4 *buf = lds_w + (gn % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        pah[0] = buf[0]; pal[0] = buf[64]; pah[1] = buf[128]; pal[1] = buf[192];
+    };
+    sync_and_prefetch(0u, int_tag<0>{});
+    refill(0u);
+    if (SN_WIDE_REFILL_LATE == 2 && 3u < total_chunks) { refill_piece(0u, 0); refill_piece(0u, 1); refill_piece(0u, 2); refill_piece(0u, 3); }
+    prefetch_first_pair(0u);
+
+    const float act_slope = a.leaky ? 0.01f : 0.0f;
+    auto act = [&](float t) { return __builtin_fmaxf(t, t * act_slope); };   // k_mlp_wide: multiply + max (network.py:65-66)
+    auto bias_tile = [&](uint32_t l, int mt, floatx16 &b) {      // register r of this lane = neuron 32 mt + (r&3) + 8 (r>>2) + 4 half
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(lds_bias + l * (uint32_t)WIDE + 32u * mt + 8u * q + 4u * half);
+            b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+        }
+    };
+
+    // one chunk = one k-step x 8 output tiles.  FIRST: the layer's first k-step -- the accumulators start from the bias, handed to each
+    // tile's first MFMA as its C operand.  prep(mt): the mt-th piece of whatever makes the NEXT k-step's B operand; it is emitted
+    // inside tile mt's scheduling region and dealt out behind that tile's MFMAs.
+    // ESC: the layer's last k-step -- finished tiles leave the accumulators for `prev` two tiles behind the matrix pipe (tiles 6 and 7 in
+    // the next layer's FIRST chunk, before it overwrites them).  The empty asm makes the moved value opaque: without it the compiler keeps
+    // reading the accumulator itself, whose life then overlaps the next layer's.
+    auto escape_tile = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; float v = acc[t][r]; asm("" : "+v"(v)); prev[16 * t + r] = v; });
+    };
+    auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
+        constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
+        wide_trace(g);
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        const half8_t Bh = __builtin_bit_cast(half8_t, make_uint4(ob_h[0], ob_h[1], ob_h[2], ob_h[3]));
+        const half8_t Bl = __builtin_bit_cast(half8_t, make_uint4(ob_l[0], ob_l[1], ob_l[2], ob_l[3]));
+        uint4 ah[2], al[2];
+        ah[0] = pah[0]; al[0] = pal[0]; ah[1] = pah[1]; al[1] = pal[1];
+        floatx16 bias[2];
+        if constexpr (FIRST) { bias_tile(l, 0, bias[0]); bias_tile(l, 1, bias[1]); }
+        static_for<WIDE_MT>([&](auto mtc) {
+            constexpr int mt = decltype(mtc)::value, cur = mt & 1;
+            const half8_t Ah = __builtin_bit_cast(half8_t, ah[cur]), Al = __builtin_bit_cast(half8_t, al[cur]);
+            floatx16 c;
+            if constexpr (FIRST) c = bias[cur]; else c = acc[mt];
+            if constexpr (mt + 1 == WIDE_MT && SN_WIDE_REFILL_LATE == 2) {
+                const bool more = g + 4u < total_chunks && !(SN_WIDE_ABLATE & 2);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) refill_piece(g + 1u, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) refill_piece(g + 1u, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { refill_piece(g + 1u, 2); refill_piece(g + 1u, 3); }
+            } else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);   // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
+            }
+            acc[mt] = c;
+            if constexpr (mt + 2 < WIDE_MT) {
+                if (!(SN_WIDE_ABLATE & 4)) { ah[cur] = buf[(mt + 2) * 128]; al[cur] = buf[(mt + 2) * 128 + 64]; }   // ablation 4: no weight reads from LDS (wrong results)
+                if constexpr (FIRST) bias_tile(l, mt + 2, bias[cur]);
+            } else if constexpr (mt + 2 == WIDE_MT) {
+                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u, extra_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch_first_pair(g + 1u);
+            }
+            if constexpr (FIRST && mt < 2) escape_tile(int_tag<6 + mt>{});
+            if constexpr (ESC && mt >= 2) escape_tile(int_tag<mt - 2>{});
+            prep(mtc);
+            if constexpr (mt + 2 == WIDE_MT) {       // the tile's MFMAs were fenced in front of the synchronisation; what follows rides on tile 7
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, FIRST ? 3 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, FIRST ? 3 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (g + 1u < total_chunks) refill(g + 1u);
+        ++g;
+    };
+
+    // ---- operand makers ----
+    auto h_piece = [&](auto kc, auto pc, uint32_t (&nbh)[4], uint32_t (&nbl)[4]) {      // pair p (0..3) of h k-step k
+        constexpr int k = decltype(kc)::value, p = decltype(pc)::value;
+        split2h(act(prev[8 * k + 2 * p]), act(prev[8 * k + 2 * p + 1]), nbh[p], nbl[p]);
+    };
+    // x[n][16 kx + 8 half + 0..7], zero padded (XMODE 0..2)
+    auto x_values = [&](uint32_t kx, float (&v)[8]) {
+        const uint32_t c0 = 16u * kx + 8u * half;
+        if constexpr (XMODE == 2) {
+            const float *row = lds_x + (wave * 32u + (lane & 31u)) * a.din + c0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) { const float t = row[i]; v[i] = c0 + i < a.din ? t : 0.0f; }
+        } else if constexpr (XMODE == 1) {
+            const float4 p = *reinterpret_cast<const float4 *>(lds_x + (wave * 32u + (lane & 31u)) * xs + c0);
+            const float4 q = *reinterpret_cast<const float4 *>(lds_x + (wave * 32u + (lane & 31u)) * xs + c0 + 4u);
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) v[i] = c0 + i < a.din ? v[i] : 0.0f;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t c = c0 + i;
+                const float t = xrow[c < a.din ? c : a.din - 1u];
+                v[i] = (ok && c < a.din) ? t : 0.0f;
+            }
+        }
+    };
+    // operand = input k-step kxn: loads at tile 0, split in tiles 2..5
+    float xv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto prep_x = [&](auto mtc, uint32_t kxn, uint32_t (&nbh)[4], uint32_t (&nbl)[4]) {
+        constexpr int mt = decltype(mtc)::value;
+        if constexpr (XMODE != 3 && mt == 0) x_values(kxn, xv);
+        if constexpr (mt >= 2 && mt < 6) split2h(xv[2 * (mt - 2)], xv[2 * (mt - 2) + 1], nbh[mt - 2], nbl[mt - 2]);
+    };
+    // operand = the next layer's first h k-step, from tile 0 as escaped at tile 2 of an ESC chunk
+    auto prep_h0 = [&](auto mtc, uint32_t (&nbh)[4], uint32_t (&nbl)[4]) {
+        constexpr int mt = decltype(mtc)::value;
+        if constexpr (mt >= 2 && mt < 6) h_piece(int_tag<0>{}, int_tag<mt - 2>{}, nbh, nbl);
+    };
+    // the last h k-step of a layer is followed EITHER by input k-step 0 (skip layers) OR by the next layer: both operands are formed and a
+    // wave-uniform select picks (no branch inside a chunk: one scheduling region per tile)
+    auto prep_sel = [&](auto mtc, bool use_x, uint32_t (&nbh)[4], uint32_t (&nbl)[4]) {
+        constexpr int mt = decltype(mtc)::value;
+        if constexpr (XMODE != 3 && mt == 0) x_values(0u, xv);
+        if constexpr (mt >= 2 && mt < 6) {
+            constexpr int p = mt - 2;
+            const float h0 = act(prev[2 * p]), h1 = act(prev[2 * p + 1]);
+            split2h(use_x ? xv[2 * p] : h0, use_x ? xv[2 * p + 1] : h1, nbh[p], nbl[p]);
+        }
+    };
+
+    // XMODE 3: k-step kx of the input = levels 2 kx (low half-wave) and 2 kx + 1 (high half-wave) of the C = 8 grid; every lane
+    // interpolates ONE level of its own sample (k_mlp_wide).
+    struct LevelRegs { float pos[3]; float cv[8][8]; };
+    auto issue_corners = [&](uint32_t kx, LevelRegs &r, int first, int last, uint32_t (&cell)[3], uint32_t &res, uint32_t &size, uint32_t &mode, const float *&tab) {
+        if (first == 0) {
+            const uint32_t level = umin(2u * kx + half, a.g.L - 1u);
+            res = lds_lv[level]; size = lds_lv[SN_MAX_LEVELS + level]; mode = lds_lv[2 * SN_MAX_LEVELS + level];
+            tab = a.table + (size_t)lds_lv[3 * SN_MAX_LEVELS + level] * 8u;
+            float deriv[3];
+            grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, r.pos, deriv, cell);
+        }
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+            if (idx < first || idx >= last) continue;
+            uint32_t p[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3u; ++d) p[d] = ((uint32_t)idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
+            load_row<float, 8>(tab + (size_t)grid_row<3>(p, res, size, mode) * 8u, r.cv[idx]);
+        }
+    };
+    auto blend_corners = [&](const LevelRegs &r, int first, int last, float (&v)[8]) {
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+            if (idx < first || idx >= last) continue;
+            float w = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3u; ++d) w *= ((uint32_t)idx & (1u << d)) ? r.pos[d] : 1.0f - r.pos[d];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = __builtin_fmaf(w, r.cv[idx][c], idx == 0 ? 0.0f : v[c]);
+        }
+    };
+
+    uint32_t bh[4], bl[4], nbh[4] = {0u, 0u, 0u, 0u}, nbl[4] = {0u, 0u, 0u, 0u};   // operand of the chunk about to run / of the one after it
+    const uint32_t nl = a.nl;
+
+    // ---- layer 0: input k-steps only; accumulators start from the bias the plain way (once per workgroup) ----
+    {
+        const WideLayer L = a.layer[0];
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt) bias_tile(0u, mt, acc[mt]);
+        wide_trace(128u);
+        if constexpr (XMODE == 3) {
+            const uint32_t gks = (a.g.L + 1u) >> 1;                       // k-steps that carry grid levels; one more for the appended channels
+            const uint32_t K = gks + (a.E ? 1u : 0u);
+            LevelRegs S;
+            uint32_t cell[3], res, size, mode; const float *tab;
+            issue_corners(0u, S, 0, 8, cell, res, size, mode, tab);
+            {
+                float v[8];
+                blend_corners(S, 0, 8, v);
+                const bool zero = x_oob || half >= a.g.L;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) split2h(zero ? 0.0f : v[2 * p], zero ? 0.0f : v[2 * p + 1], bh[p], bl[p]);
+            }
+            issue_corners(1u, S, 0, 8, cell, res, size, mode, tab);
+            float bv[8];
+            // chunk c < K-1: blend k-step c+1 (requested during chunk c-1) behind tiles 0..2, request the rows of k-step c+2 into the same
+            // registers behind tiles 3..4 (the k-step after the last level one is the appended channels); the last chunk is peeled: it hands
+            // the layer over.  One register set: the texture path, not the latency of one wave, bounds these k-steps (4 waves share it)
+            for (uint32_t c = 0; c + 1u < K; ++c) {
+                const bool lev = c + 1u < gks;
+                chunk8(bool_tag<false>{}, bool_tag<false>{}, int_tag<16>{}, 0u, bh, bl, [&](auto mtc) {
+                    constexpr int mt = decltype(mtc)::value;
+                    if constexpr (mt == 0) blend_corners(S, 0, 3, bv);
+                    if constexpr (mt == 1) blend_corners(S, 3, 6, bv);
+                    if constexpr (mt == 2) blend_corners(S, 6, 8, bv);
+                    if constexpr (mt == 3) issue_corners(c + 2u, S, 0, 4, cell, res, size, mode, tab);
+                    if constexpr (mt == 4) issue_corners(c + 2u, S, 4, 8, cell, res, size, mode, tab);
+                    if constexpr (mt == 5) {
+                        const bool zero = x_oob || 2u * (c + 1u) + half >= a.g.L;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const float l0 = zero ? 0.0f : bv[2 * p], l1 = zero ? 0.0f : bv[2 * p + 1];
+                            split2h(lev ? l0 : ev[2 * p], lev ? l1 : ev[2 * p + 1], nbh[p], nbl[p]);
+                        }
+                    }
+                });
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+            }
+            chunk8(bool_tag<false>{}, bool_tag<true>{}, int_tag<16>{}, 0u, bh, bl, [&](auto mtc) { prep_h0(mtc, nbh, nbl); });
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+        } else {
+            {
+                float v[8];
+                x_values(0u, v);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) split2h(v[2 * p], v[2 * p + 1], bh[p], bl[p]);
+            }
+            for (uint32_t k = 0; k + 1u < L.x_ks; ++k) {
+                chunk8(bool_tag<false>{}, bool_tag<false>{}, int_tag<0>{}, 0u, bh, bl, [&](auto mtc) { prep_x(mtc, k + 1u, nbh, nbl); });
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+            }
+            chunk8(bool_tag<false>{}, bool_tag<true>{}, int_tag<0>{}, 0u, bh, bl, [&](auto mtc) { prep_h0(mtc, nbh, nbl); });
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+        }
+    }
+
+    // ---- layers 1 .. nl-1 ----
+    for (uint32_t l = 1; l < nl; ++l) {
+        const WideLayer L = a.layer[l];
+        wide_trace(128u + l);
+        if (L.narrow) {
+            // last layer with <= 64 outputs: 4 chunks of 4 k-steps x 1 tile pair (k_pack_mlp_wide); the operand of k-step k+1 is split
+            // between the six MFMAs of k-step k.  Tiles 6 and 7 of the previous layer leave the accumulators first.
+            escape_tile(int_tag<6>{}); escape_tile(int_tag<7>{});
+            floatx16 c0, c1;
+            bias_tile(l, 0, c0); bias_tile(l, 1, c1);
+            static_for<WIDE_HKS / 4>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                wide_trace(g);
+                const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+                uint4 ah[2][2], al[2][2];
+                ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
+                static_for<4>([&](auto slc) {
+                    constexpr int sl = decltype(slc)::value, k = 4 * c + sl, cb = sl & 1, nb = cb ^ 1;
+                    if constexpr (sl < 3) {
+                        ah[nb][0] = buf[(sl + 1) * 256]; al[nb][0] = buf[(sl + 1) * 256 + 64];
+                        ah[nb][1] = buf[(sl + 1) * 256 + 128]; al[nb][1] = buf[(sl + 1) * 256 + 192];
+                    } else {
+                        if (g + 1u < total_chunks) sync_and_prefetch(g + 1u, int_tag<0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        prefetch_first_pair(g + 1u);
+                    }
+                    const half8_t A0h = __builtin_bit_cast(half8_t, ah[cb][0]), A0l = __builtin_bit_cast(half8_t, al[cb][0]);
+                    const half8_t A1h = __builtin_bit_cast(half8_t, ah[cb][1]), A1l = __builtin_bit_cast(half8_t, al[cb][1]);
+                    const half8_t Bh = __builtin_bit_cast(half8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const half8_t Bl = __builtin_bit_cast(half8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+                    if constexpr (k + 1 < WIDE_HKS) static_for<4>([&](auto pc) { h_piece(int_tag<k + 1>{}, pc, nbh, nbl); });
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+                });
+                if (g + 1u < total_chunks) refill(g + 1u);
+                if (SN_WIDE_REFILL_LATE == 2 && g + 4u < total_chunks) { refill_piece(g + 1u, 0); refill_piece(g + 1u, 1); refill_piece(g + 1u, 2); refill_piece(g + 1u, 3); }
+                ++g;
+            });
+            acc[0] = c0; acc[1] = c1;
+        } else {
+            const bool has_x = L.x_ks != 0u;
+            static_for<WIDE_HKS>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                auto prep_next_h = [&](auto mtc) {
+                    constexpr int mt = decltype(mtc)::value;
+                    if constexpr (mt >= 2 && mt < 6) h_piece(int_tag<k + 1>{}, int_tag<mt - 2>{}, nbh, nbl);
+                };
+                if constexpr (k == 0) chunk8(bool_tag<true>{}, bool_tag<false>{}, int_tag<0>{}, l, bh, bl, prep_next_h);
+                else if constexpr (k + 1 < WIDE_HKS) chunk8(bool_tag<false>{}, bool_tag<false>{}, int_tag<0>{}, l, bh, bl, prep_next_h);
+                else chunk8(bool_tag<false>{}, bool_tag<true>{}, int_tag<0>{}, l, bh, bl, [&](auto mtc) { prep_sel(mtc, has_x, nbh, nbl); });
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+            });
+            if (has_x) {
+                for (uint32_t k = 0; k + 1u < L.x_ks; ++k) {
+                    chunk8(bool_tag<false>{}, bool_tag<false>{}, int_tag<0>{}, l, bh, bl, [&](auto mtc) { prep_x(mtc, k + 1u, nbh, nbl); });
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+                }
+                chunk8(bool_tag<false>{}, bool_tag<true>{}, int_tag<0>{}, l, bh, bl, [&](auto mtc) { prep_h0(mtc, nbh, nbl); });
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
+            }
+        }
+    }
+
+    // ---- epilogue (k_mlp_wide's) ----
+    const WideLayer LL = a.layer[a.nl - 1u];
+    {   // range check of the split-fp16 arithmetic: an activation beyond 65504 turned into inf in a hi half and reaches
+        // the last layer as inf / NaN.  0 * x is NaN exactly for those.  Sticky flag, read by sn_mlp_wide_overflow().
+        float chk = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(acc[mt][r], 0.0f, chk);
+        if (ok && chk != chk) g_wide_overflow = 1;
+    }
+    wide_trace(160u);                      // all layers done; what follows is the output epilogue
+    if constexpr (XMODE == 3) {
+        // renderer.py:384: out[ray, m] = sum_t w[ray, t] * logits[ray, t, m].  Rows are samples in [ray][t] order and T divides
+        // 128 or is a multiple of 32 that divides 128 (checked on the host): a ray's samples sit in T consecutive lanes of one
+        // half-wave image (T <= 32) or in T / 32 whole waves of this workgroup.  Fixed reduction tree: deterministic.
+        const float w = ok ? a.wts[n] : 0.0f;
+        const uint32_t Tl = a.T < 32u ? a.T : 32u;                        // lanes (rows) of one wave that share a ray
+        float sum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = w * acc[0][r];
+#pragma unroll
+            for (uint32_t d = 1; d < 32u; d <<= 1) { const float o = __shfl_xor(t, (int)d, 32); t = d < Tl ? t + o : t; }
+            sum[r] = t;
+        }
+        const uint32_t j = lane & 31u;
+        float *part = reinterpret_cast<float *>(lds_w);                  // [4 waves][32 neurons]: the weight ring is dead
+        if (a.T > 32u) {
+            __syncthreads();
+            if (j == 0u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[wave * 32u + (r & 3) + 8u * (r >> 2) + 4u * half] = sum[r];
+            }
+            __syncthreads();
+            const uint32_t wpr = a.T >> 5;                                // waves per ray: 2 or 4
+            if (j == 0u && (wave % wpr) == 0u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = (r & 3) + 8u * (r >> 2) + 4u * half;
+                    float t = sum[r];
+                    for (uint32_t q = 1; q < wpr; ++q) t += part[(wave + q) * 32u + m];
+                    sum[r] = t;
+                }
+            }
+            if ((wave % wpr) != 0u) return;
+        }
+        if (ok && (j % Tl) == 0u) {
+            float *orow = a.out + (size_t)(n / a.T) * LL.out;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = (r & 3) + 8u * (r >> 2) + 4u * half;
+                if (m < LL.out) orow[m] = sum[r];
+            }
+        }
+        return;
+    }
+    float mean = 0.0f, rstd = 1.0f;
+    if (a.ln_w) {
+        float s = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = 32u * mt + (r & 3) + 8u * (r >> 2) + 4u * half;
+                s += m < LL.out ? acc[mt][r] : 0.0f;
+            }
+        s += __shfl_xor(s, 32);
+        mean = s / (float)LL.out;
+        float q = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = 32u * mt + (r & 3) + 8u * (r >> 2) + 4u * half;
+                const float d = acc[mt][r] - mean;
+                q += m < LL.out ? d * d : 0.0f;
+            }
+        q += __shfl_xor(q, 32);
+        rstd = 1.0f / sqrtf(q / (float)LL.out + a.ln_eps);
+    }
+    if (a.out_lds) {
+        // full-width output through LDS (the weight ring and the input tile are dead): a wave parks its 32 rows x 256
+        // outputs, then writes whole rows -- 1 KiB per store instruction instead of 64 scattered 16-byte pieces
+        constexpr uint32_t RS = WIDE + 4;                                 // row stride in floats (16-byte aligned, conflict-free)
+        __syncthreads();
+        float *reg = reinterpret_cast<float *>(lds_w) + wave * (32u * RS + 64u);
+        float *stat = reg + 32u * RS;                                     // [32][2] mean, rstd
+        const uint32_t r = lane & 31u;
+#pragma unroll
+        for (int mt = 0; mt < WIDE_MT; ++mt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                *reinterpret_cast<float4 *>(reg + r * RS + 32u * mt + 8u * qd + 4u * half) =
+                    make_float4(acc[mt][4 * qd], acc[mt][4 * qd + 1], acc[mt][4 * qd + 2], acc[mt][4 * qd + 3]);
+        if (half == 0u) { stat[2u * r] = mean; stat[2u * r + 1u] = rstd; }
+        float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.ln_w) { w4 = reinterpret_cast<const float4 *>(a.ln_w)[lane]; b4 = reinterpret_cast<const float4 *>(a.ln_b)[lane]; }
+        const uint32_t row0 = blockIdx.x * WIDE_ROWS + wave * 32u;
+#pragma unroll 8
+        for (uint32_t i = 0; i < 32u; ++i) {
+            if (row0 + i >= a.N) break;
+            float4 v = *reinterpret_cast<const float4 *>(reg + i * RS + lane * 4u);
+            const float mu = stat[2u * i], rs = stat[2u * i + 1u];
+            v.x = (v.x - mu) * rs * w4.x + b4.x; v.y = (v.y - mu) * rs * w4.y + b4.y;
+            v.z = (v.z - mu) * rs * w4.z + b4.z; v.w = (v.w - mu) * rs * w4.w + b4.w;
+            reinterpret_cast<float4 *>(a.out + (size_t)(row0 + i) * WIDE)[lane] = v;
+        }
+        return;
+    }
+    if (!ok) return;
+    float *orow = a.out + (size_t)n * LL.out;
+#pragma unroll
+    for (int mt = 0; mt < WIDE_MT; ++mt) {
+        if ((uint32_t)mt >= LL.mt) break;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const uint32_t m0 = 32u * mt + 8u * qd + 4u * half;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = acc[mt][4 * qd + i];
+                if (a.ln_w) {              // wave-uniform; index clamped so that the loads need no per-lane branch
+                    const uint32_t mi = m0 + i < LL.out ? m0 + i : LL.out - 1u;
+                    t = (t - mean) * rstd * a.ln_w[mi] + a.ln_b[mi];
+                }
+                v[i] = t;
+            }
+            if ((LL.out & 3u) == 0u && m0 + 3u < LL.out) {
+                *reinterpret_cast<float4 *>(orow + m0) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (m0 + i < LL.out) orow[m0 + i] = v[i];
+            }
+        }
+    }
+}
+
+// Which forward kernel: SN_WIDE_JIT=0 -> k_mlp_wide everywhere, =1 -> k_mlp_wide_j everywhere (same-library A/B; read on every call).
+// Unset: k_mlp_wide_j for the plain MLP modes (SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms), k_mlp_wide for the fused
+// mask head, whose first layer is bound by the texture path rather than by the vector work the new kernel hides (7.45 vs 7.55 ms).
+static bool wide_jit(int xmode) {
+    const char *e = getenv("SN_WIDE_JIT");
+    if (e) return atoi(e) != 0;
+    return SN_WIDE_JIT != 0 && xmode != 3;
+}
+
 static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) {
     SN_REQUIRE(m->num_layers >= 1 && m->num_layers <= SN_MAX_LAYERS, "mlp_wide: num_layers=%u outside 1..%d", m->num_layers, SN_MAX_LAYERS);
     SN_REQUIRE(m->activation <= 1u, "mlp_wide: activation must be 0 (relu) or 1 (leaky_relu 0.01)");
@@ -973,8 +1622,13 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     wa.xs = xs;
 #define SN_MLP_LAUNCH(MODE)                                                                                           \
     do {                                                                                                              \
-        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_mlp_wide<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);                     \
+        if (wide_jit(MODE)) {                                                                                         \
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k_mlp_wide_j<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);               \
+        } else {                                                                                                      \
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k_mlp_wide<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);                 \
+        }                                                                                                             \
     } while (0)
     if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
 #undef SN_MLP_LAUNCH
@@ -1112,8 +1766,13 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     rc = build_grid_levels(&wa.g, grid->offsets, grid->D, grid->C, grid->L, grid->S, grid->H, grid->gridtype, (int)grid->align_corners, grid->interp);
     if (rc) return rc;
     const size_t lds = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 4u * SN_MAX_LEVELS * sizeof(uint32_t);
-    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_mlp_wide<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);
+    if (wide_jit(3)) {
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mlp_wide_j<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);
+    } else {
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mlp_wide<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);
+    }
     SN_LAUNCH_CHECK("k_mlp_wide<3>");
     return SN_OK;
 }

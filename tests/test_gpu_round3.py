@@ -395,3 +395,52 @@ def test_bench_line_schema():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_rgb_diff_vs_gpu"] < 1e-4
     assert d["also"] and "flat128_f32" in d["also"] and "ref_f16" in d["also"]
+
+
+@pytest.mark.parametrize("din,dout,nlayers,skip,bias,ln,N", [
+    (163, 256, 5, [2], True, True, 1000),     # SAM head MLP: LDS-DMA input tile, skip layer, LayerNorm, rows not a multiple of 128
+    (143, 2, 3, [], False, False, 777),       # mask MLP: narrow last layer
+    (143, 40, 3, [], False, False, 128 * 3),  # narrow last layer with two output tiles
+    (64, 200, 2, [], True, False, 130),       # even input width (padded LDS tile), partial last output tile
+    (700, 256, 4, [1, 2], True, False, 259),  # input too wide for LDS (read per k-step), two skip layers
+    (17, 7, 1, [], True, False, 5),           # a single layer
+])
+def test_wide_mlp_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, din, dout, nlayers, skip, bias, ln, N):
+    """k_mlp_wide_j (operands made between the MFMAs of the previous k-step, layers handed over through `prev`) computes every
+    output with the same products in the same order as k_mlp_wide: the two kernels must agree bit for bit in every input mode."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(din + dout)
+    mlp = SkipConnMLP(din, dout, 256, nlayers, skip_layers=skip, bias=bias).to(gpu)
+    norm = torch.nn.LayerNorm(dout).to(gpu) if ln else None
+    x = torch.randn(N, din, device=gpu)
+    monkeypatch.setenv("SN_WIDE_JIT", "0")
+    a = rm.mlp_forward(x, mlp, norm)
+    monkeypatch.setenv("SN_WIDE_JIT", "1")
+    b = rm.mlp_forward(x, mlp, norm)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    with torch.no_grad():
+        ref = mlp(x) if norm is None else norm(mlp(x))
+    assert float((b - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,T_,n_inst,L", [(300, 32, 2, 16), (37, 128, 3, 16), (64, 16, 32, 16), (100, 8, 2, 6)])
+def test_fused_mask_head_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, N, T_, n_inst, L):
+    """The same for the fused mask head (grid gathers as the first layer's operands, compositing epilogue)."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(N)
+    enc = GridEncoder(input_dim=3, num_levels=L, level_dim=8, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).to(gpu)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1.0, 1.0)
+    E = 15
+    mlp = SkipConnMLP(L * 8 + E, n_inst, 256, 3, skip_layers=[], bias=False).to(gpu)
+    xyz = torch.rand(N, T_, 3, device=gpu) * 2.2 - 1.1        # some samples outside the grid's box
+    extra = torch.randn(N, T_, E, device=gpu)
+    w = torch.rand(N, T_, device=gpu)
+    monkeypatch.setenv("SN_WIDE_JIT", "0")
+    a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
+    monkeypatch.setenv("SN_WIDE_JIT", "1")
+    b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
