@@ -2050,6 +2050,159 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
 }
 
 // ------------------------------------------------------------------------------------------
+// final stage for fields of OTHER sizes (k_final_stage_any)
+// ------------------------------------------------------------------------------------------
+// renderer.py:221-357 does not care how large the field is: run() calls self.density / self(...) of whatever subclass it is
+// given (BASELINE configs[0]: L = 8 levels, T = 2^14, a 16-32-16 grid_mlp and a 31-32-3 view_mlp).  The kernels above are
+// instantiated for NeRFNetwork's own sizes (network.py:93-98); this one takes every size at run time, for any field of the
+// same STRUCTURE -- hash / tiled grid with level_dim 2 (up to 16 levels), bias-free ReLU grid_mlp -> [sigma_raw | geo_feat],
+// trunc_exp, compositing, degree-4 SH of the view direction, bias-free ReLU view_mlp, sigmoid -- with up to 4 layers per
+// MLP, layers up to 64 wide and up to 31 geometry channels.  One lane = one ray as everywhere; a lane's activations live in
+// its own LDS columns ([row][256 lanes]: 64 + 64 ping-pong rows + 32 compositing rows = 160 floats per lane = all 160 KiB),
+// the weights are wave-uniform and come through the scalar cache, every neuron is one k-ascending fmaf chain and the grid
+// blend is k_grid_forward's (grid.hip) -- i.e. the oracle's arithmetic in the oracle's order.  No matrix cores: a field
+// this small is bound by its launch, and the proposal stages in front of it (if the field has the reference's) stay fused.
+struct AnyShape {
+    uint32_t ng, nv;               // linear layers of grid_mlp / view_mlp
+    uint32_t dg[5], dv[5];         // widths: dg[0] = L * 2 ... dg[ng] = 1 + geo;  dv[0] = geo + 16 ... dv[nv] = 3
+    const float *wg[4], *wv[4];    // nn.Linear.weight [out][in]
+};
+constexpr uint32_t ANY_W = 64, ANY_GEO = 31, ANY_LAYERS = 4;
+constexpr uint32_t ANY_LDS_FLOATS = (2u * ANY_W + ANY_GEO + 1u) * 256u;
+
+__device__ __forceinline__ void dense_any(const float *__restrict__ W, uint32_t in, uint32_t out, bool relu, const float *xin, float *yout) {
+    for (uint32_t o = 0; o < out; ++o) {
+        const float *w = W + (size_t)o * in;
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < in; ++k) acc = __builtin_fmaf(w[k], xin[k * 256u], acc);
+        if (relu) acc = __builtin_fmaxf(acc, 0.0f);
+        yout[o * 256u] = acc;
+    }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256, 1) void k_final_stage_any(FinalArgs a, AnyShape s) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufA = lds + threadIdx.x, *bufB = lds + ANY_W * 256u + threadIdx.x, *accf = lds + 2u * ANY_W * 256u + threadIdx.x;
+    uint32_t n;
+    const uint32_t wg = tile_id(a.rc);
+    const bool ok = ray_of_lane(a.rc, wg, n);
+    const uint32_t r = wg * 256u + threadIdx.x;
+    const uint32_t Npad = a.rc.Npad;
+    RaySetup rs;
+    setup_ray(a.rc, n, rs);
+    const uint32_t T = a.T, L = a.g.L, GEO = s.dg[s.ng] - 1u, NCOL = GEO + 16u;
+    const float b0step = 1.0f / (float)T;
+    auto bin_at = [&](uint32_t j) -> float {
+        if (a.bins_in) return a.bins_in[(size_t)j * Npad + r];
+        if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
+        return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
+    };
+    float dirn[3] = {rs.d[0], rs.d[1], rs.d[2]};     // normalised twice like the reference (renderer.py:294, sphere_harmonics.py:82)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float aa = dirn[0] * dirn[0], bb = dirn[1] * dirn[1], cc = dirn[2] * dirn[2];
+        const float nrm = sqrtf((aa + bb) + cc);
+        dirn[0] = dirn[0] / nrm; dirn[1] = dirn[1] / nrm; dirn[2] = dirn[2] / nrm;
+    }
+    for (uint32_t c = 0; c < GEO; ++c) accf[c * 256u] = 0.0f;
+    float dep = 0.0f;
+    double cum = 0.0, wsum = 0.0;
+    const TT *table = reinterpret_cast<const TT *>(a.table);
+    float bprev = bin_at(0);
+    float rb_prev = real_bin(rs, bprev);
+    if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
+    for (uint32_t j = 0; j < T; ++j) {
+        const float bnext = bin_at(j + 1u);
+        const float rb_next = real_bin(rs, bnext);
+        const float tmid = (rb_next + rb_prev) / 2.0f;
+        float p[3], x01[3];
+        sample_x01(a.rc, rs, tmid, p, x01);
+        // ---- grid features: gridencoder.cu:94-201 as k_grid_forward states it ----
+        const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
+        for (uint32_t l = 0; l < L; ++l) {
+            float acc[2] = {0.0f, 0.0f};
+            if (!oob) {
+                const uint32_t res = a.g.res[l], size = a.g.size[l], mode = a.g.mode[l];
+                const TT *tab = table + (size_t)a.g.off[l] * 2u;
+                float pos[3], deriv[3];
+                uint32_t cell[3];
+                grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, pos, deriv, cell);
+#pragma unroll
+                for (uint32_t idx = 0; idx < 8u; ++idx) {
+                    float w = 1.0f;
+                    uint32_t q[3];
+#pragma unroll
+                    for (uint32_t d = 0; d < 3u; ++d) {
+                        if ((idx & (1u << d)) == 0u) { w *= 1.0f - pos[d]; q[d] = cell[d]; }
+                        else { w *= pos[d]; q[d] = umin(cell[d] + 1u, res - 1u); }
+                    }
+                    float v[2];
+                    load_row<TT, 2>(tab + (size_t)grid_row<3>(q, res, size, mode) * 2u, v);
+                    acc[0] = __builtin_fmaf(w, v[0], acc[0]);
+                    acc[1] = __builtin_fmaf(w, v[1], acc[1]);
+                }
+            }
+            bufA[(2u * l) * 256u] = acc[0];
+            bufA[(2u * l + 1u) * 256u] = acc[1];
+        }
+        // ---- grid_mlp (network.py:146-153): the lane's own LDS columns, in -> out ping-pong ----
+        float *xin = bufA, *xout = bufB;
+        for (uint32_t i = 0; i < s.ng; ++i) {
+            dense_any(s.wg[i], s.dg[i], s.dg[i + 1u], i + 1u < s.ng, xin, xout);
+            float *t = xin; xin = xout; xout = t;
+        }
+        const float sigma = expf_det(xin[0]);                // network.py:151
+        const float delta = rb_next - rb_prev;
+        float ds = delta * sigma;
+        if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
+        const float alpha = 1.0f - expf_det(-ds);
+        const float tr = expf_det(-(float)cum);
+        float w = alpha * tr;
+        if (w != w) w = 0.0f;
+        cum += (double)ds;
+        wsum += (double)w;
+        dep = __builtin_fmaf(w, tmid, dep);
+        for (uint32_t c = 0; c < GEO; ++c) accf[c * 256u] = __builtin_fmaf(w, xin[(1u + c) * 256u], accf[c * 256u]);
+        if (a.w_out) a.w_out[(size_t)j * Npad + r] = w;
+        if (ok) {
+            if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
+            if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
+            if (a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
+            if (a.dbg_xyz) { float *q = a.dbg_xyz + ((size_t)n * T + j) * 3; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            if (a.dbg_geo) { float *q = a.dbg_geo + ((size_t)n * T + j) * GEO; for (uint32_t c = 0; c < GEO; ++c) q[c] = xin[(1u + c) * 256u]; }
+        }
+        if (a.stop_cum > 0.0f && __all((float)cum > a.stop_cum)) break;
+        rb_prev = rb_next;
+    }
+    // ---- per-ray colour head: view_mlp([f_geo | SH(d) * sum w]) -> sigmoid -> + (1 - sum w) * bg (renderer.py:340-357) ----
+    const float ws = (float)wsum;
+    {
+        float sh[16];
+        sh_degree4(dirn[0], dirn[1], dirn[2], sh);
+        for (uint32_t c = 0; c < GEO; ++c) bufA[c * 256u] = accf[c * 256u];
+#pragma unroll
+        for (uint32_t c = 0; c < 16u; ++c) bufA[(GEO + c) * 256u] = sh[c] * ws;
+    }
+    if (ok && a.dbg_fimg) for (uint32_t c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = bufA[c * 256u];
+    float *xin = bufA, *xout = bufB;
+    for (uint32_t i = 0; i < s.nv; ++i) {
+        dense_any(s.wv[i], s.dv[i], s.dv[i + 1u], i + 1u < s.nv, xin, xout);
+        float *t = xin; xin = xout; xout = t;
+    }
+    if (ok) {
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            const float sg = 1.0f / (1.0f + expf_det(-xin[c * 256u]));
+            const float bgm = (1.0f - ws) * a.rc.bg;
+            a.image[(size_t)n * 3 + c] = sg + bgm;
+        }
+        a.depth[n] = dep;
+        a.wsum[n] = ws;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // final stage, role-split waves (k_final_stage_rs; SN_RENDER_RS)
 // ------------------------------------------------------------------------------------------
 // In k_final_stage every wave alternates between two very different phases: the gather / blend phase (vector ALU + texture
@@ -3275,8 +3428,6 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     static const uint32_t d_prop[3] = {10, 16, 1};
     static const uint32_t d_main[4] = {32, 64, 64, 16};
     static const uint32_t d_view[4] = {31, 32, 32, 3};
-    static const uint32_t d_c1[3] = {16, 32, 16};
-    static const uint32_t d_c1v[3] = {31, 32, 3};
     GridLevels gl_prop[SN_MAX_STAGES], gl_main;
     for (uint32_t k = 0; k + 1 < S; ++k) {
         int rc = to_levels(&gl_prop[k], &cfg->prop_grid[k]);
@@ -3291,13 +3442,37 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         if (rc) return rc;
     }
     const bool is_main = cfg->grid.L == 16 && cfg->grid.C == 2 && mlp_is(&cfg->grid_mlp, 3, d_main) && mlp_is(&cfg->view_mlp, 3, d_view) && levels_fast(gl_main);
-    const bool is_c1 = cfg->grid.L == 8 && cfg->grid.C == 2 && mlp_is(&cfg->grid_mlp, 2, d_c1) && mlp_is(&cfg->view_mlp, 2, d_c1v);
-    if (!is_main && !is_c1) {
-        set_error("render_rays: field is neither the L=16,F=2 grid + 32-64-64-16 / 31-32-32-3 MLPs (network.py:93-98) nor the C1 test field");
+    // any other field of the same structure (sizes at run time: k_final_stage_any; BASELINE configs[0] is one)
+    AnyShape any_shape;
+    memset(&any_shape, 0, sizeof(any_shape));
+    bool is_any = false;
+    if (!is_main) {
+        const sn_mlp_desc *gm = &cfg->grid_mlp, *vm = &cfg->view_mlp;
+        auto plain = [](const sn_mlp_desc *m) {
+            if (m->num_layers < 1u || m->num_layers > ANY_LAYERS || m->activation != 0u || m->skip_mask != 0u) return false;
+            for (uint32_t l = 0; l < m->num_layers; ++l) if (m->bias[l] != nullptr || m->weight[l] == nullptr) return false;
+            for (uint32_t l = 0; l <= m->num_layers; ++l) if (m->dims[l] < 1u || m->dims[l] > ANY_W) return false;
+            return true;
+        };
+        is_any = cfg->grid.D == 3 && cfg->grid.C == 2 && cfg->grid.L >= 1 && cfg->grid.L * 2u <= ANY_W && plain(gm) && plain(vm) &&
+                 gm->dims[0] == cfg->grid.L * 2u && gm->dims[gm->num_layers] >= 2u && gm->dims[gm->num_layers] - 1u <= ANY_GEO &&
+                 cfg->sh_degree == 4u && vm->dims[0] == gm->dims[gm->num_layers] - 1u + 16u && vm->dims[vm->num_layers] == 3u;
+        if (is_any) {
+            any_shape.ng = gm->num_layers; any_shape.nv = vm->num_layers;
+            for (uint32_t l = 0; l <= gm->num_layers; ++l) any_shape.dg[l] = gm->dims[l];
+            for (uint32_t l = 0; l <= vm->num_layers; ++l) any_shape.dv[l] = vm->dims[l];
+            for (uint32_t l = 0; l < gm->num_layers; ++l) any_shape.wg[l] = gm->weight[l];
+            for (uint32_t l = 0; l < vm->num_layers; ++l) any_shape.wv[l] = vm->weight[l];
+        }
+    }
+    if (!is_main && !is_any) {
+        set_error("render_rays: the field is neither the L=16,F=2 grid + 32-64-64-16 / 31-32-32-3 MLPs (network.py:93-98) nor of the shape the "
+                  "size-agnostic final stage takes (3-D grid with level_dim 2 and <= 32 levels' worth of 64 features, bias-free ReLU MLPs of "
+                  "<= 4 layers and <= 64 neurons, <= 31 geometry channels, degree-4 SH)");
         return SN_ERR_UNSUPPORTED;
     }
-    if (is_c1) {
-        set_error("render_rays: the C1 plumbing field is a CPU-only configuration (BASELINE.json configs[0]); not instantiated for the GPU");
+    if (is_any && (cfg->compact_live || cfg->with_feat)) {
+        set_error("render_rays: compact_live / the in-render feature stage are instantiated for the reference network's sizes only");
         return SN_ERR_UNSUPPORTED;
     }
     GridLevels gl_feat;
@@ -3344,7 +3519,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     PairTab pairs;
     pairs.base = nullptr;
     for (int l = 0; l < 8; ++l) pairs.off[l] = 0;
-    if (use_mfma) {
+    if (use_mfma && !is_any) {
         ProfScope ps(st, PK_PACK);
         if (mlp_mode == MLP_F16X3)
             hipLaunchKernelGGL(k_pack_grid_mlp_f16, dim3(PACK16_VECS * 64 / 256), dim3(256), 0, st, cfg->grid_mlp.weight[0],
@@ -3375,7 +3550,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         ProfScope ps(st, PK_PACK);
         // (the main grid's region is sized for the densified layout whenever the sample count allows it; levels 5-6 are packed only
         //  when the kernel that reads them will run)
-        int rcp = pack_pairs(&cfg->grid, gl_main, pairs, Kv_main, pair_floats_of(&cfg->grid, main_samples));
+        int rcp = pack_pairs(&cfg->grid, gl_main, pairs, is_any ? 0 : Kv_main, pair_floats_of(&cfg->grid, main_samples));
         if (rcp) return rcp;
         for (uint32_t k = 0; k + 1 < S; ++k) {
             rcp = pack_pairs(&cfg->prop_grid[k], gl_prop[k], prop_pairs[k], dense_prefix(gl_prop[k]), pair_floats_of(&cfg->prop_grid[k]));
@@ -3496,6 +3671,22 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         const bool per_sample_out = fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo || fa.w_out;
         fa.stop_cum = (cfg->early_stop_eps > 0.0f && cfg->early_stop_eps < 1.0f && !per_sample_out) ? -logf(cfg->early_stop_eps) : 0.0f;
         const bool f16 = cfg->grid.table_dtype == SN_F16;
+        if (is_any) {     // sizes at run time
+            ProfScope ps_final(st, PK_FINAL);
+            const uint32_t geo = any_shape.dg[any_shape.ng] - 1u;
+            fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * geo : nullptr;
+            fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * (geo + 16u) : nullptr;
+            const size_t lds_bytes = (size_t)ANY_LDS_FLOATS * sizeof(float);
+            if (f16) {
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_any<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL(k_final_stage_any<__half>, dim3(nblk), dim3(256), lds_bytes, st, fa, any_shape);
+            } else {
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_any<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL(k_final_stage_any<float>, dim3(nblk), dim3(256), lds_bytes, st, fa, any_shape);
+            }
+            SN_LAUNCH_CHECK("k_final_stage_any");
+            continue;
+        }
         {
         ProfScope ps_final(st, PK_FINAL);
 #define SN_LAUNCH_FINAL_T(TT_, MODE_, KK, AUX_, LDS_FLOATS)                                                                      \

@@ -150,8 +150,8 @@ class NeRFRenderer(nn.Module):
         self._plan = None
 
     def _plan_tensors(self, with_feat: bool):
-        encs = [self.grid] + list(self.prop_encoders) + ([self.s_grid] if with_feat else [])
-        mlps = [self.grid_mlp, self.view_mlp] + list(self.prop_mlp)
+        encs = [self.grid] + list(getattr(self, "prop_encoders", [])) + ([self.s_grid] if with_feat else [])
+        mlps = [self.grid_mlp, self.view_mlp] + list(getattr(self, "prop_mlp", []))
         return [e.embeddings for e in encs] + [lin.weight for m in mlps for lin in m.net]
 
     def _get_plan(self, with_feat: bool = False):
@@ -178,29 +178,49 @@ class NeRFRenderer(nn.Module):
             self._plan.cfg.aabb[i] = ab[i]
         return self._plan
 
+    # A subclass whose forward() is NOT "grid -> grid_mlp -> [trunc_exp(sigma) | geo_feat], colour = view_mlp(cat(geo_feat, SH(d)))"
+    # (network.py:146-186) sets this to False: the fused kernels restate that structure, they do not call forward().
+    standard_field = True
+
     def _fused_shape(self) -> bool:
-        """Is this field the shape sn_rm_render_rays instantiates (nerf/network.py:93-98, 131-143: L=16 F=2 grid, 32-64-64-16
-        and 31-32-32-3 bias-free ReLU MLPs, degree-4 SH, L=5 F=2 proposal grids with 10-16-1 MLPs)?  Any other field -- a
-        subclass with its own sizes, e.g. BASELINE configs[0]: L=8 grid, 16-32-16 MLP -- renders through the stage loop over
-        the stand-alone HIP operators (grid_encode, SH, sample_pdf, weights, composite) instead; the library itself would
-        answer SN_ERR_UNSUPPORTED."""
+        """Can sn_rm_render_rays take this field?  Two kernels serve the last stage: the one instantiated for the reference
+        network's own sizes (nerf/network.py:93-98, 131-143: L=16 F=2 grid, 32-64-64-16 and 31-32-32-3 bias-free ReLU MLPs) on the
+        matrix cores, and a size-agnostic one (k_final_stage_any) for any other field of the same structure -- level_dim 2,
+        up to 32 levels' worth of 64 features, bias-free ReLU MLPs of <= 4 layers and <= 64 neurons, <= 31 geometry channels;
+        BASELINE configs[0] (L=8 grid, 16-32-16 / 31-32-3 MLPs) is one.  Proposal stages must be the reference's (L=5 F=2 grids,
+        10-16-1 MLPs).  Anything else renders through the stage loop over the stand-alone HIP operators (grid_encode, SH,
+        sample_pdf, weights, composite); the library itself would answer SN_ERR_UNSUPPORTED."""
+        return self._fused_kind() is not None
+
+    def _fused_kind(self):
         def dims(mlp):
             net = list(getattr(mlp, "net", []))
             return [net[0].weight.shape[1]] + [l.weight.shape[0] for l in net] if net and all(l.bias is None for l in net) else None
         try:
+            if not self.standard_field:
+                return None
             g = self.grid
-            ok = (g.input_dim == 3 and g.num_levels == 16 and g.level_dim == 2 and g.gridtype_id == 0 and not g.align_corners
-                  and g.interp_id == 0 and dims(self.grid_mlp) == [32, 64, 64, 16] and dims(self.view_mlp) == [31, 32, 32, 3]
-                  and getattr(self.view_encoder, "degree", 0) == 4)
+            if not (g.input_dim == 3 and g.level_dim == 2 and getattr(self.view_encoder, "degree", 0) == 4):
+                return None
             n_prop = len(self.opt.num_steps) - 1
-            if ok and n_prop > 0:
+            if n_prop > 0:
                 encs, mlps = list(self.prop_encoders), list(self.prop_mlp)
-                ok = len(encs) >= n_prop and all(
-                    e.input_dim == 3 and e.num_levels == 5 and e.level_dim == 2 and e.gridtype_id == 0 and not e.align_corners
-                    and e.interp_id == 0 and dims(m) == [10, 16, 1] for e, m in zip(encs[:n_prop], mlps[:n_prop]))
-            return bool(ok)
+                if not (len(encs) >= n_prop and all(
+                        e.input_dim == 3 and e.num_levels == 5 and e.level_dim == 2 and e.gridtype_id == 0 and not e.align_corners
+                        and e.interp_id == 0 and dims(m) == [10, 16, 1] for e, m in zip(encs[:n_prop], mlps[:n_prop]))):
+                    return None
+            dg, dv = dims(self.grid_mlp), dims(self.view_mlp)
+            if (g.num_levels == 16 and g.gridtype_id == 0 and not g.align_corners and g.interp_id == 0
+                    and dg == [32, 64, 64, 16] and dv == [31, 32, 32, 3]):
+                return "main"
+            relu = all(type(m).__name__ == "MLP" for m in (self.grid_mlp, self.view_mlp))      # network.py:9-29: ReLU between the layers
+            if (dg is not None and dv is not None and relu and g.num_levels * 2 <= 64 and len(dg) <= 5 and len(dv) <= 5
+                    and max(dg) <= 64 and max(dv) <= 64 and dg[0] == g.num_levels * 2 and 2 <= dg[-1] <= 32
+                    and dv[0] == dg[-1] - 1 + 16 and dv[-1] == 3 and getattr(self, "geom_feat_dim", dg[-1] - 1) == dg[-1] - 1):
+                return "any"
+            return None
         except AttributeError:
-            return False
+            return None
 
     def _sam_fusable(self) -> bool:
         """f_sam can be accumulated inside the fused render (no graph through s_grid wanted, standard hash grid)."""
@@ -320,7 +340,7 @@ class NeRFRenderer(nn.Module):
         # per-ray perturbed bins and u as inputs, exactly the reference's jitter (renderer.py:101-102, 267-270) -- and only the
         # last stage, which carries the gradients, goes through the autograd operators below.
         prop_needs_grad = update_proposal and torch.is_grad_enabled() and any(
-            p.requires_grad for m in (list(self.prop_encoders) + list(self.prop_mlp)) for p in m.parameters())
+            p.requires_grad for m in (list(getattr(self, "prop_encoders", [])) + list(getattr(self, "prop_mlp", []))) for p in m.parameters())
         wants_prop_loss = self.training and not opt.with_mask and not opt.with_sam and opt.lambda_proposal > 0 and update_proposal
         first_stage = 0
         if (len(steps) > 1 and not prop_needs_grad and not wants_prop_loss and rays_o.is_cuda and self._fused_shape()

@@ -490,8 +490,8 @@ class RenderPlan:
         self.activation_bound = 0.0
         self.check_range()
         self.num_steps = [int(t) for t in num_steps]
-        self.geo = model.geom_feat_dim
-        self.ncol = model.geom_feat_dim + model.view_encoder.output_dim
+        self.geo = int(getattr(model, "geom_feat_dim", list(model.grid_mlp.net)[-1].weight.shape[0] - 1))
+        self.ncol = self.geo + model.view_encoder.output_dim
         self._ws: Optional[torch.Tensor] = None
 
     @torch.no_grad()

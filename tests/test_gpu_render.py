@@ -336,12 +336,13 @@ def test_full_size_properties(gpu, orc):
     np.testing.assert_allclose(dep[idx].cpu().numpy(), want["depth"], rtol=1e-5, atol=1e-5)
 
 
-def test_config1_small_field_renders_through_the_hip_operators(gpu, orc):
-    """BASELINE configs[0] (64x64, hashgrid L=8 T=2^14, 1-hidden-x32 MLP, 32 samples/ray) on the GPU.  The fused kernel is
-    instantiated for the reference network's shape only; a field with other sizes -- here the same small subclass the
-    fixture generator derives from the reference's NeRFRenderer -- goes through NeRFRenderer.run's stage loop over the
-    stand-alone HIP operators (near/far, sample positions + contraction, grid_encode, SH, weights, composite).  Checked
-    against the reference's own output (tests/golden/render_c1.npz) and the oracle."""
+def test_config1_small_field_through_the_fused_call_and_the_operator_chain(gpu, orc):
+    """BASELINE configs[0] (64x64, hashgrid L=8 T=2^14, 1-hidden-x32 MLP, 32 samples/ray) on the GPU.  The field is the same small
+    subclass the fixture generator derives from the reference's NeRFRenderer.  Round 3: sn_rm_render_rays takes it -- its last
+    stage has a size-agnostic kernel (k_final_stage_any) next to the one instantiated for the reference network's sizes -- and
+    NeRFRenderer.run routes it there; a field that declares a non-standard forward() (standard_field = False) still goes
+    through the stage loop over the stand-alone HIP operators.  Both routes are checked against the reference's own output
+    (tests/golden/render_c1.npz); the fused one also against the oracle on every ray."""
     from sanerf_hq_amd import raymarching as rm, synth
     from sanerf_hq_amd.activation import trunc_exp
     from sanerf_hq_amd.encoding import get_encoder
@@ -367,17 +368,93 @@ def test_config1_small_field_renders_through_the_hip_operators(gpu, orc):
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
     assert not unexpected and all(m.endswith("offsets") or m.startswith("aabb") for m in missing), (missing, unexpected)
     model = model.to(gpu).eval()
-    assert not model._fused_shape()
+    assert model._fused_kind() == "any"
     H, W = [int(v) for v in g["HW"]]
     ro, rd = rm.generate_rays(g["pose"], synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    with torch.no_grad():
+        fused = model.render(ro, rd, staged=True, perturb=False)
+    for k, tol in (("image", RGB_TOL), ("depth", 1e-4), ("weights_sum", 1e-5)):
+        np.testing.assert_allclose(fused[k].cpu().numpy().reshape(g[k].shape), g[k], rtol=0, atol=tol)
+    # the oracle on the same field: fmaf chains in the same order -> round-off level agreement on every ray
+    keep = orc._Keep()
+    cfg = orc.OrcRenderCfg()
+    cfg.num_stages = 1; cfg.num_steps[0] = 32
+    gr = model.grid
+    cfg.grid = orc.make_grid(gr.embeddings.detach().cpu().numpy(), gr.offsets.cpu().numpy(), gr.per_level_scale, gr.base_resolution, keep=keep)
+    cfg.grid_mlp = orc.make_mlp([l.weight.detach().cpu().numpy() for l in model.grid_mlp.net], keep=keep)
+    cfg.view_mlp = orc.make_mlp([l.weight.detach().cpu().numpy() for l in model.view_mlp.net], keep=keep)
+    cfg.sh_degree = 4
+    for i, v in enumerate(model.aabb_infer.cpu().numpy()):
+        cfg.aabb[i] = float(v)
+    cfg.min_near, cfg.bound, cfg.contract, cfg.last_sample_opaque, cfg.bg_color = 0.2, 2.0, 1, 1, 1.0
+    want = orc.render(cfg, ro.cpu().numpy(), rd.cpu().numpy())
+    assert np.abs(fused["image"].cpu().numpy().reshape(-1, 3) - want["image"]).max() <= 2e-6
+    assert np.abs(fused["depth"].cpu().numpy().reshape(-1) - want["depth"]).max() <= 2e-5
+    # the operator-chain route (a field that does not vouch for the standard structure)
+    model.standard_field = False
+    assert not model._fused_shape()
     with torch.no_grad():
         out = model.render(ro, rd, staged=True, perturb=False)
     for k, tol in (("image", RGB_TOL), ("depth", 1e-4), ("weights_sum", 1e-5)):
         np.testing.assert_allclose(out[k].cpu().numpy().reshape(g[k].shape), g[k], rtol=0, atol=tol)
-    # the library says so itself when asked to fuse this field
-    with pytest.raises(RuntimeError, match="C1|neither"):
-        model.prop_encoders, model.prop_mlp, model.geom_feat_dim = torch.nn.ModuleList(), torch.nn.ModuleList(), 15
+    assert float((out["image"] - fused["image"]).abs().max()) <= 2e-5
+    # a shape neither kernel takes: the library says so itself
+    model.standard_field = True
+    model.view_mlp = MLP(31, 3, 96, 2, bias=False).to(gpu)
+    assert not model._fused_shape()
+    model.prop_encoders, model.prop_mlp, model.geom_feat_dim = torch.nn.ModuleList(), torch.nn.ModuleList(), 15
+    with pytest.raises(RuntimeError, match="neither"):
         rm.render_rays(rm.RenderPlan(model, [32]), ro, rd)
+
+
+@pytest.mark.parametrize("L,log2T,hid,nlayers,geo,vhid,vlayers,steps,f16", [
+    (12, 15, 48, 3, 7, 24, 2, [48, 24, 16], False),     # the reference's proposal stages in front of a field of other sizes
+    (5, 12, 64, 4, 31, 64, 4, [20], False),             # the widest the kernel takes
+    (16, 19, 20, 1, 3, 8, 1, [33], True),               # single linear layers, fp16 table, odd step count
+])
+def test_size_agnostic_final_stage_vs_oracle(gpu, orc, L, log2T, hid, nlayers, geo, vhid, vlayers, steps, f16):
+    """k_final_stage_any: fields of the reference's structure with other sizes (renderer.py:221-357 is size-agnostic) against the
+    oracle -- sample indices of the fused proposal stages bit-exact, RGB <= 1e-5, per-sample tensors of the last stage."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.encoding import get_encoder
+    from sanerf_hq_amd.nerf.network import MLP
+    params = synthetic_params(steps, seed=41 + L)
+    model = product_model(params, steps, False, gpu)
+    torch.manual_seed(L * 100 + geo)
+    model.grid, d = get_encoder("hashgrid", input_dim=3, level_dim=2, num_levels=L, log2_hashmap_size=log2T, desired_resolution=1024)
+    model.grid_mlp = MLP(d, 1 + geo, hid, nlayers, bias=False)
+    model.view_mlp = MLP(geo + 16, 3, vhid, vlayers, bias=False)
+    model.geom_feat_dim = geo
+    model = model.to(gpu).eval()
+    with torch.no_grad():
+        model.grid.embeddings.uniform_(-1.0, 1.0)
+        for lin in list(model.grid_mlp.net) + list(model.view_mlp.net):
+            lin.weight.mul_(3.0)
+    assert model._fused_kind() == "any"
+    H = W = 24
+    _, _, ro, rd = camera_rays(orc, H, W)
+    tdt = torch.float16 if f16 else torch.float32
+    plan = rm.RenderPlan(model, steps, table_dtype=tdt)
+    want_keys = ("inds", "weights_last", "xyzs_last", "geo_feat_last", "f_image")
+    out = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W, want=want_keys)
+    cfg = oracle_cfg(orc, params, steps, table_f16=f16)          # proposal nets as the reference's; replace the main field
+    keep = cfg._keep
+    emb = model.grid.embeddings.detach().cpu().numpy()
+    cfg.grid = orc.make_grid(emb.astype(np.float16) if f16 else emb, model.grid.offsets.cpu().numpy(), model.grid.per_level_scale, model.grid.base_resolution, keep=keep)
+    cfg.grid_mlp = orc.make_mlp([l.weight.detach().cpu().numpy() for l in model.grid_mlp.net], keep=keep)
+    cfg.view_mlp = orc.make_mlp([l.weight.detach().cpu().numpy() for l in model.view_mlp.net], keep=keep)
+    want = orc.render(cfg, ro, rd, debug=True)
+    for k in range(1, len(steps)):
+        assert np.array_equal(out[f"inds{k}"].cpu().numpy(), want[f"inds{k}"])
+    assert np.abs(out["image"].cpu().numpy() - want["image"]).max() <= 1e-5
+    assert np.abs(out["depth"].cpu().numpy() - want["depth"]).max() <= 5e-5
+    assert np.abs(out["weights_sum"].cpu().numpy() - want["weights_sum"]).max() <= 1e-5
+    last = len(steps) - 1
+    np.testing.assert_allclose(out["weights_last"].cpu().numpy(), want[f"weights{last}"], rtol=0, atol=1e-5)
+    assert out["geo_feat_last"].shape == (H * W, steps[-1], geo) and out["f_image"].shape == (H * W, geo + 16)
+    # the same call in linear order and in two chunks of rays gives the same image (a16)
+    lin = rm.render_rays(plan, T(ro, gpu), T(rd, gpu))
+    assert torch.equal(lin["image"], out["image"])
 
 
 def test_config3_full_size_heads_spot_checked(gpu, orc):
