@@ -91,6 +91,8 @@ struct PackArgs {
     WideLayer layer[SN_MAX_LAYERS];
     uint4 *pack;
     uint32_t transposed;                  // 1: w[l] is read as its transpose (backward pass): element [m][k] = w[l][k * in_dim[l] + m]
+    uint32_t pair_ks;                     // k_mlp_wide_j<3>: the first pair_ks input k-steps of layer 0 hold (half-wave h, slot i) = level 2 kx + (i >> 2),
+                                          // channel 4 h + (i & 3) of the C = 8 grid instead of input column 16 kx + 8 h + i (see issue_pair)
 };
 
 __device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo) {
@@ -145,7 +147,7 @@ __global__ void k_pack_mlp_wide(PackArgs a) {
             col = 32u * (ks >> 1) + (r & 3u) + 8u * (r >> 2) + 4u * hi;
         } else {
             const uint32_t kx = ks - (L.uses_h ? (uint32_t)WIDE_HKS : 0u);
-            const uint32_t c = 16u * kx + 8u * hi + i;
+            const uint32_t c = (layer == 0u && kx < a.pair_ks) ? 16u * kx + 8u * (i >> 2) + 4u * hi + (i & 3u) : 16u * kx + 8u * hi + i;
             valid = valid && c < a.din;
             col = (L.uses_h ? (uint32_t)WIDE : 0u) + c;   // skip layers see cat([h, x]) (network.py:61-63)
         }
@@ -595,7 +597,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             uint32_t p[3];
 #pragma unroll
             for (uint32_t d = 0; d < 3u; ++d) p[d] = (idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
+#if SN_WIDE_ABLATE & 8          // timing experiment (wrong results): every corner reads row 0 of its level (same loads, perfect locality)
+            load_row<float, 8>(tab, r.cv[idx]);
+#elif SN_WIDE_ABLATE & 16       // timing experiment (wrong results): no gathers at all
+#pragma unroll
+            for (int c = 0; c < 8; ++c) r.cv[idx][c] = r.pos[c % 3] + (float)p[c % 3];
+#else
             load_row<float, 8>(tab + (size_t)grid_row<3>(p, res, size, mode) * 8u, r.cv[idx]);
+#endif
         }
     };
     auto blend_level = [&](uint32_t kx, const LevelRegs &r, uint4 &bh, uint4 &bl) {
@@ -893,10 +902,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #ifndef SN_WIDE_REFILL_LATE
 #define SN_WIDE_REFILL_LATE 0 // where the four DMA pieces of chunk g+4 are issued: 0 = right after the barrier (tile 6), 1 = behind the last tile's MFMAs,
 #endif                        // 2 = one between / two behind the three MFMAs of the last tile.  Measured per h k-step: 1110 / 1160 / 1260 cycles
+#ifndef SN_WIDE_NT
+#define SN_WIDE_NT 0         // cache policy of the fused mask head's gathers (experiments, see issue_pair)
+#endif
 #ifndef SN_WIDE_JV
 #define SN_WIDE_JV 8         // vector instructions the scheduler may place behind each MFMA of a tile
 #endif
 
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float *p) {      // 16-byte load with the non-temporal cache policy
+    const floatx4v v = __builtin_nontemporal_load(reinterpret_cast<const floatx4v *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 template <bool B> struct bool_tag { static constexpr bool value = B; };
 template <int N> struct int_tag { static constexpr int value = N; };
 // compile-time loop: f(int_tag<0>{}) ... f(int_tag<N-1>{}).  (`#pragma unroll` is a request: the 16 k-steps of a layer came back as a
@@ -910,9 +927,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];        // WIDE_NBUF x WIDE_CHUNK_U4, then floats
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t half = lane >> 5;
-    const uint32_t n = blockIdx.x * WIDE_ROWS + wave * 32u + (lane & 31u);
-    const bool ok = n < a.N;
+    // XMODE 0..2: one tile of 128 consecutive rows per workgroup.  XMODE 3 (fused mask head): a workgroup owns 32 CONSECUTIVE RAYS and walks
+    // their T samples in T / 4 tiles -- wave w of tile p takes sample t = 4 p + w of every ray, lanes n and n + 32 share ray n -- so that a
+    // gather instruction fetches the rows of 32 neighbouring pixels at ONE depth (they share fine-level lines) instead of 32 samples along
+    // one ray (which share none: every 32-byte row cost a 128-byte line from beyond the L2, and that traffic bound the first layer)
+    uint32_t n = blockIdx.x * WIDE_ROWS + wave * 32u + (lane & 31u);
+    bool ok = n < a.N;
     const float *xrow = a.x + (size_t)(ok ? n : 0u) * a.din;
+    const uint32_t ntiles = XMODE == 3 ? a.T >> 2 : 1u;
     float *lds_bias = reinterpret_cast<float *>(lds_w + WIDE_NBUF * WIDE_CHUNK_U4);      // [nl][WIDE], zero where absent
     float *lds_x = lds_bias + SN_MAX_LAYERS * WIDE;                               // [128][xs]
     const uint32_t xs = a.xs;
@@ -961,35 +983,42 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             lds_lv[tid] = a.g.res[tid]; lds_lv[SN_MAX_LEVELS + tid] = a.g.size[tid];
             lds_lv[2 * SN_MAX_LEVELS + tid] = a.g.mode[tid]; lds_lv[3 * SN_MAX_LEVELS + tid] = a.g.off[tid];
         }
-        const float *p = a.xyz + (size_t)(ok ? n : a.N - 1u) * 3u;
+    }
+    auto load_sample = [&](uint32_t tile) {          // XMODE 3: row of (ray, t) for this lane, its position and appended channels
+        const uint32_t ray = blockIdx.x * 32u + (lane & 31u), t = 4u * tile + wave;
+        ok = ray < a.N / a.T;
+        n = (ok ? ray : 0u) * a.T + t;
+        const float *p = a.xyz + (size_t)n * 3u;
+        x_oob = false;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {   // grid.py:156
-            const float t = p[d] + a.bound;
-            x01[d] = a.inv_den != 0.0f ? t * a.inv_den : t / (2.0f * a.bound);
+            const float v = p[d] + a.bound;
+            x01[d] = a.inv_den != 0.0f ? v * a.inv_den : v / (2.0f * a.bound);
             x_oob = x_oob || x01[d] < 0.0f || x01[d] > 1.0f;                // gridencoder.cu:105-130: zeros outside [0,1]
         }
         if (a.E) {
-            const float *row = a.extra + (size_t)(ok ? n : a.N - 1u) * a.E;
+            const float *row = a.extra + (size_t)n * a.E;
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint32_t c = 8u * half + i;
-                const float t = row[c < a.E ? c : a.E - 1u];
-                ev[i] = c < a.E ? t : 0.0f;
+                const float v = row[c < a.E ? c : a.E - 1u];
+                ev[i] = c < a.E ? v : 0.0f;
             }
         }
-    }
+    };
 
     floatx16 acc[WIDE_MT];
     float prev[16 * WIDE_MT];              // the previous layer's outputs before the activation: prev[16 t + r] = register r of its tile t
     uint32_t g = 0;                        // chunks consumed so far
-    const uint32_t total_chunks = a.total_chunks;
+    const uint32_t tile_chunks = a.total_chunks;
+    const uint32_t total_chunks = tile_chunks * ntiles;     // the workgroup's whole stream: the packed weights, once per tile, back to back
     const uint32_t lds_w_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_w) + wave * 1024u;
     constexpr uint32_t CHUNK_BYTES = WIDE_CHUNK_U4 * sizeof(uint4);
     constexpr int PIECES = WIDE_CHUNK_U4 / 256;
 #pragma unroll
     for (uint32_t c = 0; c < (uint32_t)WIDE_NBUF - 1u; ++c) {
         if (c < total_chunks) {
-            const uint4 *src = a.pack + (size_t)c * WIDE_CHUNK_U4 + tid;
+            const uint4 *src = a.pack + (size_t)(c % tile_chunks) * WIDE_CHUNK_U4 + tid;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) dma16(src + i * 256, lds_w_off + c * CHUNK_BYTES + (uint32_t)i * 4096u);
         }
@@ -1024,7 +1053,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #endif
 #if SN_WIDE_REFILL_LATE == 0
         if (gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
-            const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+            const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + tid;
             const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
@@ -1034,13 +1063,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     // refill the buffer chunk gn-1 was read from (every wave passed the barrier above after its last read of it) with chunk gn+3.
     // Issued BEHIND the last tile's MFMAs: the four pieces cost ~100 cycles of address / m0 set-up that used to sit between two tiles
     auto refill_piece = [&](uint32_t gn, int i) {
-        const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+        const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + tid;
         const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
         dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
     };
     auto refill = [&](uint32_t gn) {
         if (SN_WIDE_REFILL_LATE == 1 && gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
-            const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
+            const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + tid;
             const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
@@ -1077,7 +1106,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     };
     auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
         constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
-        wide_trace(g);
+        if (g < 128u) wide_trace(g);
         const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
         const half8_t Bh = __builtin_bit_cast(half8_t, make_uint4(ob_h[0], ob_h[1], ob_h[2], ob_h[3]));
         const half8_t Bl = __builtin_bit_cast(half8_t, make_uint4(ob_l[0], ob_l[1], ob_l[2], ob_l[3]));
@@ -1187,79 +1216,112 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         }
     };
 
-    // XMODE 3: k-step kx of the input = levels 2 kx (low half-wave) and 2 kx + 1 (high half-wave) of the C = 8 grid; every lane
-    // interpolates ONE level of its own sample (k_mlp_wide).
-    struct LevelRegs { float pos[3]; float cv[8][8]; };
-    auto issue_corners = [&](uint32_t kx, LevelRegs &r, int first, int last, uint32_t (&cell)[3], uint32_t &res, uint32_t &size, uint32_t &mode, const float *&tab) {
-        if (first == 0) {
-            const uint32_t level = umin(2u * kx + half, a.g.L - 1u);
-            res = lds_lv[level]; size = lds_lv[SN_MAX_LEVELS + level]; mode = lds_lv[2 * SN_MAX_LEVELS + level];
-            tab = a.table + (size_t)lds_lv[3 * SN_MAX_LEVELS + level] * 8u;
-            float deriv[3];
-            grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, r.pos, deriv, cell);
-        }
+    // XMODE 3: input k-step kx carries levels A = 2 kx and B = 2 kx + 1 of the C = 8 grid.  In k_mlp_wide<3> the low half-wave interpolates
+    // level A and the high one level B of the SAME 32 samples, every lane fetching both 16-byte halves of its 8 corner rows: 16 gather
+    // instructions per k-step that each touch up to 64 rows -- and those k-steps are bound by the texture path (cycle trace: 9-12 thousand
+    // cycles per k-step with random positions, 4 waves on one address path).  Here lanes n and n + 32 SHARE the rows of sample n: each fetches
+    // ONE half (channels 4 h .. 4 h + 3) of the 8 corner rows of BOTH levels, so a gather instruction touches 32 rows instead of 64 and no
+    // data has to be exchanged; only the bookkeeping is split -- the low half-wave locates level A, the high one level B, and one
+    // v_permlane32_swap per value hands row offsets and blend weights to the other half.  The operand's slots become (h, i) = level
+    // A / B (i >> 2), channel 4 h + (i & 3): a permutation of the first layer's input columns that k_pack_mlp_wide applies (pair_ks).
+    struct PairRegs { float wA[8], wB[8]; float4 rA[8], rB[8]; };
+    auto issue_pair = [&](uint32_t kx, PairRegs &r) {
+        const uint32_t level = umin(2u * kx + half, a.g.L - 1u);
+        const uint32_t res = lds_lv[level], size = lds_lv[SN_MAX_LEVELS + level], mode = lds_lv[2 * SN_MAX_LEVELS + level];
+        const uint32_t base = lds_lv[3 * SN_MAX_LEVELS + level];
+        float pos[3], deriv[3];
+        uint32_t cell[3];
+        grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, pos, deriv, cell);
+        const float *tabh = a.table + 4u * half;                        // this lane's half of every row
+#if SN_WIDE_NT == 2
+        const bool ntA = (a.g.mode[umin(2u * kx, a.g.L - 1u)] & 1u) != 0u, ntB = (a.g.mode[umin(2u * kx + 1u, a.g.L - 1u)] & 1u) != 0u;
+#endif
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-            if (idx < first || idx >= last) continue;
-            uint32_t p[3];
-#pragma unroll
-            for (uint32_t d = 0; d < 3u; ++d) p[d] = ((uint32_t)idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
-            load_row<float, 8>(tab + (size_t)grid_row<3>(p, res, size, mode) * 8u, r.cv[idx]);
-        }
-    };
-    auto blend_corners = [&](const LevelRegs &r, int first, int last, float (&v)[8]) {
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-            if (idx < first || idx >= last) continue;
+        for (uint32_t idx = 0; idx < 8u; ++idx) {
+            uint32_t q[3];
             float w = 1.0f;
 #pragma unroll
-            for (uint32_t d = 0; d < 3u; ++d) w *= ((uint32_t)idx & (1u << d)) ? r.pos[d] : 1.0f - r.pos[d];
+            for (uint32_t d = 0; d < 3u; ++d) {                            // weights as k_mlp_wide's blend_level forms them (grid.hip:k_grid_forward)
+                q[d] = (idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
+                w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
+            }
+            const uint32_t off = (base + grid_row<3>(q, res, size, mode)) * 8u;     // floats from the table's start (< 2^32: checked on the host)
+            const auto po = __builtin_amdgcn_permlane32_swap(off, off, false, false);                                   // [A | A], [B | B]
+            const auto pw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+            r.wA[idx] = __uint_as_float(pw[0]); r.wB[idx] = __uint_as_float(pw[1]);
+#if SN_WIDE_NT == 1             // experiment: every gather non-temporal
+            r.rA[idx] = nt_load4(tabh + po[0]);
+            r.rB[idx] = nt_load4(tabh + po[1]);
+#elif SN_WIDE_NT == 2           // experiment: the hashed levels' rows (used once) non-temporal, the dense levels' rows (shared by all rays) cached
+            if (ntA) r.rA[idx] = nt_load4(tabh + po[0]);
+            else r.rA[idx] = *reinterpret_cast<const float4 *>(tabh + po[0]);
+            if (ntB) r.rB[idx] = nt_load4(tabh + po[1]);
+            else r.rB[idx] = *reinterpret_cast<const float4 *>(tabh + po[1]);
+#else
+            r.rA[idx] = *reinterpret_cast<const float4 *>(tabh + po[0]);
+            r.rB[idx] = *reinterpret_cast<const float4 *>(tabh + po[1]);
+#endif
+        }
+    };
+    auto blend_pair = [&](const PairRegs &r, int first, int last, float (&v)[8]) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = __builtin_fmaf(w, r.cv[idx][c], idx == 0 ? 0.0f : v[c]);
+        for (int idx = 0; idx < 8; ++idx) {
+            if (idx < first || idx >= last) continue;
+            const float ra[4] = {r.rA[idx].x, r.rA[idx].y, r.rA[idx].z, r.rA[idx].w}, rb[4] = {r.rB[idx].x, r.rB[idx].y, r.rB[idx].z, r.rB[idx].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] = __builtin_fmaf(r.wA[idx], ra[c], idx == 0 ? 0.0f : v[c]);
+                v[4 + c] = __builtin_fmaf(r.wB[idx], rb[c], idx == 0 ? 0.0f : v[4 + c]);
+            }
         }
     };
 
     uint32_t bh[4], bl[4], nbh[4] = {0u, 0u, 0u, 0u}, nbl[4] = {0u, 0u, 0u, 0u};   // operand of the chunk about to run / of the one after it
     const uint32_t nl = a.nl;
 
-    // ---- layer 0: input k-steps only; accumulators start from the bias the plain way (once per workgroup) ----
+    float out_acc[16];                     // XMODE 3: sum over this wave's samples of weight x logit, per ray (neurons as tile 0's registers)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out_acc[r] = 0.0f;
+    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+    if constexpr (XMODE == 3) load_sample(tile);
+    // ---- layer 0: input k-steps only; accumulators start from the bias the plain way (once per tile) ----
     {
         const WideLayer L = a.layer[0];
 #pragma unroll
         for (int mt = 0; mt < WIDE_MT; ++mt) bias_tile(0u, mt, acc[mt]);
-        wide_trace(128u);
+        if (tile == 0u) wide_trace(128u);
         if constexpr (XMODE == 3) {
             const uint32_t gks = (a.g.L + 1u) >> 1;                       // k-steps that carry grid levels; one more for the appended channels
             const uint32_t K = gks + (a.E ? 1u : 0u);
-            LevelRegs S;
-            uint32_t cell[3], res, size, mode; const float *tab;
-            issue_corners(0u, S, 0, 8, cell, res, size, mode, tab);
+            PairRegs S;
+            const uint32_t Lg = a.g.L;
+            issue_pair(0u, S);
             {
                 float v[8];
-                blend_corners(S, 0, 8, v);
-                const bool zero = x_oob || half >= a.g.L;
+                blend_pair(S, 0, 8, v);
+                const bool zA = x_oob, zB = x_oob || 1u >= Lg;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) split2h(zero ? 0.0f : v[2 * p], zero ? 0.0f : v[2 * p + 1], bh[p], bl[p]);
+                for (int p = 0; p < 4; ++p) { const bool z = p < 2 ? zA : zB; split2h(z ? 0.0f : v[2 * p], z ? 0.0f : v[2 * p + 1], bh[p], bl[p]); }
             }
-            issue_corners(1u, S, 0, 8, cell, res, size, mode, tab);
+            issue_pair(1u, S);
             float bv[8];
             // chunk c < K-1: blend k-step c+1 (requested during chunk c-1) behind tiles 0..2, request the rows of k-step c+2 into the same
-            // registers behind tiles 3..4 (the k-step after the last level one is the appended channels); the last chunk is peeled: it hands
+            // registers behind tile 3 (the k-step after the last level one is the appended channels); the last chunk is peeled: it hands
             // the layer over.  One register set: the texture path, not the latency of one wave, bounds these k-steps (4 waves share it)
             for (uint32_t c = 0; c + 1u < K; ++c) {
                 const bool lev = c + 1u < gks;
                 chunk8(bool_tag<false>{}, bool_tag<false>{}, int_tag<16>{}, 0u, bh, bl, [&](auto mtc) {
                     constexpr int mt = decltype(mtc)::value;
-                    if constexpr (mt == 0) blend_corners(S, 0, 3, bv);
-                    if constexpr (mt == 1) blend_corners(S, 3, 6, bv);
-                    if constexpr (mt == 2) blend_corners(S, 6, 8, bv);
-                    if constexpr (mt == 3) issue_corners(c + 2u, S, 0, 4, cell, res, size, mode, tab);
-                    if constexpr (mt == 4) issue_corners(c + 2u, S, 4, 8, cell, res, size, mode, tab);
+                    if constexpr (mt == 0) blend_pair(S, 0, 3, bv);
+                    if constexpr (mt == 1) blend_pair(S, 3, 6, bv);
+                    if constexpr (mt == 2) blend_pair(S, 6, 8, bv);
+                    if constexpr (mt == 3) issue_pair(c + 2u, S);
                     if constexpr (mt == 5) {
-                        const bool zero = x_oob || 2u * (c + 1u) + half >= a.g.L;
+                        const bool zA = x_oob || 2u * (c + 1u) >= Lg, zB = x_oob || 2u * (c + 1u) + 1u >= Lg;
 #pragma unroll
                         for (int p = 0; p < 4; ++p) {
-                            const float l0 = zero ? 0.0f : bv[2 * p], l1 = zero ? 0.0f : bv[2 * p + 1];
+                            const bool z = p < 2 ? zA : zB;
+                            const float l0 = z ? 0.0f : bv[2 * p], l1 = z ? 0.0f : bv[2 * p + 1];
                             split2h(lev ? l0 : ev[2 * p], lev ? l1 : ev[2 * p + 1], nbh[p], nbl[p]);
                         }
                     }
@@ -1291,7 +1353,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     // ---- layers 1 .. nl-1 ----
     for (uint32_t l = 1; l < nl; ++l) {
         const WideLayer L = a.layer[l];
-        wide_trace(128u + l);
+        if (tile == 0u) wide_trace(128u + l);
         if (L.narrow) {
             // last layer with <= 64 outputs: 4 chunks of 4 k-steps x 1 tile pair (k_pack_mlp_wide); the operand of k-step k+1 is split
             // between the six MFMAs of k-step k.  Tiles 6 and 7 of the previous layer leave the accumulators first.
@@ -1300,7 +1362,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             bias_tile(l, 0, c0); bias_tile(l, 1, c1);
             static_for<WIDE_HKS / 4>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                wide_trace(g);
+                if (g < 128u) wide_trace(g);
                 const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
                 uint4 ah[2][2], al[2][2];
                 ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
@@ -1368,7 +1430,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     }
 
     // ---- epilogue (k_mlp_wide's) ----
-    const WideLayer LL = a.layer[a.nl - 1u];
     {   // range check of the split-fp16 arithmetic: an activation beyond 65504 turned into inf in a hi half and reaches
         // the last layer as inf / NaN.  0 * x is NaN exactly for those.  Sticky flag, read by sn_mlp_wide_overflow().
         float chk = 0.0f;
@@ -1378,48 +1439,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(acc[mt][r], 0.0f, chk);
         if (ok && chk != chk) g_wide_overflow = 1;
     }
+    if constexpr (XMODE == 3) {            // renderer.py:384: out[ray, m] = sum_t w[ray, t] * logits[ray, t, m]: this wave's t of this tile
+        const float w = ok ? a.wts[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float t = w * acc[0][r]; out_acc[r] = out_acc[r] + t; }
+    }
+    }                                      // tiles
+    const WideLayer LL = a.layer[a.nl - 1u];
     wide_trace(160u);                      // all layers done; what follows is the output epilogue
     if constexpr (XMODE == 3) {
-        // renderer.py:384: out[ray, m] = sum_t w[ray, t] * logits[ray, t, m].  Rows are samples in [ray][t] order and T divides
-        // 128 or is a multiple of 32 that divides 128 (checked on the host): a ray's samples sit in T consecutive lanes of one
-        // half-wave image (T <= 32) or in T / 32 whole waves of this workgroup.  Fixed reduction tree: deterministic.
-        const float w = ok ? a.wts[n] : 0.0f;
-        const uint32_t Tl = a.T < 32u ? a.T : 32u;                        // lanes (rows) of one wave that share a ray
-        float sum[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float t = w * acc[0][r];
-#pragma unroll
-            for (uint32_t d = 1; d < 32u; d <<= 1) { const float o = __shfl_xor(t, (int)d, 32); t = d < Tl ? t + o : t; }
-            sum[r] = t;
-        }
+        // the four waves hold different samples of the same 32 rays: fixed-order sum through LDS (the weight ring is dead), wave 0 stores
+        float *part = reinterpret_cast<float *>(lds_w);                  // [4 waves][32 rays][32 neurons]
         const uint32_t j = lane & 31u;
-        float *part = reinterpret_cast<float *>(lds_w);                  // [4 waves][32 neurons]: the weight ring is dead
-        if (a.T > 32u) {
-            __syncthreads();
-            if (j == 0u) {
+        __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) part[wave * 32u + (r & 3) + 8u * (r >> 2) + 4u * half] = sum[r];
-            }
-            __syncthreads();
-            const uint32_t wpr = a.T >> 5;                                // waves per ray: 2 or 4
-            if (j == 0u && (wave % wpr) == 0u) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t m = (r & 3) + 8u * (r >> 2) + 4u * half;
-                    float t = sum[r];
-                    for (uint32_t q = 1; q < wpr; ++q) t += part[(wave + q) * 32u + m];
-                    sum[r] = t;
-                }
-            }
-            if ((wave % wpr) != 0u) return;
-        }
-        if (ok && (j % Tl) == 0u) {
-            float *orow = a.out + (size_t)(n / a.T) * LL.out;
+        for (int r = 0; r < 16; ++r) part[(wave * 32u + j) * 32u + (r & 3) + 8u * (r >> 2) + 4u * half] = out_acc[r];
+        __syncthreads();
+        if (wave == 0u && ok) {
+            float *orow = a.out + (size_t)(blockIdx.x * 32u + j) * LL.out;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t m = (r & 3) + 8u * (r >> 2) + 4u * half;
-                if (m < LL.out) orow[m] = sum[r];
+                const float t = ((part[(0u * 32u + j) * 32u + m] + part[(1u * 32u + j) * 32u + m]) + part[(2u * 32u + j) * 32u + m]) + part[(3u * 32u + j) * 32u + m];
+                if (m < LL.out) orow[m] = t;
             }
         }
         return;
@@ -1505,13 +1547,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     }
 }
 
-// Which forward kernel: SN_WIDE_JIT=0 -> k_mlp_wide everywhere, =1 -> k_mlp_wide_j everywhere (same-library A/B; read on every call).
-// Unset: k_mlp_wide_j for the plain MLP modes (SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms), k_mlp_wide for the fused
-// mask head, whose first layer is bound by the texture path rather than by the vector work the new kernel hides (7.45 vs 7.55 ms).
+// Which forward kernel: SN_WIDE_JIT=0 -> k_mlp_wide everywhere, =1 / unset -> k_mlp_wide_j (same-library A/B; read on every call):
+// SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms, 400x400 mask render 7.49 -> 7.13 ms (fused mask head: ray-major tiles, lanes
+// n / n + 32 sharing the corner rows of a sample; with fewer than 4 samples per ray the head keeps k_mlp_wide<3>).
 static bool wide_jit(int xmode) {
     const char *e = getenv("SN_WIDE_JIT");
+    (void)xmode;
     if (e) return atoi(e) != 0;
-    return SN_WIDE_JIT != 0 && xmode != 3;
+    return SN_WIDE_JIT != 0;
 }
 
 static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) {
@@ -1586,7 +1629,7 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mlp_wide: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
     const uint32_t nl = mlp->num_layers, din = mlp->dims[0];
     hipStream_t st = (hipStream_t)stream;
-    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0;
+    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0; pa.pair_ks = 0;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         pa.w[l] = mlp->weight[l];
@@ -1672,7 +1715,7 @@ extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_ou
     if (rc) return rc;
     SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mlp_wide_backward: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
     hipStream_t st = (hipStream_t)stream;
-    pa.din = b.dims[0]; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 1;
+    pa.din = b.dims[0]; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 1; pa.pair_ks = 0;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         pa.w[l] = b.weight[l];
@@ -1727,6 +1770,7 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     const uint32_t nl = mlp->num_layers;
     SN_REQUIRE(mlp->dims[0] == grid->L * 8u + E, "mask_head: mlp input width %u != %u grid features + %u appended", mlp->dims[0], grid->L * 8u, E);
     SN_REQUIRE((grid->L & 1u) == 0u || E == 0u, "mask_head: an odd number of levels cannot be followed by appended channels");
+    SN_REQUIRE((uint64_t)grid->offsets[grid->L] * 8u < (1ull << 32), "mask_head: table too large for 32-bit row offsets");
     PackArgs pa;
     size_t u4 = 0;
     int rc = wide_plan(mlp, pa.layer, &u4);
@@ -1741,6 +1785,8 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     const uint32_t rows = (uint32_t)rows64, width = mlp->dims[0];
     hipStream_t st = (hipStream_t)stream;
     pa.din = width; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0;
+    const bool jit3 = wide_jit(3) && T >= 4u;       // (T is a power of two: the ray-major tiling needs 4 samples of a ray per tile)
+    pa.pair_ks = jit3 ? (grid->L + 1u) >> 1 : 0u;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         pa.w[l] = mlp->weight[l];
@@ -1766,9 +1812,9 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     rc = build_grid_levels(&wa.g, grid->offsets, grid->D, grid->C, grid->L, grid->S, grid->H, grid->gridtype, (int)grid->align_corners, grid->interp);
     if (rc) return rc;
     const size_t lds = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 4u * SN_MAX_LEVELS * sizeof(uint32_t);
-    if (wide_jit(3)) {
+    if (jit3) {          // a workgroup = 32 consecutive rays, all their samples (T / 4 tiles of 128 rows)
         SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mlp_wide_j<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);
+        hipLaunchKernelGGL(k_mlp_wide_j<3>, dim3(div_up(N, 32u)), dim3(256), lds, st, wa);
     } else {
         SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_mlp_wide<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);

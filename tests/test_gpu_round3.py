@@ -425,8 +425,10 @@ def test_wide_mlp_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, din, do
 
 
 @pytest.mark.parametrize("N,T_,n_inst,L", [(300, 32, 2, 16), (37, 128, 3, 16), (64, 16, 32, 16), (100, 8, 2, 6)])
-def test_fused_mask_head_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, N, T_, n_inst, L):
-    """The same for the fused mask head (grid gathers as the first layer's operands, compositing epilogue)."""
+def test_fused_mask_head_just_in_time_kernel_agrees(gpu, monkeypatch, N, T_, n_inst, L):
+    """The fused mask head in k_mlp_wide_j<3>: lanes n and n + 32 share the corner rows of sample n (each fetches one 16-byte half of the
+    rows of both levels of a k-step: half the rows per gather instruction), which permutes the first layer's input columns inside a
+    k-step -- same products, another summation order within 16 terms: round-off agreement with k_mlp_wide<3>, not bit identity."""
     from sanerf_hq_amd import raymarching as rm
     from sanerf_hq_amd.gridencoder import GridEncoder
     from sanerf_hq_amd.nerf.network import SkipConnMLP
@@ -443,4 +445,4 @@ def test_fused_mask_head_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, 
     a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
     monkeypatch.setenv("SN_WIDE_JIT", "1")
     b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
-    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
