@@ -200,6 +200,11 @@ typedef struct sn_render_cfg {
     uint32_t     num_steps[SN_MAX_STAGES];
     sn_grid_desc prop_grid[SN_MAX_STAGES];  /* stages 0..num_stages-2 (network.py:131-143) */
     sn_mlp_desc  prop_mlp[SN_MAX_STAGES];
+    /* The field.  Two last-stage kernels exist: the reference network's own sizes (network.py:93-98: L=16, level_dim 2,
+     * 32-64-64-16 and 31-32-32-3 bias-free ReLU MLPs) run on the matrix cores; any OTHER field of the same structure
+     * (renderer.py:221-357 is size-agnostic) -- 3-D grid with level_dim 2 and <= 64 features, bias-free ReLU MLPs of <= 4
+     * layers and <= 64 neurons, grid_mlp -> [sigma_raw | <= 31 geometry channels], view_mlp input = geometry channels + 16 SH
+     * values, 3 outputs -- runs in a size-agnostic kernel (fp32 fmaf chains).  Other fields: SN_ERR_UNSUPPORTED. */
     sn_grid_desc grid;                      /* network.py:93 */
     sn_mlp_desc  grid_mlp;                  /* network.py:94: -> [sigma_raw | geo_feat] */
     sn_mlp_desc  view_mlp;                  /* network.py:98: per ray, after compositing */
