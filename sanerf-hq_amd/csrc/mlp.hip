@@ -902,18 +902,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #ifndef SN_WIDE_REFILL_LATE
 #define SN_WIDE_REFILL_LATE 0 // where the four DMA pieces of chunk g+4 are issued: 0 = right after the barrier (tile 6), 1 = behind the last tile's MFMAs,
 #endif                        // 2 = one between / two behind the three MFMAs of the last tile.  Measured per h k-step: 1110 / 1160 / 1260 cycles
-#ifndef SN_WIDE_NT
-#define SN_WIDE_NT 0         // cache policy of the fused mask head's gathers (experiments, see issue_pair)
-#endif
 #ifndef SN_WIDE_JV
 #define SN_WIDE_JV 8         // vector instructions the scheduler may place behind each MFMA of a tile
 #endif
 
-typedef float floatx4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float *p) {      // 16-byte load with the non-temporal cache policy
-    const floatx4v v = __builtin_nontemporal_load(reinterpret_cast<const floatx4v *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
 template <bool B> struct bool_tag { static constexpr bool value = B; };
 template <int N> struct int_tag { static constexpr int value = N; };
 // compile-time loop: f(int_tag<0>{}) ... f(int_tag<N-1>{}).  (`#pragma unroll` is a request: the 16 k-steps of a layer came back as a
@@ -1233,9 +1225,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         uint32_t cell[3];
         grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, pos, deriv, cell);
         const float *tabh = a.table + 4u * half;                        // this lane's half of every row
-#if SN_WIDE_NT == 2
-        const bool ntA = (a.g.mode[umin(2u * kx, a.g.L - 1u)] & 1u) != 0u, ntB = (a.g.mode[umin(2u * kx + 1u, a.g.L - 1u)] & 1u) != 0u;
-#endif
 #pragma unroll
         for (uint32_t idx = 0; idx < 8u; ++idx) {
             uint32_t q[3];
@@ -1249,18 +1238,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             const auto po = __builtin_amdgcn_permlane32_swap(off, off, false, false);                                   // [A | A], [B | B]
             const auto pw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
             r.wA[idx] = __uint_as_float(pw[0]); r.wB[idx] = __uint_as_float(pw[1]);
-#if SN_WIDE_NT == 1             // experiment: every gather non-temporal
-            r.rA[idx] = nt_load4(tabh + po[0]);
-            r.rB[idx] = nt_load4(tabh + po[1]);
-#elif SN_WIDE_NT == 2           // experiment: the hashed levels' rows (used once) non-temporal, the dense levels' rows (shared by all rays) cached
-            if (ntA) r.rA[idx] = nt_load4(tabh + po[0]);
-            else r.rA[idx] = *reinterpret_cast<const float4 *>(tabh + po[0]);
-            if (ntB) r.rB[idx] = nt_load4(tabh + po[1]);
-            else r.rB[idx] = *reinterpret_cast<const float4 *>(tabh + po[1]);
-#else
             r.rA[idx] = *reinterpret_cast<const float4 *>(tabh + po[0]);
             r.rB[idx] = *reinterpret_cast<const float4 *>(tabh + po[1]);
-#endif
         }
     };
     auto blend_pair = [&](const PairRegs &r, int first, int last, float (&v)[8]) {

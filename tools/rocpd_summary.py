@@ -61,7 +61,7 @@ def pmc(db):
     for r in rows:
         agg[short(r[ki])][r[ci]].append(r[vi])
     for k, cs in agg.items():
-        if not any(t in k for t in ("k_final", "k_prop", "k_pack")):
+        if not any(t in k for t in ("k_final", "k_prop", "k_pack", "k_mlp_wide", "k_feat")):
             continue
         for c, v in sorted(cs.items()):
             print(f"{k:30s} {c:28s} dispatches={len(v):4d} mean={sum(v) / len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
