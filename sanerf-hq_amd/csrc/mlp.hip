@@ -913,6 +913,15 @@ template <int N> struct int_tag { static constexpr int value = N; };
 template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(int_tag<Is>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// four LDS-DMA pieces of one wave with ONE m0 write and one address: the instruction offset applies to the global and to the LDS address
+// alike, so a wave copies 4 KiB that are contiguous in both (k_mlp_wide gives a wave four pieces 4 KiB apart: four m0 writes, four
+// addresses -- ~100 cycles of issue per k-step on an in-order wave)
+__device__ __forceinline__ void dma16x4(const void *gptr, uint32_t lds_byte_offset_uniform) {
+    const uint32_t base = __builtin_amdgcn_readfirstlane(lds_byte_offset_uniform);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" : : "v"(gptr), "s"(base) : "memory");
+}
+
 template <int XMODE>
 __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     static_assert(XMODE >= 0 && XMODE <= 3, "the backward mode keeps k_mlp_wide");
@@ -1004,15 +1013,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     uint32_t g = 0;                        // chunks consumed so far
     const uint32_t tile_chunks = a.total_chunks;
     const uint32_t total_chunks = tile_chunks * ntiles;     // the workgroup's whole stream: the packed weights, once per tile, back to back
-    const uint32_t lds_w_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_w) + wave * 1024u;
+    const uint32_t lds_w_off4 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void *)lds_w) + wave * 4096u;   // a wave's 4 KiB of every chunk
     constexpr uint32_t CHUNK_BYTES = WIDE_CHUNK_U4 * sizeof(uint4);
     constexpr int PIECES = WIDE_CHUNK_U4 / 256;
 #pragma unroll
     for (uint32_t c = 0; c < (uint32_t)WIDE_NBUF - 1u; ++c) {
         if (c < total_chunks) {
-            const uint4 *src = a.pack + (size_t)(c % tile_chunks) * WIDE_CHUNK_U4 + tid;
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) dma16(src + i * 256, lds_w_off + c * CHUNK_BYTES + (uint32_t)i * 4096u);
+            dma16x4(a.pack + (size_t)(c % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane, lds_w_off4 + c * CHUNK_BYTES);
         }
     }
     if constexpr (XMODE == 2) {          // the input tile's pieces were issued first and the counter retires in order (k_mlp_wide)
@@ -1045,26 +1052,20 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #endif
 #if SN_WIDE_REFILL_LATE == 0
         if (gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
-            const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + tid;
-            const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+            dma16x4(a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane, lds_w_off4 + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES);
         }
 #endif
     };
     // refill the buffer chunk gn-1 was read from (every wave passed the barrier above after its last read of it) with chunk gn+3.
     // Issued BEHIND the last tile's MFMAs: the four pieces cost ~100 cycles of address / m0 set-up that used to sit between two tiles
     auto refill_piece = [&](uint32_t gn, int i) {
-        const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + tid;
-        const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
-        dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+        const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane;
+        const uint32_t ndst = lds_w_off4 + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
+        dma16(nsrc + i * 64, ndst + (uint32_t)i * 1024u);
     };
     auto refill = [&](uint32_t gn) {
         if (SN_WIDE_REFILL_LATE == 1 && gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
-            const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + tid;
-            const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
+            dma16x4(a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane, lds_w_off4 + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES);
         }
     };
     auto prefetch_first_pair = [&](uint32_t gn) {

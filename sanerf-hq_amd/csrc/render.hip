@@ -2058,7 +2058,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
 // same STRUCTURE -- hash / tiled grid with level_dim 2 (up to 16 levels), bias-free ReLU grid_mlp -> [sigma_raw | geo_feat],
 // trunc_exp, compositing, degree-4 SH of the view direction, bias-free ReLU view_mlp, sigmoid -- with up to 4 layers per
 // MLP, layers up to 64 wide and up to 31 geometry channels.  One lane = one ray as everywhere; a lane's activations live in
-// its own LDS columns ([row][256 lanes]: 64 + 64 ping-pong rows + 32 compositing rows = 160 floats per lane = all 160 KiB),
+// its own LDS columns ([row][256 lanes]: two ping-pong buffers of 16 / 32 / 64 rows + the compositing rows; 160 KiB at the widest),
 // the weights are wave-uniform and come through the scalar cache, every neuron is one k-ascending fmaf chain and the grid
 // blend is k_grid_forward's (grid.hip) -- i.e. the oracle's arithmetic in the oracle's order.  No matrix cores: a field
 // this small is bound by its launch, and the proposal stages in front of it (if the field has the reference's) stay fused.
@@ -2066,24 +2066,64 @@ struct AnyShape {
     uint32_t ng, nv;               // linear layers of grid_mlp / view_mlp
     uint32_t dg[5], dv[5];         // widths: dg[0] = L * 2 ... dg[ng] = 1 + geo;  dv[0] = geo + 16 ... dv[nv] = 3
     const float *wg[4], *wv[4];    // nn.Linear.weight [out][in]
+    uint32_t rows;                 // LDS rows per activation buffer (16 / 32 / 64); 2 * rows + geo rows of 256 floats in all
 };
 constexpr uint32_t ANY_W = 64, ANY_GEO = 31, ANY_LAYERS = 4;
-constexpr uint32_t ANY_LDS_FLOATS = (2u * ANY_W + ANY_GEO + 1u) * 256u;
 
-__device__ __forceinline__ void dense_any(const float *__restrict__ W, uint32_t in, uint32_t out, bool relu, const float *xin, float *yout) {
-    for (uint32_t o = 0; o < out; ++o) {
-        const float *w = W + (size_t)o * in;
-        float acc = 0.0f;
-        for (uint32_t k = 0; k < in; ++k) acc = __builtin_fmaf(w[k], xin[k * 256u], acc);
-        if (relu) acc = __builtin_fmaxf(acc, 0.0f);
-        yout[o * 256u] = acc;
+// one layer: the lane's inputs come out of its LDS column ONCE into registers (a first version read them inside the k loop: one LDS round
+// trip per multiply-add, 2.2 ms for a 64x64 image of the configs[0] field); the weights are wave-uniform (scalar loads, 8 at a time); the k
+// loop is unrolled for the bucket INB >= in, whole groups of 8 beyond `in` are skipped, a partial group multiplies clamped weights by 0 --
+// fmaf(0, x, acc) = acc -- so every neuron is still the oracle's k-ascending chain
+template <int INB>
+__device__ __forceinline__ void dense_any_b(const float *__restrict__ W, uint32_t in, uint32_t out, bool relu, const float *xin, float *yout) {
+    float x[INB];
+#pragma unroll
+    for (int k = 0; k < INB; ++k) x[k] = xin[(uint32_t)k * 256u];          // rows beyond `in` exist (buffers hold the bucket) and meet weight 0
+    // four neurons at a time: their scalar weight loads are in flight together and their four chains interleave (one wave per SIMD when the
+    // batch is small: a single dependent chain would run at the latency of every instruction)
+    for (uint32_t o0 = 0; o0 < out; o0 += 4u) {
+        const float *w[4];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) w[q] = W + (size_t)umin(o0 + q, out - 1u) * in;      // (a tail group repeats the last neuron: not stored)
+#pragma unroll
+        for (int g = 0; g < INB / 8; ++g) {
+            if (8u * (uint32_t)g < in) {
+                if (8u * (uint32_t)g + 8u <= in) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (uint32_t q = 0; q < 4u; ++q) acc[q] = __builtin_fmaf(w[q][8 * g + j], x[8 * g + j], acc[q]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t kk = 8u * (uint32_t)g + (uint32_t)j;
+#pragma unroll
+                        for (uint32_t q = 0; q < 4u; ++q) {
+                            const float wk = w[q][kk < in ? kk : in - 1u];
+                            acc[q] = __builtin_fmaf(kk < in ? wk : 0.0f, x[8 * g + j], acc[q]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            if (o0 + q < out) yout[(o0 + q) * 256u] = relu ? __builtin_fmaxf(acc[q], 0.0f) : acc[q];
+        }
     }
+}
+__device__ __forceinline__ void dense_any(const float *__restrict__ W, uint32_t in, uint32_t out, bool relu, const float *xin, float *yout) {
+    if (in <= 16u) dense_any_b<16>(W, in, out, relu, xin, yout);
+    else if (in <= 32u) dense_any_b<32>(W, in, out, relu, xin, yout);
+    else dense_any_b<64>(W, in, out, relu, xin, yout);
 }
 
 template <typename TT>
-__global__ __launch_bounds__(256, 1) void k_final_stage_any(FinalArgs a, AnyShape s) {
+__global__ __launch_bounds__(256) void k_final_stage_any(FinalArgs a, AnyShape s) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *bufA = lds + threadIdx.x, *bufB = lds + ANY_W * 256u + threadIdx.x, *accf = lds + 2u * ANY_W * 256u + threadIdx.x;
+    const uint32_t rows = s.rows;                      // rows of a ping-pong buffer: the widest layer, rounded up to the unroll bucket
+    float *bufA = lds + threadIdx.x, *bufB = lds + rows * 256u + threadIdx.x, *accf = lds + 2u * rows * 256u + threadIdx.x;
     uint32_t n;
     const uint32_t wg = tile_id(a.rc);
     const bool ok = ray_of_lane(a.rc, wg, n);
@@ -2118,33 +2158,42 @@ __global__ __launch_bounds__(256, 1) void k_final_stage_any(FinalArgs a, AnyShap
         const float tmid = (rb_next + rb_prev) / 2.0f;
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
-        // ---- grid features: gridencoder.cu:94-201 as k_grid_forward states it ----
+        // ---- grid features: gridencoder.cu:94-201 as k_grid_forward states it; four levels' rows requested before the first blend ----
         const bool oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
-        for (uint32_t l = 0; l < L; ++l) {
-            float acc[2] = {0.0f, 0.0f};
-            if (!oob) {
+        for (uint32_t l0 = 0; l0 < L; l0 += 4u) {
+            float pos[4][3], v[4][8][2];
+#pragma unroll
+            for (uint32_t gi = 0; gi < 4u; ++gi) {
+                const uint32_t l = umin(l0 + gi, L - 1u);                   // (a group's tail repeats the last level: fetched, not stored)
                 const uint32_t res = a.g.res[l], size = a.g.size[l], mode = a.g.mode[l];
                 const TT *tab = table + (size_t)a.g.off[l] * 2u;
-                float pos[3], deriv[3];
+                float deriv[3];
                 uint32_t cell[3];
-                grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, pos, deriv, cell);
+                grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, pos[gi], deriv, cell);
+#pragma unroll
+                for (uint32_t idx = 0; idx < 8u; ++idx) {
+                    uint32_t q[3];
+#pragma unroll
+                    for (uint32_t d = 0; d < 3u; ++d) q[d] = (idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
+                    load_row<TT, 2>(tab + (size_t)grid_row<3>(q, res, size, mode) * 2u, v[gi][idx]);
+                }
+            }
+#pragma unroll
+            for (uint32_t gi = 0; gi < 4u; ++gi) {
+                float acc[2] = {0.0f, 0.0f};
 #pragma unroll
                 for (uint32_t idx = 0; idx < 8u; ++idx) {
                     float w = 1.0f;
-                    uint32_t q[3];
 #pragma unroll
-                    for (uint32_t d = 0; d < 3u; ++d) {
-                        if ((idx & (1u << d)) == 0u) { w *= 1.0f - pos[d]; q[d] = cell[d]; }
-                        else { w *= pos[d]; q[d] = umin(cell[d] + 1u, res - 1u); }
-                    }
-                    float v[2];
-                    load_row<TT, 2>(tab + (size_t)grid_row<3>(q, res, size, mode) * 2u, v);
-                    acc[0] = __builtin_fmaf(w, v[0], acc[0]);
-                    acc[1] = __builtin_fmaf(w, v[1], acc[1]);
+                    for (uint32_t d = 0; d < 3u; ++d) w *= (idx & (1u << d)) ? pos[gi][d] : 1.0f - pos[gi][d];
+                    acc[0] = __builtin_fmaf(w, v[gi][idx][0], acc[0]);
+                    acc[1] = __builtin_fmaf(w, v[gi][idx][1], acc[1]);
+                }
+                if (l0 + gi < L) {
+                    bufA[(2u * (l0 + gi)) * 256u] = oob ? 0.0f : acc[0];
+                    bufA[(2u * (l0 + gi) + 1u) * 256u] = oob ? 0.0f : acc[1];
                 }
             }
-            bufA[(2u * l) * 256u] = acc[0];
-            bufA[(2u * l + 1u) * 256u] = acc[1];
         }
         // ---- grid_mlp (network.py:146-153): the lane's own LDS columns, in -> out ping-pong ----
         float *xin = bufA, *xout = bufB;
@@ -3463,6 +3512,10 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             for (uint32_t l = 0; l <= vm->num_layers; ++l) any_shape.dv[l] = vm->dims[l];
             for (uint32_t l = 0; l < gm->num_layers; ++l) any_shape.wg[l] = gm->weight[l];
             for (uint32_t l = 0; l < vm->num_layers; ++l) any_shape.wv[l] = vm->weight[l];
+            uint32_t wmax = 0;
+            for (uint32_t l = 0; l <= gm->num_layers; ++l) wmax = gm->dims[l] > wmax ? gm->dims[l] : wmax;
+            for (uint32_t l = 0; l <= vm->num_layers; ++l) wmax = vm->dims[l] > wmax ? vm->dims[l] : wmax;
+            any_shape.rows = wmax <= 16u ? 16u : wmax <= 32u ? 32u : 64u;
         }
     }
     if (!is_main && !is_any) {
@@ -3676,7 +3729,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             const uint32_t geo = any_shape.dg[any_shape.ng] - 1u;
             fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * geo : nullptr;
             fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * (geo + 16u) : nullptr;
-            const size_t lds_bytes = (size_t)ANY_LDS_FLOATS * sizeof(float);
+            const size_t lds_bytes = (size_t)(2u * any_shape.rows + geo) * 256u * sizeof(float);
             if (f16) {
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_any<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL(k_final_stage_any<__half>, dim3(nblk), dim3(256), lds_bytes, st, fa, any_shape);

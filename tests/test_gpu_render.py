@@ -369,6 +369,7 @@ def test_config1_small_field_through_the_fused_call_and_the_operator_chain(gpu, 
     assert not unexpected and all(m.endswith("offsets") or m.startswith("aabb") for m in missing), (missing, unexpected)
     model = model.to(gpu).eval()
     assert model._fused_kind() == "any"
+    model.fused_min_rays = 0              # (by default a 4096-ray batch of such a field takes the operator chain: faster below ~16 k rays)
     H, W = [int(v) for v in g["HW"]]
     ro, rd = rm.generate_rays(g["pose"], synth.pinhole_intrinsics(H, W), H, W, device=gpu)
     with torch.no_grad():

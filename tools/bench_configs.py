@@ -39,6 +39,47 @@ def build(heads_sam, heads_mask, dev):
     return model.to(dev)
 
 
+def c1_entry(dev):
+    from sanerf_hq_amd.activation import trunc_exp
+    from sanerf_hq_amd.encoding import get_encoder
+    from sanerf_hq_amd.nerf.network import MLP
+    from sanerf_hq_amd.nerf.renderer import NeRFRenderer
+
+    class C1Field(NeRFRenderer):
+        def __init__(self, opt):
+            super().__init__(opt)
+            self.grid, d = get_encoder("hashgrid", input_dim=3, level_dim=2, num_levels=8, log2_hashmap_size=14, desired_resolution=2048)
+            self.grid_mlp = MLP(d, 16, 32, 2, bias=False)
+            self.view_encoder, vd = get_encoder("sh", input_dim=3, degree=4)
+            self.view_mlp = MLP(15 + vd, 3, 32, 2, bias=False)
+
+        def forward(self, x, d, **kw):
+            f = self.grid_mlp(self.grid(x, bound=self.bound))
+            return dict(sigma=trunc_exp(f[..., 0]), geo_feat=f[..., 1:], color=torch.cat([f[..., 1:], self.view_encoder(d)], -1), grid_output=None)
+
+    torch.manual_seed(5)
+    model = C1Field(make_opt(num_steps=[32])).to(dev).eval()
+    model.fused_min_rays = 0              # measure the fused call at both sizes (by default batches below 16 384 rays take the chain)
+    with torch.no_grad():
+        model.grid.embeddings.uniform_(-1.0, 1.0)
+    res = {}
+    for H in (64, 400):
+        ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, H), H, H, device=dev)
+
+        def render():
+            with torch.no_grad():
+                return model.render(ro, rd, staged=False, perturb=False, H=H, W=H, tile_w=H)
+        model.standard_field = True
+        t_f = timeit(render)
+        img = render()["image"].clone()
+        model.standard_field = False
+        t_c = timeit(render)
+        d = float((render()["image"] - img).abs().max())
+        res[f"{H}x{H}"] = {"ms_fused_call": round(t_f * 1e3, 3), "ms_operator_chain": round(t_c * 1e3, 3), "rays_per_s_fused": round(H * H / t_f, 1),
+                           "image_max_abs_diff": d}
+    return res
+
+
 def main():
     dev = torch.device("cuda:0")
     out = {}
@@ -56,6 +97,9 @@ def main():
     out["C3_sam_head_400x400"] = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
     del model
     torch.cuda.empty_cache()
+    # ---- C1 = BASELINE configs[0] (64x64, L=8 T=2^14 grid, 16-32-16 / 31-32-3 MLPs, 32 samples per ray) on the GPU: the fused call
+    #      (size-agnostic last stage, k_final_stage_any) vs the stage loop over the stand-alone operators; also at 400x400 ----
+    out["C1_small_field"] = c1_entry(dev)
     # ---- mask head at inference (renderer.py:304-305, 376-385): 400x400, [128,64,32]: the one-kernel head vs the three-kernel route ----
     model = build(False, True, dev).eval()
 

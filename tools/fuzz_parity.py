@@ -22,7 +22,65 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def main_any():
+    """python tools/fuzz_parity.py any [cases] [seed]: random fields of OTHER sizes than the reference network's (levels, table size, MLP depths and
+    widths, geometry channels) through the size-agnostic last stage (k_final_stage_any) behind the fused proposal stages, against the oracle."""
+    from sanerf_hq_amd.encoding import get_encoder
+    from sanerf_hq_amd.nerf.network import MLP
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        S = int(rng.integers(1, 4))
+        steps = [int(rng.integers(3, 70)) for _ in range(S)]
+        H, W = int(rng.integers(5, 40)), int(rng.integers(5, 40))
+        f16 = bool(rng.integers(0, 2))
+        L, log2T = int(rng.integers(1, 17)), int(rng.integers(10, 20))
+        geo = int(rng.integers(1, 32))
+        ng, nv = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        hid, vhid = int(rng.integers(4, 65)), int(rng.integers(4, 65))
+        params = synthetic_params(steps, seed=3000 + c)
+        model = product_model(params, steps, False, dev)
+        torch.manual_seed(seed * 1000 + c)
+        model.grid, d = get_encoder("hashgrid" if rng.integers(0, 4) else "tiledgrid", input_dim=3, level_dim=2, num_levels=L, log2_hashmap_size=log2T,
+                                    desired_resolution=int(rng.integers(64, 4096)))
+        model.grid_mlp = MLP(d, 1 + geo, hid, ng, bias=False)
+        model.view_mlp = MLP(geo + 16, 3, vhid, nv, bias=False)
+        model.geom_feat_dim = geo
+        model = model.to(dev).eval()
+        with torch.no_grad():
+            model.grid.embeddings.uniform_(-1.0, 1.0)
+            for lin in list(model.grid_mlp.net) + list(model.view_mlp.net):
+                lin.weight.mul_(float(rng.uniform(1.0, 4.0)))
+        assert model._fused_kind() == "any", model._fused_kind()
+        _, _, ro, rd = camera_rays(orc, H, W, radius=float(rng.uniform(0.4, 2.5)), elev=float(rng.uniform(-60, 70)), azim=float(rng.uniform(0, 360)))
+        plan = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32)
+        tiled = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=W, want=("inds",)).items()}
+        linear = rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=0, out={}, want=("inds",))
+        cfg = oracle_cfg(orc, params, steps, table_f16=f16)
+        emb = model.grid.embeddings.detach().cpu().numpy()
+        cfg.grid = orc.make_grid(emb.astype(np.float16) if f16 else emb, model.grid.offsets.cpu().numpy(), model.grid.per_level_scale, model.grid.base_resolution,
+                                 gridtype=model.grid.gridtype_id, keep=cfg._keep)
+        cfg.grid_mlp = orc.make_mlp([l.weight.detach().cpu().numpy() for l in model.grid_mlp.net], keep=cfg._keep)
+        cfg.view_mlp = orc.make_mlp([l.weight.detach().cpu().numpy() for l in model.view_mlp.net], keep=cfg._keep)
+        want = orc.render(cfg, ro, rd, debug=True)
+        same_order = all(torch.equal(tiled[k], linear[k]) for k in tiled)
+        inds_ok = all(np.array_equal(tiled[f"inds{k}"].cpu().numpy(), want[f"inds{k}"]) for k in range(1, S))
+        e_img = float(np.abs(tiled["image"].cpu().numpy() - want["image"]).max())
+        e_ws = float(np.abs(tiled["weights_sum"].cpu().numpy() - want["weights_sum"]).max())
+        ok = same_order and inds_ok and e_img <= 1e-5 and e_ws <= 2e-6
+        print(f"case {c}: steps={steps} {H}x{W} f16={f16} L={L} T=2^{log2T} grid_mlp {2 * L}-{hid}x{ng - 1}-{1 + geo} view_mlp {geo + 16}-{vhid}x{nv - 1}-3  "
+              f"dRGB={e_img:.1e} dwsum={e_ws:.1e} tiled==linear:{same_order} inds:{inds_ok}  {'ok' if ok else 'MISMATCH'}")
+        bad += 0 if ok else 1
+    print("mismatching cases:", bad)
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "any":
+        return main_any()
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dev = torch.device("cuda:0")
