@@ -294,3 +294,32 @@ def test_round2_host_logic_has_no_cpu_fallback():
     assert not rm.mask_head_fusable(enc, mlp, 32, 14)                                   # input width does not match
     with pytest.raises(RuntimeError, match="CUDA"):
         rm.mask_head(torch.zeros(2, 32), torch.zeros(2, 32, 3), torch.zeros(2, 32, 15), enc, mlp, 2.0)
+
+
+def test_fused_route_selection_is_host_logic():
+    """NeRFRenderer._fused_kind(): which last-stage kernel (if any) sn_rm_render_rays has for a field -- the reference network's own sizes
+    ("main"), another field of the same structure within the size-agnostic kernel's limits ("any": BASELINE configs[0]), or neither (the
+    operator chain: a non-standard forward(), biases, layers wider than 64, another level_dim)."""
+    from sanerf_hq_amd.encoding import get_encoder
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    from sanerf_hq_amd.nerf.network import MLP
+    from sanerf_hq_amd.nerf.renderer import NeRFRenderer
+    from sanerf_hq_amd.synth import make_opt
+    assert NeRFNetwork(make_opt(num_steps=[128, 64, 32]))._fused_kind() == "main"
+
+    class Small(NeRFRenderer):
+        def __init__(self, opt, level_dim=2, hidden=32, bias=False):
+            super().__init__(opt)
+            self.grid, d = get_encoder("hashgrid", input_dim=3, level_dim=level_dim, num_levels=8, log2_hashmap_size=14, desired_resolution=2048)
+            self.grid_mlp = MLP(d, 16, hidden, 2, bias=bias)
+            self.view_encoder, vd = get_encoder("sh", input_dim=3, degree=4)
+            self.view_mlp = MLP(15 + vd, 3, 32, 2, bias=False)
+
+    m = Small(make_opt(num_steps=[32]))
+    assert m._fused_kind() == "any" and m._fused_shape() and m.fused_min_rays == 16384
+    m.standard_field = False
+    assert m._fused_kind() is None and not m._fused_shape()
+    assert Small(make_opt(num_steps=[32]), hidden=96)._fused_kind() is None           # wider than the kernel's 64
+    assert Small(make_opt(num_steps=[32]), bias=True)._fused_kind() is None           # biases: not the reference's structure
+    assert Small(make_opt(num_steps=[32]), level_dim=4)._fused_kind() is None         # the size-agnostic kernel is built for level_dim 2
+    assert Small(make_opt(num_steps=[32, 16]))._fused_kind() is None                  # a proposal stage without the reference's proposal networks
