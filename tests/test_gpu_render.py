@@ -482,6 +482,26 @@ def test_config3_full_size_heads_spot_checked(gpu, orc):
     np.testing.assert_allclose(a["instance_mask_logits"][idx].cpu().numpy(), want["instance_mask_logits"], rtol=0, atol=RGB_TOL)
 
 
+def test_config3_full_size_with_fp16_tables(gpu, orc):
+    """BASELINE configs[2] says "same grid" as configs[1], i.e. the fp16 configuration: tables in half like the reference's fp16 mode
+    (grid.py:43-49), arithmetic fp32.  With render_table_dtype = float16 the radiance grid, the proposal grids AND the SAM-feature grid
+    (in-render feature stage) are read as half; 256 random pixels of the 400x400 render against the oracle run on the same rounded tables."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    steps = [128, 64, 32]
+    params = synthetic_params(steps, heads=True, seed=23)
+    model = product_model(params, steps, True, gpu)
+    model.render_table_dtype = torch.float16
+    H = W = 400
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    with torch.no_grad():
+        a = model.render(ro, rd, staged=False, perturb=False, return_feats=1, H=H, W=W, tile_w=W)
+    assert torch.isfinite(a["samvit"]).all() and a["samvit"].shape == (H, W, 256)
+    idx = (synth.hash_u01(256, 19) * (H * W)).astype(np.int64)
+    want = orc.render(oracle_cfg(orc, params, steps, heads=True, table_f16=True), ro[idx].cpu().numpy(), rd[idx].cpu().numpy())
+    np.testing.assert_allclose(a["image"].reshape(-1, 3)[idx].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a["samvit"].reshape(-1, 256)[idx].cpu().numpy(), want["samvit"], rtol=0, atol=RGB_TOL)
+
+
 def test_config5_full_size_training_step_properties(gpu, orc):
     """BASELINE configs[4] at its full size (4096 rays, mask NLL, radiance field frozen): the forward logits of 256 random
     rays against the CPU oracle; the table gradient from the sorted backward against the atomic backward (two independent

@@ -95,6 +95,11 @@ def main():
     with torch.no_grad():
         t_rgb = timeit(lambda: rm.render_rays(model._get_plan(), ro, rd, tile_w=W))
     out["C3_sam_head_400x400"] = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
+    # configs[2] names "same grid" as configs[1] (the fp16 configuration): tables in half (radiance, proposal and SAM-feature grids), arithmetic fp32
+    model.render_table_dtype = torch.float16
+    t16 = timeit(c3)
+    out["C3_sam_head_400x400"].update({"ms_f16_tables": round(t16 * 1e3, 3), "rays_per_s_f16_tables": round(H * W / t16, 1)})
+    model.render_table_dtype = torch.float32
     del model
     torch.cuda.empty_cache()
     # ---- C1 = BASELINE configs[0] (64x64, L=8 T=2^14 grid, 16-32-16 / 31-32-3 MLPs, 32 samples per ray) on the GPU: the fused call
