@@ -305,9 +305,10 @@ int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const fl
 /* Mask head (nerf/renderer.py:304-305, 376-385; network.py:104, 118-123) in one kernel:
  *   out[n, :] = sum_t weights[n,t] * mask_mlp(cat([m_grid(xyzs[n,t]), extra[n,t]]))        out [N, dims[num_layers]]
  * xyzs [N,T,3] (contracted sample positions; x01 = (xyz + bound) / (2 bound) as gridencoder/grid.py:156), extra [N,T,E]
- * (the detached geometry features, E <= 16), weights [N,T].  Every lane of the matrix-core MLP kernel interpolates one
- * level of its own sample straight into the first layer's B operand and the epilogue composites the logits, so neither
- * the [N*T, L*8+E] input nor the [N*T, n_inst] logits are written.  Needs a 3-D fp32 grid with level_dim 8, hidden width
+ * (the detached geometry features, E <= 16), weights [N,T].  The lanes of the matrix-core MLP kernel interpolate the grid
+ * levels of their samples straight into the first layer's B operand and the epilogue composites the logits, so neither
+ * the [N*T, L*8+E] input nor the [N*T, n_inst] logits are written.  (T >= 4: a workgroup walks the samples of 32
+ * consecutive rays -- neighbouring rays at one depth share table lines; rays are expected in image order.)  Needs a 3-D fp32 grid with level_dim 8, hidden width
  * 256, <= 32 outputs, no skip layers, T a power of two <= 128; anything else returns SN_ERR_UNSUPPORTED and the caller
  * composes sn_grid_encode_forward_cat + sn_mlp_wide_forward + sn_rm_composite.  Inference only.  Range of the split-fp16
  * arithmetic as sn_mlp_wide_forward (the overflow flag is not raised by this entry).  workspace >=
