@@ -2078,7 +2078,10 @@ template <int INB>
 __device__ __forceinline__ void dense_any_b(const float *__restrict__ W, uint32_t in, uint32_t out, bool relu, const float *xin, float *yout) {
     float x[INB];
 #pragma unroll
-    for (int k = 0; k < INB; ++k) x[k] = xin[(uint32_t)k * 256u];          // rows beyond `in` exist (buffers hold the bucket) and meet weight 0
+    for (int k = 0; k < INB; ++k) {      // rows beyond `in` exist (buffers hold the bucket) but may hold anything, NaN included: 0 * NaN is NaN, so they read as 0
+        const float t = xin[(uint32_t)k * 256u];
+        x[k] = (uint32_t)k < in ? t : 0.0f;
+    }
     // four neurons at a time: their scalar weight loads are in flight together and their four chains interleave (one wave per SIMD when the
     // batch is small: a single dependent chain would run at the latency of every instruction)
     for (uint32_t o0 = 0; o0 < out; o0 += 4u) {

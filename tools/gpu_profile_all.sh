@@ -57,6 +57,7 @@ SN_AB_STEPS=128 python $root/tools/prop_sp_ab.py 2>/dev/null | tail -1 > $out/sm
 # robustness evidence: every fused path repeated on identical inputs (bit-equal?), random configurations against the oracle
 python $root/tools/stress_determinism.py 30 2>&1 | grep -v amdgpu.ids > $out/stress_determinism.txt
 python $root/tools/fuzz_parity.py 60 31 2>&1 | grep -v amdgpu.ids | tail -12 > $out/fuzz_parity_tail.txt
+python $root/tools/fuzz_parity.py any 150 5 2>&1 | grep -v amdgpu.ids | grep -E "MISMATCH|mismatching|case 1[0-9]:" | cut -c1-300 > $out/fuzz_parity_any.txt
 # un-profiled numbers
 cd $root
 python tools/bench_configs.py 2>/dev/null | tail -1 > $out/bench_configs.json
