@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised check of the head-MLP kernels (not part of the test suite: python tools/fuzz_wide.py [cases] [seed] on the GPU box).
+Per case a random SkipConnMLP / MLP-like stack (input width 1..700, 1..8 layers, skip layers, bias, output width 1..256, optional LayerNorm,
+1..5000 rows): k_mlp_wide_j must equal k_mlp_wide bit for bit and agree with the torch module to 1e-4; and a random fused mask head (levels,
+table size, appended channels, samples per ray, outputs, positions partly outside the box): the two kernels agree to round-off and with the
+unfused composition (grid_encode -> torch MLP -> weighted sum) to 1e-4."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sanerf_hq_amd import raymarching as rm  # noqa: E402
+from sanerf_hq_amd.gridencoder import GridEncoder  # noqa: E402
+from sanerf_hq_amd.nerf.network import SkipConnMLP  # noqa: E402
+
+
+def both(fn):
+    os.environ["SN_WIDE_JIT"] = "0"
+    a = fn()
+    os.environ["SN_WIDE_JIT"] = "1"
+    b = fn()
+    return a, b
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        torch.manual_seed(seed * 100003 + c)
+        nl = int(rng.integers(1, 9))
+        din = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 300)), int(rng.integers(300, 701))]))
+        dout = int(rng.choice([int(rng.integers(1, 65)), int(rng.integers(65, 257)), 256]))
+        skips = sorted(set(int(v) for v in rng.integers(1, max(nl, 2), size=int(rng.integers(0, 3))) if v < nl)) if nl > 1 else []
+        bias = bool(rng.integers(0, 2))
+        N = int(rng.choice([int(rng.integers(1, 130)), int(rng.integers(130, 5000))]))
+        mlp = SkipConnMLP(din, dout, 256, nl, skip_layers=skips, bias=bias).to(dev)
+        ln = torch.nn.LayerNorm(dout).to(dev) if rng.integers(0, 2) else None
+        x = torch.randn(N, din, device=dev)
+        a, b = both(lambda: rm.mlp_forward(x, mlp, ln))
+        with torch.no_grad():
+            ref = mlp(x) if ln is None else ln(mlp(x))
+        err = float((b - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        ok = bool(torch.equal(a, b)) and bool(torch.isfinite(b).all()) and err <= 1e-4
+        print(f"mlp {c}: {din}-256x{nl - 1}-{dout} skips={skips} bias={bias} ln={ln is not None} N={N}  bit-equal:{bool(torch.equal(a, b))} vs torch {err:.1e}  {'ok' if ok else 'MISMATCH'}")
+        bad += 0 if ok else 1
+        # fused mask head
+        L = int(rng.integers(1, 17))
+        E = int(rng.integers(0, 17)) if L % 2 == 0 else 0
+        T = int(2 ** rng.integers(0, 8))
+        n_inst = int(rng.integers(1, 33))
+        R = int(rng.integers(1, 400))
+        enc = GridEncoder(input_dim=3, num_levels=L, level_dim=8, base_resolution=16, log2_hashmap_size=int(rng.integers(10, 18)), desired_resolution=int(rng.integers(32, 2048))).to(dev)
+        with torch.no_grad():
+            enc.embeddings.uniform_(-1.0, 1.0)
+        head = SkipConnMLP(L * 8 + E, n_inst, 256, 3, skip_layers=[], bias=False).to(dev)
+        xyz = torch.rand(R, T, 3, device=dev) * 2.2 - 1.1
+        extra = torch.randn(R, T, E, device=dev) if E else None
+        w = torch.rand(R, T, device=dev)
+        a, b = both(lambda: rm.mask_head(w, xyz, extra if E else torch.zeros(R, T, 0, device=dev), enc, head, 1.0))
+        with torch.no_grad():
+            feats = enc(xyz.reshape(-1, 3), bound=1.0)
+            inp = torch.cat([feats, extra.reshape(-1, E)], -1) if E else feats
+            ref = (head(inp).reshape(R, T, n_inst) * w[..., None]).sum(1)
+        scale = max(1.0, float(ref.abs().max()))
+        e_ab, e_ref = float((a - b).abs().max()) / scale, float((b - ref).abs().max()) / scale
+        ok = bool(torch.isfinite(b).all()) and e_ab <= 2e-6 and e_ref <= 1e-4
+        print(f"head {c}: L={L} E={E} T={T} n_inst={n_inst} rays={R}  kernels agree {e_ab:.1e} vs unfused {e_ref:.1e}  {'ok' if ok else 'MISMATCH'}")
+        bad += 0 if ok else 1
+    print("mismatching cases:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
