@@ -241,7 +241,8 @@ class NeRFRenderer(nn.Module):
         kind = self._fused_kind()
         # the size-agnostic last stage gives a ray to one lane for all its samples: below ~16 k rays the chip is mostly idle and the operator
         # chain, which spreads the SAMPLES over the lanes, is faster (configs[0], 4096 rays: 0.63 vs 0.44 ms; 160 000 rays: 1.9 vs 3.2 ms)
-        if kind == "any" and rays_o.shape[0] < self.fused_min_rays:
+        # (single-stage fields only: with proposal stages in front, the chain would also leave THEIR fused kernels)
+        if kind == "any" and len(self.opt.num_steps) == 1 and rays_o.shape[0] < self.fused_min_rays:
             kind = None
         if perturb or self._needs_field_grad(update_proposal) or kind is None:
             return self._run_autograd(rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
