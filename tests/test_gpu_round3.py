@@ -446,3 +446,22 @@ def test_fused_mask_head_just_in_time_kernel_agrees(gpu, monkeypatch, N, T_, n_i
     monkeypatch.setenv("SN_WIDE_JIT", "1")
     b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
     assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+def test_random_field_sizes_through_the_size_agnostic_stage(gpu):
+    """tools/fuzz_parity.py any: random fields of other sizes than the reference network's (levels, table size, hash / tiled, MLP depths and
+    widths, geometry channels, schedules, fp16 / fp32 tables) against the oracle -- indices exact, RGB <= 1e-5, tile == linear order.  (A 120-case
+    run of this sweep found what 20-case runs had not: an unrolled layer multiplying a never-written LDS row -- NaN -- by weight 0.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "any", "40", "13"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatching cases: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_random_head_mlps_and_mask_heads(gpu):
+    """tools/fuzz_wide.py: random 256-wide stacks (widths, depths, skip layers, LayerNorm, row counts) -- k_mlp_wide_j bit-equal to k_mlp_wide and
+    within 1e-4 of torch -- and random fused mask heads (levels, appended channels, samples per ray, outputs) against the unfused composition."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_wide.py"), "40", "17"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatching cases: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
