@@ -169,7 +169,7 @@ class NeRFRenderer(nn.Module):
             self._plan = rm.RenderPlan(self, self.opt.num_steps, self.render_table_dtype,
                                        feat_encoder=self.s_grid if with_feat else None,
                                        early_stop_eps=float(getattr(self.opt, "early_stop_eps", 0.0) or 0.0),
-                                       compact_live=bool(getattr(self.opt, "compact_live", False)))
+                                       compact_live=bool(getattr(self.opt, "compact_live", False)) and self._fused_kind() == "main")
             self._plan_key = key
         elif not getattr(self, "render_tables_static", False):
             self._plan.refresh_tables()        # (the fp16 range guard is re-checked by render_rays before a final-stage launch)
@@ -228,6 +228,8 @@ class NeRFRenderer(nn.Module):
         if not self.opt.with_sam or not self.opt.sam_use_view_direction:
             return False
         if torch.is_grad_enabled() and self.s_grid.embeddings.requires_grad:
+            return False
+        if self._fused_kind() != "main":                    # the in-render feature stage is instantiated next to the reference network's last stage only
             return False
         g = self.s_grid
         return g.gridtype_id == 0 and not g.align_corners and g.interp_id == 0 and g.level_dim in (2, 4, 8)

@@ -465,3 +465,34 @@ def test_random_head_mlps_and_mask_heads(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_wide.py"), "40", "17"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "mismatching cases: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_other_field_sizes_with_the_feature_heads(gpu):
+    """A field of other sizes WITH the SAM-feature and mask heads: the fused call renders RGB and hands the last stage's samples over (the
+    in-render feature stage and the compaction exist next to the reference network's last stage only, so f_sam comes from the stand-alone
+    grid_composite); everything must agree with the operator-chain route of the same model."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.encoding import get_encoder
+    from sanerf_hq_amd.nerf.network import MLP
+    steps = [48, 24, 16]
+    params = synthetic_params(steps, heads=True, seed=77)
+    model = product_model(params, steps, True, gpu)
+    torch.manual_seed(3)
+    model.grid, d = get_encoder("hashgrid", input_dim=3, level_dim=2, num_levels=10, log2_hashmap_size=15, desired_resolution=512)
+    model.grid_mlp = MLP(d, 16, 40, 2, bias=False)            # 15 geometry channels: what the heads of the reference network expect
+    model.view_mlp = MLP(31, 3, 24, 3, bias=False)
+    model = model.to(gpu).eval()
+    with torch.no_grad():
+        model.grid.embeddings.uniform_(-1.0, 1.0)
+    model.opt.compact_live = True                             # asked for, not available for this field: must be ignored, not fatal
+    assert model._fused_kind() == "any" and not model._sam_fusable()
+    H = W = 40
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    with torch.no_grad():
+        a = model.render(ro, rd, staged=False, perturb=False, return_feats=1, return_mask=1, H=H, W=W, tile_w=W)
+        a = {k: v.clone() for k, v in a.items() if torch.is_tensor(v)}
+        model.standard_field = False
+        b = model.render(ro, rd, staged=False, perturb=False, return_feats=1, return_mask=1, H=H, W=W, tile_w=W)
+    for k, tol in (("image", 2e-5), ("depth", 1e-4), ("samvit", 1e-4), ("instance_mask_logits", 1e-4)):
+        assert torch.isfinite(a[k]).all(), k
+        assert float((a[k].reshape(b[k].shape) - b[k]).abs().max()) <= tol * max(1.0, float(b[k].abs().max())), k
