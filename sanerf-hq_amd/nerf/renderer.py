@@ -117,7 +117,7 @@ class NeRFRenderer(nn.Module):
         for head in range(0, N, step):
             tail = min(head + step, N)
             cnf = cam_near_far if cam_near_far is None or cam_near_far.shape[0] == 1 else cam_near_far[head:tail]
-            part = self.run(rays_o[head:tail], rays_d[head:tail], cam_near_far=cnf, **kwargs)
+            part = self.run(rays_o[head:tail], rays_d[head:tail], cam_near_far=cnf, _image_rays=N, **kwargs)   # (one route for every chunk of the image)
             for k, v in part.items():
                 if v is None:
                     continue
@@ -244,7 +244,7 @@ class NeRFRenderer(nn.Module):
         # the size-agnostic last stage gives a ray to one lane for all its samples: below ~16 k rays the chip is mostly idle and the operator
         # chain, which spreads the SAMPLES over the lanes, is faster (configs[0], 4096 rays: 0.63 vs 0.44 ms; 160 000 rays: 1.9 vs 3.2 ms)
         # (single-stage fields only: with proposal stages in front, the chain would also leave THEIR fused kernels)
-        if kind == "any" and len(self.opt.num_steps) == 1 and rays_o.shape[0] < self.fused_min_rays:
+        if kind == "any" and len(self.opt.num_steps) == 1 and int(kwargs.get("_image_rays", rays_o.shape[0])) < self.fused_min_rays:
             kind = None
         if perturb or self._needs_field_grad(update_proposal) or kind is None:
             return self._run_autograd(rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
