@@ -357,6 +357,24 @@ def main():
             r = measure(sch, args.tables, 3, 1, rays=(ro4, rd4, H4, H4 * H4))
             also[f"c4_1600x1600_{sch}_{args.tables}"] = {"rays_per_s": round(r["value"], 1), "ms_per_step": round(r["ms_per_step"], 4),
                                                          "num_steps": r["steps"], "tables": args.tables, "rays": H4 * H4}
+        # BASELINE configs[3] on 8 GPUs, as far as ONE GPU can show it: every rank's row band (dist.shard_rows with dist.band_align, what an
+        # 8-rank run launches) rendered on its own; projected_speedup_8 = whole-image time / slowest band.  The all-gather (51 MB per frame,
+        # overlapped with the next frame by PipelinedGather) and the rendezvous are what only a real N = 8 run adds.
+        from sanerf_hq_amd.dist import all_shards
+        bands8 = all_shards(H4, 8, band_align(H4, 8))
+        proj = {}
+        for sch in ("flat128", "ref"):
+            t_full = also[f"c4_1600x1600_{sch}_{args.tables}"]["ms_per_step"]
+            t_band = []
+            for b0, e0 in bands8:
+                r = measure(sch, args.tables, 3, 1, rays=(ro4[b0 * H4:e0 * H4], rd4[b0 * H4:e0 * H4], H4, (e0 - b0) * H4))
+                t_band.append(round(r["ms_per_step"], 4))
+            proj[sch] = {"whole_image_ms": t_full, "band_ms": t_band, "rows_per_band": [e0 - b0 for b0, e0 in bands8],
+                         "workgroups_per_band": [-(-(((H4 + 7) // 8) * ((e0 - b0 + 7) // 8)) // 4) for b0, e0 in bands8],
+                         "projected_speedup_8": round(t_full / max(t_band), 3)}
+        also["c4_eight_band_projection"] = dict(proj, note="one GPU renders each of the 8 row bands of the 1600x1600 image separately (3 timed frames each, "
+                                                "wall clock incl. launches); a workgroup is four 8x8-pixel wave tiles, so a 200-row band is 1250 workgroups "
+                                                "(2.44 rounds of 512 resident workgroups; the stages' time steps at multiples of 256: profiles/r04/staircase_1600.txt)")
         del ro4, rd4
         # opt-in live-sample compaction (not reference behaviour, off in every line above): a scene whose aabb
         # two thirds of the rays miss (renderer.py:133-135), default kernels vs k_final_stage_cmp; images are bit-equal

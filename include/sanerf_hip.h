@@ -77,13 +77,18 @@ int sn_grid_encode_backward(const float *grad, const float *inputs, const void *
                             float S, uint32_t H, const float *dy_dx, float *grad_inputs,
                             uint32_t gridtype, int align_corners, uint32_t interp,
                             int layout, sn_stream_t stream);
-/* Same result as sn_grid_encode_backward (embedding gradient only) without the reference's atomics-per-corner scatter:
- * (row, contribution) pairs are radix-sorted and every table row is then written by one thread (grid_sorted.hip).
- * D in {2,3}; B*max_level*2^D < 2^31; workspace >= sn_grid_backward_sorted_workspace_bytes() device bytes (keys,
- * indices and the B*max_level*2^D*C pre-multiplied contributions), 16-byte aligned like grad; grad_embeddings
- * zero-initialised by the caller.  Several times faster than the atomic path at the sizes of the training steps. */
-size_t sn_grid_backward_sorted_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level);
-int sn_grid_encode_backward_sorted(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
+/* Same result as sn_grid_encode_backward (embedding gradient only; replaces the scatter of gridencoder.cu:252-349 / grid.py:71-95)
+ * without the reference's atomics-per-corner: a level's rows are cut into bins sized to what a workgroup holds in LDS, the
+ * (row, contribution) pairs are partitioned by bin in one pass and every bin is counting-sorted and summed in LDS by the workgroup(s)
+ * that own it (grid_binned.hip; rounds 1-3 sorted the pairs with a library radix sort instead).  D in {2,3}; C a power of two <= 32;
+ * B*max_level*2^D < 2^31; every level at most 4096 bins of 4096 rows -- sn_grid_backward_binned_workspace_bytes() returns 0 for shapes
+ * outside that, which then take sn_grid_encode_backward.  workspace >= that many device bytes (bin counters, work lists, 2-byte row keys
+ * and the B*max_level*2^D*C pre-multiplied contributions, partial-sum slabs of split bins <= twice the table), 16-byte aligned like grad;
+ * grad_embeddings zero-initialised by the caller, rows without contribution are not written.  offsets_host = the L+1 level offsets
+ * (host memory).  No host synchronisation, static grids (graph-capturable).  Sums are order-nondeterministic in the last bits, like the
+ * reference's atomicAdd.  Several times faster than the atomic path at the sizes of the training steps. */
+size_t sn_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, const int32_t *offsets_host);
+int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
                                    float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                    int layout, void *workspace, size_t workspace_bytes, sn_stream_t stream);

@@ -66,8 +66,8 @@ _SIGNATURES = {
     "sn_grid_encode_forward": (_int, [_vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _int, _u32, _int, _vp]),
     "sn_grid_encode_forward_cat": (_int, [_vp, _vp, _int, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _vp]),
     "sn_grid_encode_backward": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _int, _u32, _int, _vp]),
-    "sn_grid_backward_sorted_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32, _u32]),
-    "sn_grid_encode_backward_sorted": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp, C.c_size_t, _vp]),
+    "sn_grid_backward_binned_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32, _u32, _u32, _vp]),
+    "sn_grid_encode_backward_binned": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp, C.c_size_t, _vp]),
     "sn_grad_total_variation": (_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp]),
     "sn_grad_weight_decay": (_int, [_vp, _vp, _vp, _f32, _u32, _u32, _u32, _vp]),
     "sn_sh_encode_forward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),

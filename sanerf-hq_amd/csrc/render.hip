@@ -56,16 +56,25 @@ __device__ __forceinline__ uint32_t tile_id_x(const RayCommon &rc, uint32_t b, u
 }
 __device__ __forceinline__ uint32_t tile_id(const RayCommon &rc) { return tile_id_x(rc, blockIdx.x, gridDim.x); }
 
-// lane -> ray.  Tile mode: block = 16x16 pixels, wave = 8x8.
+// lane -> ray.  Tile mode: wave = 8x8 pixels; a workgroup takes four CONSECUTIVE wave tiles of this order: wave-tile rows go in
+// pairs, column-major inside a pair ((0,0) (0,1) (1,0) (1,1) (2,0) ...), so that a workgroup is a 16x16-pixel block wherever the
+// image has one, and an odd last wave-tile row is walked left to right (32x8 pixels per workgroup).  The launch has
+// ceil(wave tiles / 4) workgroups whatever the shape -- a 200-row band of a 1600-wide image (BASELINE configs[3] on 8 GPUs) is 1250
+// workgroups, not the 1300 of whole 16x16 tiles: tools/staircase.py shows the stages' time stepping at multiples of 256 workgroups
+// (one per CU), 1300 is just past the step at 1280 (profiles/r04/staircase_1600.txt).  Host twin: blocks_for().
 __device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t wg, uint32_t &n) {
     const uint32_t tid = threadIdx.x;
     if (rc.W) {
-        const uint32_t tiles_x = (rc.W + 15u) >> 4;
-        const uint32_t by = wg / tiles_x, bx = wg - by * tiles_x;
+        const uint32_t tx8 = (rc.W + 7u) >> 3, ty8 = (rc.rows + 7u) >> 3;
         const uint32_t wave = tid >> 6, lane = tid & 63u;
-        const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
-        const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-        const bool ok = px < rc.W && py < rc.rows;
+        const uint32_t g = wg * 4u + wave;                       // wave tile
+        const uint32_t pair = 2u * tx8, paired = (ty8 >> 1) * pair;
+        uint32_t wx, wy;
+        if (g < paired) { const uint32_t p = g / pair, i = g - p * pair; wx = i >> 1; wy = 2u * p + (i & 1u); }
+        else { wx = g - paired; wy = ty8 & ~1u; }                // the odd last row (wx >= tx8: padding of the last workgroup)
+        const uint32_t py = wy * 8u + (lane >> 3);
+        const uint32_t px = wx * 8u + (lane & 7u);
+        const bool ok = wx < tx8 && px < rc.W && py < rc.rows;
         n = ok ? py * rc.W + px : 0u;
         return ok;
     }
@@ -2319,8 +2328,10 @@ __device__ __forceinline__ bool rs_ray_of_lane(const RayCommon &rc, uint32_t wg,
         const uint32_t px = bx * 32u + (pw & 3u) * 8u + (lane & 7u);
         const bool ok = px < rc.W && py < rc.rows;
         n = ok ? py * rc.W + px : 0u;
-        const uint32_t tiles_x16 = (rc.W + 15u) >> 4;
-        col = ok ? ((py >> 4) * tiles_x16 + (px >> 4)) * 256u + (((py >> 3) & 1u) * 2u + ((px >> 3) & 1u)) * 64u + (py & 7u) * 8u + (px & 7u) : 0u;
+        // the other stages' wave-tile order (ray_of_lane): pairs of wave-tile rows column-major, an odd last row left to right
+        const uint32_t tx8 = (rc.W + 7u) >> 3, ty8 = (rc.rows + 7u) >> 3, wx = px >> 3, wy = py >> 3;
+        const uint32_t g = wy < (ty8 & ~1u) ? (wy >> 1) * 2u * tx8 + wx * 2u + (wy & 1u) : (ty8 >> 1) * 2u * tx8 + wx;
+        col = ok ? g * 64u + (py & 7u) * 8u + (px & 7u) : 0u;
         return ok;
     }
     n = wg * (uint32_t)(RS_PROD * 64) + pw * 64u + lane;
@@ -3326,7 +3337,7 @@ static bool rs_enabled() {
 }
 
 static uint32_t blocks_for(uint32_t n, uint32_t W) {
-    if (W) { const uint32_t rows = (n + W - 1) / W; return ((W + 15u) >> 4) * ((rows + 15u) >> 4); }
+    if (W) { const uint32_t rows = (n + W - 1) / W; return div_up(((W + 7u) >> 3) * ((rows + 7u) >> 3), 4u); }   // four 8x8 wave tiles each (ray_of_lane)
     return div_up(n, 256);
 }
 

@@ -58,27 +58,31 @@ def _table_dtype(embeddings: torch.Tensor) -> int:
     raise RuntimeError("embeddings must be a floating tensor (float32 or float16)")
 
 
-# Gradient scatter strategy of the grid encoder: "auto" uses the sort-based kernel (no atomics per corner,
-# grid_sorted.hip) once the scatter is large enough to amortise the sort, "atomic" / "sorted" force one path.
+# Gradient scatter strategy of the grid encoder: "auto" uses the binned kernels (one partition pass + LDS accumulation, no atomics
+# per corner: grid_binned.hip) once the scatter is large enough to amortise their five launches, "atomic" / "binned" force one path
+# ("sorted", the name of the rounds 1-3 implementation, is accepted as an alias of "binned").
 GRID_BACKWARD_MODE = "auto"
-_SORTED_MIN_CONTRIBUTIONS = 1 << 19
-_sorted_ws = {}
+_BINNED_MIN_CONTRIBUTIONS = 1 << 19
+_binned_ws = {}
 
 
-def _use_sorted_backward(B: int, D: int, max_level: int, dy_dx) -> bool:
+def _binned_workspace_bytes(B: int, D: int, Cc: int, L: int, max_level: int, offs, dy_dx) -> int:
+    """Device bytes the binned backward needs, or 0 when this call takes the atomic kernel."""
     if GRID_BACKWARD_MODE == "atomic" or dy_dx is not None or D not in (2, 3) or B >= (1 << 24):
-        return False
+        return 0
     n = B * max_level * (1 << D)
     if n == 0 or n >= (1 << 31):
-        return False
-    return GRID_BACKWARD_MODE == "sorted" or n >= _SORTED_MIN_CONTRIBUTIONS
+        return 0
+    if GRID_BACKWARD_MODE not in ("binned", "sorted") and n < _BINNED_MIN_CONTRIBUTIONS:
+        return 0
+    return int(_lib.lib().sn_grid_backward_binned_workspace_bytes(B, D, Cc, L, max_level, _lib.host_i32(offs)))   # 0: shape outside the kernels' limits
 
 
-def _sorted_workspace(nbytes: int, device) -> torch.Tensor:
-    ws = _sorted_ws.get(device)
+def _binned_workspace(nbytes: int, device) -> torch.Tensor:
+    ws = _binned_ws.get(device)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _sorted_ws[device] = ws
+        _binned_ws[device] = ws
     return ws
 
 
@@ -129,13 +133,13 @@ class _grid_encode(Function):
         grad_embeddings = torch.zeros(table.shape, device=table.device, dtype=torch.float32)   # grid.py:83
         grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
         lib = _lib.lib()
-        if _use_sorted_backward(B, D, max_level, dy_dx):
-            need = int(lib.sn_grid_backward_sorted_workspace_bytes(B, D, Cc, max_level))
-            ws = _sorted_workspace(need, table.device)
-            _lib.check(lib.sn_grid_encode_backward_sorted(
+        need = _binned_workspace_bytes(B, D, Cc, L, max_level, offs, dy_dx)
+        if need:
+            ws = _binned_workspace(need, table.device)
+            _lib.check(lib.sn_grid_encode_backward_binned(
                 _lib.dev(grad, "grad"), _lib.dev(inputs, "inputs"), _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"),
                 B, D, Cc, L, max_level, S, H, gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC,
-                ws.data_ptr(), ws.numel(), _lib.stream()), "grid_encode_backward_sorted")
+                ws.data_ptr(), ws.numel(), _lib.stream()), "grid_encode_backward_binned")
             return None, grad_embeddings.to(emb_dtype), None, None, None, None, None, None, None, None
         _lib.check(lib.sn_grid_encode_backward(
             _lib.dev(grad, "grad"), _lib.dev(inputs, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table),

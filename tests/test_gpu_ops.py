@@ -81,8 +81,8 @@ def test_grid_backward_matches_oracle(gpu, orc, cfg):
 
 @pytest.mark.parametrize("cfg,B", [(GRID_CASES[1], 3001), (GRID_CASES[1], 70000), (GRID_CASES[2], 40000), (GRID_CASES[4], 9000),
                                    (GRID_CASES[5], 5000)])
-def test_grid_backward_sorted_matches_oracle(gpu, orc, cfg, B):
-    """The atomics-free scatter (radix sort + one owner per table row) against the oracle, including heavy row
+def test_grid_backward_binned_matches_oracle(gpu, orc, cfg, B):
+    """The atomics-free scatter (one partition pass by row bin + LDS accumulation, one owner per table row: grid_binned.hip) against the oracle, including heavy row
     sharing (coherent samples on coarse levels), out-of-range samples and the tiled / align_corners variants."""
     from sanerf_hq_amd import ops
     from sanerf_hq_amd.gridencoder import grid_encode
@@ -93,7 +93,7 @@ def test_grid_backward_sorted_matches_oracle(gpu, orc, cfg, B):
     old = ops.GRID_BACKWARD_MODE
     res = {}
     try:
-        for mode in ("sorted", "atomic"):
+        for mode in ("binned", "atomic"):
             ops.GRID_BACKWARD_MODE = mode
             et = T(emb, gpu).requires_grad_(True)
             out = grid_encode(T(x, gpu), et, T(offs, gpu), pls, 16, False, cfg["gridtype"], cfg["ac"], cfg["interp"])

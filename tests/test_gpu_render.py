@@ -504,7 +504,7 @@ def test_config3_full_size_with_fp16_tables(gpu, orc):
 
 def test_config5_full_size_training_step_properties(gpu, orc):
     """BASELINE configs[4] at its full size (4096 rays, mask NLL, radiance field frozen): the forward logits of 256 random
-    rays against the CPU oracle; the table gradient from the sorted backward against the atomic backward (two independent
+    rays against the CPU oracle; the table gradient from the binned backward against the atomic backward (two independent
     HIP paths) within the 1e-3 budget; exact linearity of the backward in the upstream gradient; every
     untouched row's gradient exactly zero."""
     from sanerf_hq_amd import ops, raymarching as rm, synth
@@ -538,7 +538,7 @@ def test_config5_full_size_training_step_properties(gpu, orc):
         finally:
             ops.GRID_BACKWARD_MODE = "auto"
 
-    logits, loss, g_sorted, gw = step("sorted")
+    logits, loss, g_sorted, gw = step("binned")
     assert np.isfinite(loss) and torch.isfinite(g_sorted).all()
     sub = (synth.hash_u01(256, 7) * N).astype(np.int64)
     want = orc.render(oracle_cfg(orc, params, steps, heads=True), ro[sub].cpu().numpy(), rd[sub].cpu().numpy())
@@ -551,7 +551,7 @@ def test_config5_full_size_training_step_properties(gpu, orc):
         int(((g_sorted.abs().sum(-1) > 0) != (g_atomic.abs().sum(-1) > 0)).sum()) <= 1e-4 * int((g_atomic.abs().sum(-1) > 0).sum())
     for x, y in zip(gw, gw2):
         assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
-    _, _, g2, gw3 = step("sorted", scale=2.0)                           # the backward is linear in the upstream gradient
+    _, _, g2, gw3 = step("binned", scale=2.0)                           # the backward is linear in the upstream gradient
     assert float((g2 - 2 * g_sorted).abs().max()) <= 1e-6 * float(g_sorted.abs().max())
     assert model.grid.embeddings.grad is None
 

@@ -5,7 +5,7 @@ the imported reference on the oracle's own encoders -- circular for the encoder 
 comes from tools/gen_kat_encoders.py: Python-integer index arithmetic + float64 blending written from
 gridencoder.cu:45-201,264-348, and SH from the associated-Legendre definition.  A wrong prime, stride walk, clamp,
 resolution rounding or SH sign shared by oracle.c and the HIP kernels fails here.
-  * CPU: the oracle against the vectors;  * -m gpu: the HIP kernels (forward, atomic and sorted backward) against them.
+  * CPU: the oracle against the vectors;  * -m gpu: the HIP kernels (forward, atomic and binned backward) against them.
 Limit of the pin: the vectors restate the reference's algorithm from its source text; nothing the reference EXECUTES on
 this machine produced them (no nvcc, no GPU in the build container)."""
 import os
@@ -69,8 +69,8 @@ def test_hip_grid_matches_independent_vectors(gpu, name):
     dev = gpu
     x = torch.from_numpy(c["x"]).to(dev)
     offs = torch.from_numpy(c["offs"].astype(np.int32)).to(dev)
-    for mode in ("atomic", "sorted"):
-        if mode == "sorted" and c["D"] != 3:
+    for mode in ("atomic", "binned"):
+        if mode == "binned" and c["D"] not in (2, 3):
             continue
         emb = torch.from_numpy(c["table"]).to(dev).requires_grad_(True)
         old = ops.GRID_BACKWARD_MODE
