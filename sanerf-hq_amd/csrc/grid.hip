@@ -306,12 +306,23 @@ __global__ __launch_bounds__(256) void k_grid_wd(const float *__restrict__ table
         else if (D == 2 && C == 2) { CALL(2, 2); }                                              \
         else if (D == 2 && C == 4) { CALL(2, 4); }                                              \
         else if (D == 2 && C == 8) { CALL(2, 8); }                                              \
+        else if (D == 2 && C == 16) { CALL(2, 16); }                                            \
+        else if (D == 2 && C == 32) { CALL(2, 32); }                                            \
+        else if (D == 4 && C == 1) { CALL(4, 1); }                                              \
         else if (D == 4 && C == 2) { CALL(4, 2); }                                              \
         else if (D == 4 && C == 4) { CALL(4, 4); }                                              \
+        else if (D == 4 && C == 8) { CALL(4, 8); }                                              \
+        else if (D == 4 && C == 16) { CALL(4, 16); }                                            \
+        else if (D == 4 && C == 32) { CALL(4, 32); }                                            \
+        else if (D == 5 && C == 1) { CALL(5, 1); }                                              \
         else if (D == 5 && C == 2) { CALL(5, 2); }                                              \
+        else if (D == 5 && C == 4) { CALL(5, 4); }                                              \
+        else if (D == 5 && C == 8) { CALL(5, 8); }                                              \
+        else if (D == 5 && C == 16) { CALL(5, 16); }                                            \
+        else if (D == 5 && C == 32) { CALL(5, 32); }                                            \
         else done__ = false;                                                                    \
         if (!done__) {                                                                          \
-            ::sn::set_error("grid: combination D=%u C=%u is valid in the reference but not instantiated in this build", D, C); \
+            ::sn::set_error("grid: D=%u C=%u is outside the reference's instantiations (gridencoder.cu:385-411: D in 2..5, C in 1,2,4,8,16,32)", D, C); \
             return SN_ERR_UNSUPPORTED;                                                          \
         }                                                                                       \
     } while (0)
