@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="world size 1 only: still go through RCCL (init, all-gather pipeline, barriers)")
     ap.add_argument("--primary-only", action="store_true", help="skip the extra configurations reported under `also`")
+    ap.add_argument("--tuning", default="", help="kernel-selection fields of raymarching.Tuning for A/B runs, e.g. densify=1,per_sample_form=1 "
+                                                  "(mlp_mode also takes f16x3 / mfma32 / valu); default: the shipped kernels")
     return ap.parse_args()
 
 
@@ -93,10 +95,15 @@ def flops_per_ray(steps):
     return 2 * (sum(t * 176 for t in steps[:-1]) + steps[-1] * 7168 + 2112)
 
 
-def gather_instructions_per_wave_sample(tables):
-    """Final stage (render.hip): 5 dense levels as aligned pair rows (fp32: 4 loads) / quad rows (fp16: 2 loads),
-    11 hashed levels x 8 corners."""
-    return 5 * (4 if tables == "f32" else 2) + 11 * 8
+def apply_tuning(text):
+    """--tuning "field=value,...": the process default of sanerf_hq_amd.raymarching (the library reads no environment)."""
+    from sanerf_hq_amd import _lib, raymarching as rm
+    names = {"f16x3": _lib.MLP_F16X3, "mfma32": _lib.MLP_MFMA32, "valu": _lib.MLP_VALU, "auto": _lib.MLP_AUTO}
+    for item in filter(None, (t.strip() for t in text.split(","))):
+        k, v = item.split("=")
+        if k.strip() not in rm.Tuning.FIELDS:
+            sys.exit(f"bench.py: --tuning: unknown field {k!r} (fields: {', '.join(rm.Tuning.FIELDS)})")
+        setattr(rm.tuning, k.strip(), names[v] if v in names else int(v))
 
 
 def gather_ceiling():
@@ -162,6 +169,7 @@ def main():
 
     from sanerf_hq_amd import _lib, raymarching as rm, synth
     from sanerf_hq_amd.dist import PipelinedGather, band_align, shard_rows
+    apply_tuning(args.tuning)
 
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "single")
     hw = args.hw or (1600 if scaling == "strong" else 800)
@@ -240,6 +248,7 @@ def main():
         mhz, probe_ms = C.c_float(0), C.c_float(0)
         _lib.check(lib.sn_rm_profile_shader_clock(C.byref(mhz), C.byref(probe_ms)), "profile_shader_clock")
         lib.sn_rm_profile_enable(0)
+        launch = rm.last_launch_info()                      # the last stage that really ran (kernel variant, gather instructions per wave-sample)
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps))
         if gather and multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -251,7 +260,7 @@ def main():
         return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=n_total / (elapsed / n_steps),
                     ms_per_step=elapsed / n_steps * 1e3, median_ms=per_step[len(per_step) // 2], tables=tables,
                     s_bytes=2 if tables == "f16" else 4, final_ms=per(4), final_launches=int(cnt[4]), pack_ms=per(0),
-                    prop_ms=[per(1), per(2)], shader_mhz=float(mhz.value), probe_ms=float(probe_ms.value),
+                    prop_ms=[per(1), per(2)], shader_mhz=float(mhz.value), probe_ms=float(probe_ms.value), launch=launch,
                     image=pipe.drain() if pipe is not None else None)
 
     m = measure(args.schedule, args.tables, args.steps, args.warmup)
@@ -273,7 +282,7 @@ def main():
         del ro_f, rd_f
 
     # ---- roofline of the dominant kernel (final stage) on this rank ----
-    gpw = gather_instructions_per_wave_sample(args.tables)
+    gpw = m["launch"]["gathers_per_wave_sample"]         # read back from the library: 86 for the densified fp16 kernel, 98 / 108 for K = 5
     waves = -(-n_local // 64)
     gather_instr = waves * steps[-1] * gpw
     clock_hz = m["shader_mhz"] * 1e6 if m["shader_mhz"] > 0 else None
@@ -301,8 +310,17 @@ def main():
     roofline = {
         # the contract's four: ALGORITHMIC bytes per launch (every corner fetch once, no cache credit) / kernel time vs HBM peak.
         # L1 / L2 / Infinity Cache serve neighbouring rays, so this figure can exceed 1 -- the fractions that bind follow.
-        "kernel": "k_final_stage", "bound": "hbm", "achieved": round(alg_gbps, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "kernel": m["launch"]["final_kernel"], "bound": "hbm", "achieved": round(alg_gbps, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": round(alg_gbps * 1e9 / HBM_PEAK, 4), "traffic": traffic,
+        # what actually binds: NOT HBM.  The four fields above are the contract's ALGORITHMIC figure (every corner fetch once, no
+        # cache credit: cache-absorbed, can exceed 1); the kernel is co-limited by the texture-address rate, vector-ALU issue and the
+        # power-managed shader clock, and moves `fabric_frac` of the HBM peak beyond its L2s
+        "binding": {"limiter": "texture-address rate (TA), co-limited with VALU issue and the shader clock under matrix-core load",
+                    "frac": round(ta_floor / final_ms, 4) if ta_floor else None,
+                    "hbm_side_frac": (traffic / (final_ms * 1e-3) / HBM_PEAK) if traffic else None,
+                    "note": "frac = gather instructions x measured cycles per wave-gather per CU / kernel time at the clock measured in the kernel "
+                            "(ta_address_rate below); hbm_side_frac = PMC-derived bytes beyond the L2s / time / 8 TB/s (fabric below)"},
+        "launch": m["launch"],
         "fabric_frac": fabric["frac"],                     # counter-derived, guide-corrected: measured HBM-side bytes / time / 8 TB/s
         "fabric": fabric,
         "counters": counters,                              # MfmaUtil, VALUBusy, TA busy, L2 hit rate of the same kernel (profiles/<round>/pmc_*.txt)
@@ -389,6 +407,19 @@ def main():
                 # (the compacting kernel keeps the per-sample third layer, the default kernel applies its geometry rows once per ray:
                 #  equal up to fp32 round-off, bit-equal with SN_RENDER_LT=0 -- tests/test_gpu_render.py)
                 "image_max_abs_diff": float((img0 - r1["out"]["image"]).abs().max()), "num_steps": r1["steps"]}
+        # the other BASELINE configurations, driver-timed (short runs; tools/bench_configs.py holds the long forms and more variants)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            import bench_configs as bc
+            torch.cuda.empty_cache()
+            also["c3_sam_head_400x400"] = dict(bc.c3_entry(dev, 2, 6), note="BASELINE configs[2]: 400x400 rays + 256-d SAM-feature head, [128,64,32]; fp32 tables, and "
+                                               "with every table in half (incl. the per-call conversion)")
+            also["mask_head_400x400"] = dict(bc.mask_head_entry(dev, 2, 5), note="400x400 render with the per-sample mask head (renderer.py:376-385), one-kernel head vs three-kernel route")
+            also["c5_train_step_ms"] = dict(bc.c5_entry(dev, 3, 8, optimisers=False), note="BASELINE configs[4]: mask-field training step, 4096 rays, fwd+bwd [+ single-pass Adam]")
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001   (the headline line must survive a failure of an extra)
+            also["extras_error"] = f"{type(e).__name__}: {e}"
         out = m["out"]
 
     cpu_baseline = None
@@ -424,9 +455,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "median_ms_per_step": round(m["median_ms"], 4),
             "higher_is_better": True, "scaling": "weak" if scaling == "weak" else "strong", "vs_baseline": None,
-            "dtype": "f32", "tables": args.tables, "data": "synthetic",
+            "dtype": "f32 arithmetic / %s tables" % args.tables, "tables": args.tables, "data": "synthetic",
             "dtype_note": f"arithmetic fp32 (positions, interpolation, compositing; the 32-64-64-16 MLP multiplies fp16 hi/lo splits of fp32 operands "
                           f"on the matrix cores with fp32 accumulation: 2^-22 per product); hash tables stored as {args.tables}"
+                          + (" (the fp16 copies of the module's fp32 parameters are made once when the RenderPlan is built, OUTSIDE the timed region: "
+                             "a frozen field is rendered; a training loop would re-convert 3 tables per step, 0.05 ms)" if args.tables == "f16" else "")
                           + (" -- BASELINE configs[1] is the fp16 configuration: tables in half like the reference's fp16 mode (grid.py:43-49), "
                              "results equal the fp32 oracle run on the same rounded tables to 1e-5 (also.flat128_f32: fp32 tables)" if args.tables == "f16" else ""),
             "rccl_ranks": rccl_ranks,

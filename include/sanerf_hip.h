@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 6
+#define SN_ABI_VERSION 7
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -46,6 +46,16 @@ enum { SN_F32 = 0, SN_F16 = 1 };                 /* table storage type */
 enum { SN_LAYOUT_LBC = 0, SN_LAYOUT_BLC = 1 };   /* [L,B,C] (reference kernel) or [B,L*C] (what grid.py:63 returns) */
 
 int sn_abi_version(void);
+/* How this library was built: bit 0 (SN_BUILD_EXPERIMENTS) = -DSN_EXPERIMENTS, the measured-and-rejected kernel variants are compiled in
+ * (sn_render_tuning.experiment, sn_debug_set); bit 1 (SN_BUILD_POISON_LDS) = -DSN_POISON_LDS, every kernel that uses LDS fills it with
+ * signalling NaNs at entry (a read-before-write shows up as NaN in the result: the r03 bug class of k_final_stage_any).  The product
+ * library (`make`) carries neither. */
+#define SN_BUILD_EXPERIMENTS 1
+#define SN_BUILD_POISON_LDS 2
+int sn_build_flags(void);
+/* Experiments builds only (SN_ERR_UNSUPPORTED otherwise): process-wide A/B switches of variants that are not reachable through a
+ * descriptor.  Keys: "wide_jit" (0: the superseded k_mlp_wide forward instead of k_mlp_wide_j). */
+int sn_debug_set(const char *key, int value);
 const char *sn_last_error(void);
 /* number of HIP devices visible; <0 on error.  Lets hosts fail loudly before any launch. */
 int sn_device_count(void);
@@ -200,6 +210,26 @@ typedef struct sn_mlp_desc {
     uint32_t     skip_mask;
 } sn_mlp_desc;
 
+/* Kernel selection of sn_rm_render_rays, read from the caller's cfg on every call (ABI <= 6 read process-wide environment variables
+ * instead).  All zero = the defaults.  None of these changes WHAT is computed beyond fp32 round-off; the notes say which are bit-neutral. */
+enum { SN_MLP_AUTO = 0, SN_MLP_F16X3 = 1, SN_MLP_MFMA32 = 2, SN_MLP_VALU = 3 };
+enum { SN_EXP_NONE = 0, SN_EXP_ROLE_SPLIT = 1, SN_EXP_LDS_LEVEL0 = 2 };
+typedef struct sn_render_tuning {
+    int32_t mlp_mode;            /* SN_MLP_AUTO: split-fp16 on the matrix cores unless cfg.mlp_exact_fp32; SN_MLP_F16X3 forces it (overrides the
+                                  * range guard); SN_MLP_MFMA32: exact fp32 v_mfma_f32_32x32x2_f32; SN_MLP_VALU: vector-ALU fallback (A/B of the layouts) */
+    int32_t per_sample_form;     /* 1: the last stage evaluates the third MLP layer per sample everywhere (no "linear tail"): bit-identical to
+                                  * the compacting / several-lanes-per-ray kernels, fp32 round-off away from the default */
+    int32_t densify;             /* hashed levels 5-6 of the main grid re-laid out per call like dense levels (bit-neutral): 0 automatic (fp16
+                                  * tables and >= 64 M last-stage samples), 1 never, 2 whenever the kernel exists for the call */
+    int32_t linear_tile_order;   /* 1: workgroup b renders tile b (no XCD-aware remap; bit-neutral) */
+    int32_t prop_sp_max_rays;    /* linear-order batches up to this many rays run the proposal stages with 8 lanes per ray (bit-neutral):
+                                  * 0 default (32768), < 0 never */
+    int32_t final_sp_max_rays;   /* the same for the last stage (several lanes per ray, per-sample form): 0 default (16384), < 0 never */
+    int32_t feat_levels;         /* levels per workgroup pass of the feature stage: 0 default (2), 1, 2 or 4 (bit-neutral) */
+    int32_t experiment;          /* SN_EXP_*: variants that were built, verified bit-identical and measured SLOWER; honoured only by
+                                  * a library built with -DSN_EXPERIMENTS (sn_build_flags), SN_ERR_UNSUPPORTED otherwise */
+} sn_render_tuning;
+
 typedef struct sn_render_cfg {
     uint32_t     num_stages;                /* len(opt.num_steps), 1..SN_MAX_STAGES */
     uint32_t     num_steps[SN_MAX_STAGES];
@@ -231,8 +261,8 @@ typedef struct sn_render_cfg {
     /* Arithmetic of the 32-64-64-16 MLP on the matrix cores.  0 (default): fp16 hi/lo-split products with fp32 accumulation
      * (2^-22 per product) -- requires every weight and activation of that MLP to stay below 65504 in magnitude, which the
      * CALLER guarantees (the Python mirror derives a bound from max|table| and the weights' row norms and sets 1 when it
-     * cannot).  1: exact fp32 v_mfma_f32_32x32x2_f32 (no range limit, ~2.2x slower final stage).  The environment
-     * variable SN_RENDER_MLP (f16x3 / mfma32 / valu) overrides this field. */
+     * cannot).  1: exact fp32 v_mfma_f32_32x32x2_f32 (no range limit, ~2.2x slower final stage).  tuning.mlp_mode != SN_MLP_AUTO
+     * overrides this field. */
     int32_t      mlp_exact_fp32;
     /* opt-in, NOT reference behaviour: the last stage runs with per-ray termination and wave-level compaction of live
      * samples (k_final_stage_cmp).  A ray stops taking samples once its transmittance is below early_stop_eps (if > 0),
@@ -244,6 +274,7 @@ typedef struct sn_render_cfg {
      * weight comes out 0 as well).  Ignored (default kernel runs) when per-sample outputs or the feature stage are on,
      * for tables the FinalLv fast path does not cover, and in the exact-fp32 / VALU MLP modes. */
     int32_t      compact_live;
+    sn_render_tuning tuning;
 } sn_render_cfg;
 
 typedef struct sn_render_io {
@@ -282,6 +313,14 @@ typedef struct sn_render_io {
 /* bytes of device workspace sn_rm_render_rays needs for N rays (tile_w as in sn_render_io) */
 size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w);
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream);
+/* What the last sn_rm_render_rays call of THIS THREAD launched as its last stage (measurement: bench.py prices the gather stream of the
+ * kernel that really ran).  final_kernel: "k_final_stage<lt,K=7>", "k_final_stage_sp", ...; dense_levels: levels of the main grid read
+ * as packed pair / quad rows; gathers_per_wave_sample: 64-lane gather instructions one sample of one wave issues in that kernel. */
+typedef struct sn_launch_info {
+    char     final_kernel[64];
+    uint32_t workgroups, lds_bytes, dense_levels, gathers_per_wave_sample, launches;
+} sn_launch_info;
+int sn_rm_last_launch_info(sn_launch_info *info);
 
 /* Feature-head accumulation, nerf/renderer.py:301-302 + 361: out[n, :] = sum_j weights[n,j] * grid(xyzs[n,j])
  * = composite(weights, s_grid(xyzs, bound)) without materialising the [N*T, L*C] per-sample features.

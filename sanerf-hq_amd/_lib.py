@@ -34,6 +34,22 @@ class MlpDesc(C.Structure):
                 ("activation", C.c_uint32), ("skip_mask", C.c_uint32)]
 
 
+MLP_AUTO, MLP_F16X3, MLP_MFMA32, MLP_VALU = 0, 1, 2, 3              # sn_render_tuning.mlp_mode
+EXP_NONE, EXP_ROLE_SPLIT, EXP_LDS_LEVEL0 = 0, 1, 2                   # sn_render_tuning.experiment (experiments builds only)
+BUILD_EXPERIMENTS, BUILD_POISON_LDS = 1, 2                           # sn_build_flags()
+ADAM_ZERO_GRAD, ADAM_LAZY = 1, 2                                     # sn_adam_step flags
+
+
+class RenderTuning(C.Structure):
+    _fields_ = [("mlp_mode", C.c_int32), ("per_sample_form", C.c_int32), ("densify", C.c_int32), ("linear_tile_order", C.c_int32),
+                ("prop_sp_max_rays", C.c_int32), ("final_sp_max_rays", C.c_int32), ("feat_levels", C.c_int32), ("experiment", C.c_int32)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("final_kernel", C.c_char * 64), ("workgroups", C.c_uint32), ("lds_bytes", C.c_uint32), ("dense_levels", C.c_uint32),
+                ("gathers_per_wave_sample", C.c_uint32), ("launches", C.c_uint32)]
+
+
 class RenderCfg(C.Structure):
     _fields_ = [("num_stages", C.c_uint32), ("num_steps", C.c_uint32 * MAX_STAGES),
                 ("prop_grid", GridDesc * MAX_STAGES), ("prop_mlp", MlpDesc * MAX_STAGES),
@@ -41,7 +57,7 @@ class RenderCfg(C.Structure):
                 ("sh_degree", C.c_uint32), ("aabb", C.c_float * 6), ("min_near", C.c_float), ("bound", C.c_float),
                 ("contract", C.c_int32), ("last_sample_opaque", C.c_int32), ("bg_color", C.c_float),
                 ("feat_grid", GridDesc), ("with_feat", C.c_int32), ("early_stop_eps", C.c_float), ("mlp_exact_fp32", C.c_int32),
-                ("compact_live", C.c_int32)]
+                ("compact_live", C.c_int32), ("tuning", RenderTuning)]
 
 
 class RenderIO(C.Structure):
@@ -57,10 +73,12 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 6   # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 7   # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),
+    "sn_build_flags": (_int, []),
+    "sn_debug_set": (_int, [C.c_char_p, _int]),
     "sn_last_error": (C.c_char_p, []),
     "sn_device_count": (_int, []),
     "sn_grid_encode_forward": (_int, [_vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _int, _u32, _int, _vp]),
@@ -103,6 +121,7 @@ _SIGNATURES = {
     "sn_rm_profile_read": (_int, [_vp, _vp, _int]),
     "sn_rm_profile_shader_clock": (_int, [_vp, _vp]),
     "sn_rm_debug_occupancy": (_int, [_vp, _vp, _int]),
+    "sn_rm_last_launch_info": (_int, [_vp]),
     "sn_debug_eval": (_int, [_int, _vp, _vp, _u32, _vp, _vp]),
 }
 

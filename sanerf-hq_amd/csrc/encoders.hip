@@ -19,6 +19,7 @@ __device__ __forceinline__ void sh_values(float x, float y, float z, uint32_t C,
 // one lane per direction; outputs staged through registers and written as contiguous rows
 __global__ __launch_bounds__(256) void k_sh_forward(const float *__restrict__ inputs, float *__restrict__ outputs,
                                                     uint32_t B, uint32_t C, float *__restrict__ dy_dx) {
+    SN_POISON_ALL();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const uint32_t C2 = C * C;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void k_sh_forward(const float *__restrict__ in
 // shencoder.cu:358-382 — accumulates into grad_inputs
 __global__ __launch_bounds__(256) void k_sh_backward(const float *__restrict__ grad, const float *__restrict__ dy_dx,
                                                      float *__restrict__ grad_inputs, uint32_t B, uint32_t D, uint32_t C2) {
+    SN_POISON_ALL();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * D) return;
     const uint32_t b = t / D, d = t - b * D;
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(256) void k_sh_backward(const float *__restrict__ g
 // __sinf(v + pi/2) fast-math form is a lower-accuracy evaluation of the same numbers.
 __global__ __launch_bounds__(256) void k_freq_forward(const float *__restrict__ inputs, uint32_t B, uint32_t D, uint32_t C,
                                                       float *__restrict__ outputs) {
+    SN_POISON_ALL();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)B * C) return;
     const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t - (uint64_t)b * C);
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(256) void k_freq_forward(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_freq_backward(const float *__restrict__ grad, const float *__restrict__ outputs,
                                                        uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
                                                        float *__restrict__ grad_inputs) {
+    SN_POISON_ALL();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * D) return;
     const uint32_t b = t / D, d = t - b * D;

@@ -67,6 +67,7 @@ template <typename T, uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void k_grid_forward(const float *__restrict__ inputs, const T *__restrict__ table,
                                                       float *__restrict__ outputs, float *__restrict__ dy_dx,
                                                       uint32_t B, GridLevels g, int layout) {
+    SN_POISON_ALL();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const uint32_t level = blockIdx.y;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void k_grid_forward(const float *__restrict__ 
 template <uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void k_grid_backward(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                        float *__restrict__ grad_table, uint32_t B, GridLevels g, int layout) {
+    SN_POISON_ALL();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const uint32_t level = blockIdx.y;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float *__restrict__
 template <uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void k_grid_input_backward(const float *__restrict__ grad, const float *__restrict__ dy_dx,
                                                              float *__restrict__ grad_inputs, uint32_t B, uint32_t L, int layout) {
+    SN_POISON_ALL();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * D) return;
     const uint32_t b = t / D, d = t - b * D;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void k_grid_input_backward(const float *__rest
 template <uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void k_grid_tv(const float *__restrict__ inputs, const float *__restrict__ table,
                                                  float *__restrict__ grad, float weight, uint32_t B, GridLevels g) {
+    SN_POISON_ALL();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const uint32_t level = blockIdx.y;
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(256) void k_grid_tv(const float *__restrict__ input
 
 __global__ __launch_bounds__(256) void k_grid_wd(const float *__restrict__ table, float *__restrict__ grad, float weight,
                                                  uint32_t rows, uint32_t C, GridLevels g) {
+    SN_POISON_ALL();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)rows * C) return;
     const uint32_t n = (uint32_t)(t / C);
@@ -340,6 +345,7 @@ template <typename T, uint32_t C>
 __global__ __launch_bounds__(256) void k_grid_forward_rows(const float *__restrict__ inputs, const T *__restrict__ table,
                                                            float *__restrict__ outputs, uint32_t B, GridLevels g, uint32_t max_level,
                                                            const float *__restrict__ extra, uint32_t E) {
+    SN_POISON_ALL();
     constexpr uint32_t D = 3;
     extern __shared__ __attribute__((aligned(16))) float rows[];           // [64][L*C + 4]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

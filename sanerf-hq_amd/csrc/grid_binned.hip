@@ -91,6 +91,7 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
 template <uint32_t D>
 __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inputs, uint32_t B, GridLevels g, BinGeom bg,
                                                    uint32_t *__restrict__ counts) {
+    SN_POISON_ALL();
     __shared__ uint32_t hist[BIN_MAX_PER_LEVEL];
     const uint32_t level = blockIdx.y, nb = bg.nb[level], shift = bg.shift[level];
     for (uint32_t i = threadIdx.x; i < nb; i += 256u) hist[i] = 0u;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inp
 __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ cursor, uint32_t total_bins,
                                                            BinHdr *__restrict__ hdr, BinItem *__restrict__ items, BinShared *__restrict__ shared_bins,
                                                            BinGeom bg) {
+    SN_POISON_ALL();
     constexpr uint32_t NW = PLAN_THREADS / 64u;
     __shared__ uint32_t s_w[NW][5];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, cap = bg.ecap, nbs = bg.nbs;
@@ -189,6 +191,7 @@ template <uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ inputs, const float *__restrict__ grad, uint32_t B,
                                                      GridLevels g, BinGeom bg, int layout, uint32_t *__restrict__ cursor,
                                                      uint16_t *__restrict__ ekey, float *__restrict__ econtrib) {
+    SN_POISON_ALL();
     constexpr uint32_t NC = 1u << D;
     __shared__ uint32_t hist[BIN_MAX_PER_LEVEL];                 // phase 1: pairs of this block per bin; phase 2: the block's first slot per bin
     const uint32_t level = blockIdx.y, nb = bg.nb[level], shift = bg.shift[level];
@@ -262,6 +265,7 @@ template <uint32_t C>
 __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__ hdr, const BinItem *__restrict__ items, GridLevels g, BinGeom bg,
                                                       const uint16_t *__restrict__ ekey, const float *__restrict__ econtrib,
                                                       float *__restrict__ slabs, float *__restrict__ grad_table) {
+    SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
     if (blockIdx.x >= hdr->n_items) return;
     const BinItem it = items[blockIdx.x];
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__
 template <uint32_t C>
 __global__ __launch_bounds__(256) void k_bin_merge(const BinHdr *__restrict__ hdr, const BinShared *__restrict__ shared_bins, GridLevels g, BinGeom bg,
                                                    const float *__restrict__ slabs, float *__restrict__ grad_table) {
+    SN_POISON_ALL();
     const uint32_t nsb = hdr->n_shared_bins;
     for (uint32_t sbi = blockIdx.x; sbi < nsb; sbi += gridDim.x) {
         const BinShared sb = shared_bins[sbi];

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k_grid_composite(const float *__restrict_
                                                         const T *__restrict__ table, float *__restrict__ out,
                                                         uint32_t N, uint32_t Tn, GridLevels g, float bound, float inv_den,
                                                         uint32_t tile_w, uint32_t rows) {
+    SN_POISON_ALL();
     // lane -> ray: 8x8 pixel tiles per wave when the rays are an image (neighbouring lanes then share table lines)
     uint32_t n;
     bool ok;
@@ -189,9 +190,7 @@ extern "C" int sn_rm_grid_composite(const float *xyzs, const float *weights, uin
     const bool vec = (T % 4u) == 0u && table_aligned(xyzs) && table_aligned(weights);
     // levels per workgroup pass: more passes = more workgroups (the launch is a few waves per CU at image sizes of
     // interest) and fewer registers, at the price of re-reading weights/positions once per pass
-    int lg = 2;
-    if (const char *e = getenv("SN_GC_LEVELS")) lg = atoi(e);
-    if (lg != 1 && lg != 2 && lg != 4) lg = 2;
+    const int lg = 2;
     const bool fast = levels_fast(g) && (g.L % (uint32_t)lg) == 0u;
     const dim3 blk(256);
 #define SN_GC4(TT, CC, LGG, FF, VV)                                                                                    \

@@ -128,6 +128,7 @@ __device__ __forceinline__ void wide_trace(uint32_t) {}
 
 // one thread per (layer, k-step, output tile, lane): 8 weights -> (hi, lo) uint4
 __global__ void k_pack_mlp_wide(PackArgs a) {
+    SN_POISON_ALL();
     const uint32_t layer = blockIdx.y;
     const WideLayer L = a.layer[layer];
     const uint32_t nks = (L.uses_h ? WIDE_HKS : 0u) + L.x_ks;
@@ -192,6 +193,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // XMODE 0: too wide for LDS: read from memory per k-step (clamped, branch-free).
 template <int XMODE>
 __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
+    SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];        // WIDE_NBUF x WIDE_CHUNK_U4, then floats
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t half = lane >> 5;
@@ -924,6 +926,7 @@ __device__ __forceinline__ void dma16x4(const void *gptr, uint32_t lds_byte_offs
 
 template <int XMODE>
 __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
+    SN_POISON_ALL();
     static_assert(XMODE >= 0 && XMODE <= 3, "the backward mode keeps k_mlp_wide");
     extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];        // WIDE_NBUF x WIDE_CHUNK_U4, then floats
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1527,14 +1530,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     }
 }
 
-// Which forward kernel: SN_WIDE_JIT=0 -> k_mlp_wide everywhere, =1 / unset -> k_mlp_wide_j (same-library A/B; read on every call):
-// SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms, 400x400 mask render 7.49 -> 7.13 ms (fused mask head: ray-major tiles, lanes
-// n / n + 32 sharing the corner rows of a sample; with fewer than 4 samples per ray the head keeps k_mlp_wide<3>).
-static bool wide_jit(int xmode) {
-    const char *e = getenv("SN_WIDE_JIT");
-    (void)xmode;
-    if (e) return atoi(e) != 0;
-    return SN_WIDE_JIT != 0;
+// Which forward kernel: k_mlp_wide_j (operands just in time; SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms, 400x400 mask render
+// 7.49 -> 7.13 ms; bit-identical).  The superseded k_mlp_wide forward modes are compiled only into experiments builds (-DSN_EXPERIMENTS),
+// where sn_debug_set("wide_jit", 0) selects them for an A/B.  (With fewer than 4 samples per ray the fused mask head keeps k_mlp_wide<3>;
+// the backward-data pass is k_mlp_wide<4>.)
+#ifdef SN_EXPERIMENTS
+static int g_wide_jit = 1;
+static bool wide_jit(int xmode) { (void)xmode; return g_wide_jit != 0; }
+#else
+static constexpr bool wide_jit(int) { return true; }
+#endif
+
+extern "C" int sn_debug_set(const char *key, int value) {
+    SN_REQUIRE(key, "debug_set: NULL key");
+#ifdef SN_EXPERIMENTS
+    if (strcmp(key, "wide_jit") == 0) { g_wide_jit = value; return SN_OK; }
+    set_error("debug_set: unknown key '%s'", key);
+    return SN_ERR_INVALID;
+#else
+    (void)value;
+    set_error("debug_set('%s'): this library was built without -DSN_EXPERIMENTS (make exp)", key);
+    return SN_ERR_UNSUPPORTED;
+#endif
 }
 
 static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) {
@@ -1643,15 +1660,21 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     wa.out_lds = (mlp->dims[nl] == (uint32_t)WIDE && lds_cap >= out_need) ? 1u : 0u;
     if (wa.out_lds && lds < out_need) lds = out_need;
     wa.xs = xs;
+#ifdef SN_EXPERIMENTS
+#define SN_MLP_LAUNCH_OLD(MODE)                                                                                       \
+    do {                                                                                                              \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_mlp_wide<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);                     \
+    } while (0)
+#else
+#define SN_MLP_LAUNCH_OLD(MODE) do { } while (0)
+#endif
 #define SN_MLP_LAUNCH(MODE)                                                                                           \
     do {                                                                                                              \
         if (wide_jit(MODE)) {                                                                                         \
             SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL(k_mlp_wide_j<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);               \
-        } else {                                                                                                      \
-            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(k_mlp_wide<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);                 \
-        }                                                                                                             \
+        } else SN_MLP_LAUNCH_OLD(MODE);                                                                               \
     } while (0)
     if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
 #undef SN_MLP_LAUNCH
@@ -1818,6 +1841,7 @@ constexpr uint32_t WG_MAX_SLABS = 1024;   // workgroups = partial results; a wor
 
 __global__ __launch_bounds__(256) void k_linear_wgrad_partial(const float *__restrict__ x, const float *__restrict__ dy, uint32_t M,
                                                               uint32_t K, uint32_t N, float *__restrict__ partial) {
+    SN_POISON_ALL();
     __shared__ __attribute__((aligned(16))) float sx[WG_ROWS][64 + 4];
     __shared__ __attribute__((aligned(16))) float sy[WG_ROWS][64 + 4];
     const uint32_t t = threadIdx.x, tn = t >> 4, tk = t & 15u;          // 16 x 16 threads, 4 x 4 outputs each
@@ -1904,6 +1928,7 @@ __device__ __forceinline__ void wgrad_fold(float *v, uint32_t lane, uint32_t bas
 template <int K, int N>
 __global__ __launch_bounds__(256) void k_linear_wgrad_rows(const float *__restrict__ x, const float *__restrict__ dy, uint32_t M,
                                                            uint32_t rows_per_wave, float *__restrict__ partial) {
+    SN_POISON_ALL();
     const uint32_t lane = threadIdx.x & 63u, wg = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint64_t m0 = (uint64_t)wg * rows_per_wave;
     if (m0 >= M) return;
@@ -1958,6 +1983,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_rows(const float *__restri
 // loads (20 us per layer, seven layers per RGB-mode step); 64 lanes per output walk 16.
 template <uint32_t LPO>
 __global__ __launch_bounds__(256) void k_linear_wgrad_sum(const float *__restrict__ partial, uint32_t nslab, uint32_t NK, float *__restrict__ dw) {
+    SN_POISON_ALL();
     constexpr uint32_t OPB = 256u / LPO;                 // outputs per workgroup
     const uint32_t o = blockIdx.x * OPB + threadIdx.x / LPO, s = threadIdx.x % LPO;
     float v = 0.0f;
@@ -1972,6 +1998,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_sum(const float *__restric
 // the same sum for large outputs (NK % 4 == 0): 16 lanes x float4 = 256 contiguous bytes per slab, 16 slab groups per
 // workgroup each walking its slabs in order, then the 16 group sums are added in order through LDS
 __global__ __launch_bounds__(256) void k_linear_wgrad_sum4(const float4 *__restrict__ partial, uint32_t nslab, uint32_t NK4, float4 *__restrict__ dw) {
+    SN_POISON_ALL();
     __shared__ float4 red[16][16];
     const uint32_t ol = threadIdx.x & 15u, sg = threadIdx.x >> 4, o = blockIdx.x * 16u + ol;
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -2007,6 +2034,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_sum4(const float4 *__restr
 template <int CBW, bool VEC, bool FLAT, bool MSPLIT = false>
 __global__ __launch_bounds__(256, 1) void k_linear_wgrad_mfma(const float *__restrict__ x, const float *__restrict__ dy, uint32_t M,
                                                               uint32_t K, uint32_t N, uint32_t rows_per_slab, float *__restrict__ partial) {
+    SN_POISON_ALL();
     constexpr int RBW = FLAT ? 1 : 2;
     // steps (of 2 rows) whose operands are in flight ahead of the matrix cores: ~8k clocks of MFMA work, the latency
     // of a loaded HBM system (4 steps = 4k clocks left the 256 x 256 case waiting on loads: 193 us instead of ~110)
@@ -2177,7 +2205,7 @@ extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint
         SN_LAUNCH_CHECK("k_linear_wgrad_sum");
         return SN_OK;
     }
-    if (M >= 16384u && !getenv("SN_WGRAD_NO_MSPLIT")) {
+    if (M >= 16384u) {
         // <= 64 x 64 over many rows (the radiance MLP's layers): matrix cores, each wave its own slab of rows
         uint32_t rpw = sn::div_up(M, sn::WG_MAX_SLABS);
         rpw = rpw < sn::WG_ROWS ? sn::WG_ROWS : ((rpw + 1u) & ~1u);

@@ -38,6 +38,7 @@ __device__ __forceinline__ bool adam_one(float &p, float g, float &m, float &v, 
 }
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    SN_POISON_ALL();
     const uint64_t nq = a.n >> 2;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {

@@ -19,6 +19,7 @@ struct Aabb { float v[6]; };
 __global__ __launch_bounds__(256) void k_generate_rays(Pose pose, float fx, float fy, float cx, float cy,
                                                        uint32_t W, uint32_t first, uint32_t count,
                                                        float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    SN_POISON_ALL();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t n = first + t;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void k_rays_from_pixels(const float *__restric
                                                           const float *__restrict__ intr, uint32_t intr_stride,
                                                           const int64_t *__restrict__ inds, uint32_t W, uint32_t N,
                                                           float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float *m = poses + (size_t)n * pose_stride;        // 4x4 row-major cam2world
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void k_rays_from_pixels(const float *__restric
 __global__ __launch_bounds__(256) void k_near_far(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                   Aabb ab, float min_near, uint32_t N,
                                                   float *__restrict__ nears, float *__restrict__ fars) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float o[3] = {rays_o[(size_t)n * 3], rays_o[(size_t)n * 3 + 1], rays_o[(size_t)n * 3 + 2]};
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256) void k_near_far(const float *__restrict__ rays
 }
 
 __global__ __launch_bounds__(256) void k_contract(const float *__restrict__ x, uint32_t N, float *__restrict__ z) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float a = x[(size_t)n * 3], b = x[(size_t)n * 3 + 1], c = x[(size_t)n * 3 + 2];
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256) void k_contract(const float *__restrict__ x, u
 // device numerics primitives exposed element-wise for the parity tests (sn_debug_eval)
 __global__ __launch_bounds__(256) void k_debug_eval(int op, const float *__restrict__ a, const float *__restrict__ b, uint32_t n,
                                                     float *__restrict__ y) {
+    SN_POISON_ALL();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = a[i], w = b ? b[i] : 0.0f;
@@ -116,6 +121,7 @@ constexpr uint32_t RM_WAVE_PER_RAY_MAX = 65536;     // rays up to which sample_p
 __global__ __launch_bounds__(256) void k_sample_pdf(const float *__restrict__ bins, const float *__restrict__ weights,
                                                     uint32_t N, uint32_t T0, uint32_t T, const float *__restrict__ u,
                                                     uint32_t u_stride, float *__restrict__ out_bins, int32_t *__restrict__ inds) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float *w = weights + (size_t)n * T0;
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(256) void k_sample_pdf(const float *__restrict__ bi
 // nerf/renderer.py:308-325
 __global__ __launch_bounds__(256) void k_weights(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
                                                  uint32_t N, uint32_t T, int last_opaque, float *__restrict__ weights) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float *rb = real_bins + (size_t)n * (T + 1);
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(256) void k_weights(const float *__restrict__ real_
 // same values in the same order), so the results are bit-identical.
 __global__ __launch_bounds__(256) void k_weights_wave(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
                                                       uint32_t N, uint32_t T, int last_opaque, float *__restrict__ weights) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (n >= N) return;
     const float *rb = real_bins + (size_t)n * (T + 1);
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(256) void k_weights_wave(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_sample_pdf_wave(const float *__restrict__ bins, const float *__restrict__ weights,
                                                          uint32_t N, uint32_t T0, uint32_t T, const float *__restrict__ u,
                                                          uint32_t u_stride, float *__restrict__ out_bins, int32_t *__restrict__ inds) {
+    SN_POISON_ALL();
     extern __shared__ float pdf_lds[];                   // per wave: cdf[T0+1] | bins[T0+1]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_raw = blockIdx.x * 4u + wave;
@@ -275,6 +284,7 @@ __global__ __launch_bounds__(256) void k_sample_pdf_wave(const float *__restrict
 __global__ __launch_bounds__(256) void k_weights_backward(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
                                                           const float *__restrict__ grad_w, uint32_t N, uint32_t T, int last_opaque,
                                                           float *__restrict__ grad_sigmas) {
+    SN_POISON_ALL();
     const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (n >= N) return;
     const float *rb = real_bins + (size_t)n * (T + 1);
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(256) void k_sample_positions(const float *__restric
                                                           const float *__restrict__ nears, const float *__restrict__ fars,
                                                           const float *__restrict__ bins, uint32_t N, uint32_t T, int contract,
                                                           float *__restrict__ real_bins, float *__restrict__ rays_t, float *__restrict__ xyzs) {
+    SN_POISON_ALL();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)N * (T + 1)) return;
     const uint32_t n = (uint32_t)(t / (T + 1)), j = (uint32_t)(t - (uint64_t)n * (T + 1));
@@ -363,6 +374,7 @@ template <bool BACKWARD>
 __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__ bins, const float *__restrict__ weights,
                                                        const float *__restrict__ ref_bins, const float *__restrict__ ref_w,
                                                        uint32_t N, uint32_t T, uint32_t Tr, float *__restrict__ out) {
+    SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(8))) double pl_lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_raw = blockIdx.x * 4u + wave;
@@ -441,6 +453,7 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
 // value and the gradient at once:  loss_ray = (1/3) sum_k w_k^2 d_k + sum_k w_k S_k,  dloss_ray/dw_k = (2/3) w_k d_k + 2 S_k.
 __global__ __launch_bounds__(256) void k_distort_loss(const float *__restrict__ bins, const float *__restrict__ weights, uint32_t N,
                                                       uint32_t T, float *__restrict__ loss_per_ray, float *__restrict__ grad_w) {
+    SN_POISON_ALL();
     extern __shared__ float dl_lds[];                    // per wave: w[T] | m[T]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_raw = blockIdx.x * 4u + wave;
@@ -469,6 +482,7 @@ __global__ __launch_bounds__(256) void k_distort_loss(const float *__restrict__ 
 // out[n,k] = sum_t w[n,t] * v[n,t,k], sequential fmaf over t (renderer.py:333-338,361,384)
 __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ weights, const float *__restrict__ values,
                                                    uint32_t N, uint32_t T, uint32_t K, float *__restrict__ out) {
+    SN_POISON_ALL();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)N * K) return;
     const uint32_t n = (uint32_t)(t / K), k = (uint32_t)(t - (uint64_t)n * K);
@@ -481,6 +495,7 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ wei
 
 __global__ __launch_bounds__(256) void k_composite_backward(const float *__restrict__ weights, const float *__restrict__ grad_out,
                                                             uint32_t N, uint32_t T, uint32_t K, float *__restrict__ grad_values) {
+    SN_POISON_ALL();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)N * T * K) return;
     const uint32_t k = (uint32_t)(t % K);

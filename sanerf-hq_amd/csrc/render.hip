@@ -25,6 +25,7 @@
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cstdio>
 #include <type_traits>
 #include <vector>
 
@@ -795,6 +796,7 @@ __device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &
 #endif
 template <typename TT, int L, int C, int HID, int K>
 __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
+    SN_POISON_ALL();
     constexpr int IN = L * C;
     __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];   // k-major [IN][HID]
     __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];        // [1][HID]
@@ -1002,6 +1004,7 @@ constexpr uint32_t SP_STRIDE = SP_MAX_T + 4;   // floats per ray per LDS array
 
 template <typename TT, int L, int C, int HID, int K>
 __global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
+    SN_POISON_ALL();
     constexpr int IN = L * C;
     __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];
     __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];
@@ -1164,6 +1167,7 @@ constexpr int PACK_FLOATS = PACK_L3 + 32 * 64;   // 8192 floats = 32 KiB
 
 __global__ void k_pack_grid_mlp(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
                                 float *__restrict__ pack) {
+    SN_POISON_ALL();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint32_t)PACK_FLOATS) return;
     const uint32_t lane = t & 63u, vec = t >> 6;
@@ -1283,6 +1287,7 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &hi, uint32_t 
 
 __global__ void k_pack_grid_mlp_f16(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
                                     uint4 *__restrict__ pack) {
+    SN_POISON_ALL();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;        // one thread per (vec, lane)
     if (t >= (uint32_t)PACK16_VECS * 64u) return;
     const uint32_t lane = t & 63u, vec = t >> 6;
@@ -1668,6 +1673,7 @@ enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 // the plain one carries neither (one spilled register less in the march of the headline configuration)
 template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false, bool LT = false, bool L0L = false>
 __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_final_stage(FinalArgs a) {
+    SN_POISON_ALL();
     static_assert(!LT || (MODE == MLP_F16X3 && K >= 4 && K <= 8), "linear tail: split-fp16 MLP on the FinalLv path");
     static_assert(!L0L || (LT && sizeof(TT) == 2), "LDS-resident level 0: fp16 tables, linear-tail instantiation (80 KiB: 32 packed weights + 4 x 8 swizzled slabs + 16 level 0)");
     constexpr int SLAB_DW = L0L ? 16 : SLAB_STRIDE;       // dwords per slab row
@@ -2133,6 +2139,7 @@ __device__ __forceinline__ void dense_any(const float *__restrict__ W, uint32_t 
 
 template <typename TT>
 __global__ __launch_bounds__(256) void k_final_stage_any(FinalArgs a, AnyShape s) {
+    SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t rows = s.rows;                      // rows of a ping-pong buffer: the widest layer, rounded up to the unroll bucket
     float *bufA = lds + threadIdx.x, *bufB = lds + rows * 256u + threadIdx.x, *accf = lds + 2u * rows * 256u + threadIdx.x;
@@ -2263,399 +2270,9 @@ __global__ __launch_bounds__(256) void k_final_stage_any(FinalArgs a, AnyShape s
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// final stage, role-split waves (k_final_stage_rs; SN_RENDER_RS)
-// ------------------------------------------------------------------------------------------
-// In k_final_stage every wave alternates between two very different phases: the gather / blend phase (vector ALU + texture
-// path, bound by memory round trips: ~1.4 us each, four per sample, in-flight data limited by the registers the MLP holds) and
-// the matrix-core phase (accumulators + operand images that are dead weight during the gathers).  Here the two phases run in
-// different waves of one 768-thread workgroup (one per CU):
-//   * producer waves 0-7 own an 8x8-pixel tile each (the workgroup a 32x16 tile).  They do geometry, gathers and blends only,
-//     keep TWO gather spans in flight (issue span s+1, then blend span s -- no matrix-core registers to hold back), and hand
-//     the 32 features of every sample to a consumer through LDS in two 8-level halves;
-//   * consumer waves 8-11 (one per SIMD) each serve two producers: fp16 hi / lo split, the 32-64-64-16 MLP on the matrix cores,
-//     exp, ordered compositing (they hold the per-ray state of both producers' rays) and, at the end, the per-ray colour head.
-// Hand-over without workgroup barriers: per producer a ring of three half-sample images (64 rows x 16 floats, unpadded, 16-byte
-// blocks XOR-swizzled by (row >> 2) & 3: conflict-free for the consumers' ds_read_b128) and two monotonic counters in LDS --
-// halves published by the producer, halves taken by the consumer.  LDS serves one wave's instructions in order, so "data writes,
-// then counter write" / "data reads, then counter write" need no further fence; the waiting side polls with s_sleep.  A producer
-// runs up to 1.5 samples ahead of its consumer.  Arithmetic and its order are those of k_final_stage: bit-identical outputs.
-constexpr int RS_PROD = 8, RS_CONS = 4, RS_THREADS = (RS_PROD + RS_CONS) * 64;
-constexpr int RS_HALF = 64 * 16;                      // floats per half-sample image
-constexpr int RS_RING = 3;
-constexpr int RS_EXTRA = 2 * 128;                     // (delta[64], t_mid[64]) of two samples
-constexpr int RS_VIEW_W = 32 * 32 + 32 * 32 + 3 * 32; // padded view_mlp rows (31 -> 32)
-constexpr int RS_PER_PROD = RS_RING * RS_HALF + RS_EXTRA;
-constexpr int RS_OFF_VIEW = PACK_FLOATS;
-constexpr int RS_OFF_PROD = RS_OFF_VIEW + RS_VIEW_W;
-constexpr int RS_OFF_CNT = RS_OFF_PROD + RS_PROD * RS_PER_PROD;
-constexpr int RS_LDS_FLOATS = RS_OFF_CNT + 2 * RS_PROD;
-
-// gather spans of a producer: an even number, a boundary at level 8 (the half-sample images), span 0 dense
-#ifndef SN_RS_SPANS
-#define SN_RS_SPANS 8
+#ifdef SN_EXPERIMENTS
+#include "render_experiments.inc"
 #endif
-#if SN_RS_SPANS == 6
-template <typename T> struct RsSpans { static constexpr int N = 6; static constexpr int B[7] = {0, 2, 5, 8, 11, 14, 16}; static constexpr int MG = 3; };
-#elif SN_RS_SPANS == 8
-template <typename T> struct RsSpans { static constexpr int N = 8; static constexpr int B[9] = {0, 2, 4, 6, 8, 10, 12, 14, 16}; static constexpr int MG = 2; };
-#else
-template <typename T> struct RsSpans { static constexpr int N = 4; static constexpr int B[5] = {0, 4, 8, 12, 16}; static constexpr int MG = 4; };
-#endif
-
-typedef __attribute__((address_space(3))) uint32_t rs_lds_u32;     // counters are LDS words: ds_read / ds_write, never flat accesses
-__device__ __forceinline__ uint32_t rs_lds_load(const uint32_t *p) {
-    return __builtin_amdgcn_readfirstlane(*(const volatile rs_lds_u32 *)p);
-}
-// wait until the counter at p (monotonic, written by ONE other wave of the workgroup) has reached `target`
-__device__ __forceinline__ void rs_wait_ge(const uint32_t *p, uint32_t target) {
-    while ((int32_t)(rs_lds_load(p) - target) < 0) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void rs_publish(uint32_t *p, uint32_t v) {
-    asm volatile("" ::: "memory");
-    if ((threadIdx.x & 63u) == 0u) *(volatile rs_lds_u32 *)p = v;
-    asm volatile("" ::: "memory");
-}
-
-// workgroup tile -> ray of a producer lane.  Tile mode: workgroup = 32x16 pixels, producer wave pw = 8x8 pixels at
-// ((pw & 3) * 8, (pw >> 2) * 8).  `col` = the ray's column in the proposal stages' [T][Npad] scratch (their 16x16 tiling).
-__device__ __forceinline__ bool rs_ray_of_lane(const RayCommon &rc, uint32_t wg, uint32_t pw, uint32_t lane, uint32_t &n, uint32_t &col) {
-    if (rc.W) {
-        const uint32_t tiles_x = (rc.W + 31u) >> 5;
-        const uint32_t by = wg / tiles_x, bx = wg - by * tiles_x;
-        const uint32_t py = by * 16u + (pw >> 2) * 8u + (lane >> 3);
-        const uint32_t px = bx * 32u + (pw & 3u) * 8u + (lane & 7u);
-        const bool ok = px < rc.W && py < rc.rows;
-        n = ok ? py * rc.W + px : 0u;
-        // the other stages' wave-tile order (ray_of_lane): pairs of wave-tile rows column-major, an odd last row left to right
-        const uint32_t tx8 = (rc.W + 7u) >> 3, ty8 = (rc.rows + 7u) >> 3, wx = px >> 3, wy = py >> 3;
-        const uint32_t g = wy < (ty8 & ~1u) ? (wy >> 1) * 2u * tx8 + wx * 2u + (wy & 1u) : (ty8 >> 1) * 2u * tx8 + wx;
-        col = ok ? g * 64u + (py & 7u) * 8u + (px & 7u) : 0u;
-        return ok;
-    }
-    n = wg * (uint32_t)(RS_PROD * 64) + pw * 64u + lane;
-    const bool ok = n < rc.N;
-    if (!ok) n = 0;
-    col = n;
-    return ok;
-}
-
-// the 32-64-64-16 MLP of one wave-sample with the first layer's B operands already in registers ([tile][k-step]);
-// otherwise grid_mlp_mfma16 (same products, same order)
-__device__ __forceinline__ void grid_mlp_mfma16_regs(const uint4 *__restrict__ pk, const uint4 (&b1h)[2][2], const uint4 (&b1l)[2][2], float (&out)[16]) {
-    const uint32_t lane = threadIdx.x & 63u;
-    float res[2][8];
-#pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
-        floatx16 h1[2], h2[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const int vec = mt * 2 + st;
-                acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], b1h[tile][st], b1l[tile][st], acc);
-            }
-            h1[mt] = acc;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint4 bh, bl;
-                acc_to_b(h1[q >> 1], q & 1, bh, bl);
-                const int vec = 4 + mt * 4 + q;
-                acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
-            }
-            h2[mt] = acc;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint4 bh, bl;
-            acc_to_b(h2[q >> 1], q & 1, bh, bl);
-            const int vec = 12 + q;
-            acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) res[tile][r] = acc[r];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(res[0][r]), __float_as_uint(res[1][r]), false, false);
-        const int base = (r & 3) + 8 * (r >> 2);
-        out[base] = __uint_as_float(rr[0]);
-        out[base + 4] = __uint_as_float(rr[1]);
-    }
-}
-
-template <typename T, int L0, int G, int K, bool FAST, int MG>
-__device__ __forceinline__ void issue_span_into(const FinalLv &lv, const float (&x01)[3], GroupRegs<T, 2, MG> &r) {
-    static_for<0, G>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        constexpr int l = L0 + k;
-        constexpr bool DENSE = l < K;
-        issue_level_lv<T, DENSE, FAST, xswap_level<T, DENSE ? 0 : 1, l>(), l>(lv, x01, r.pos[k], r.cv[k]);
-    });
-}
-template <typename T, int L0, int G, int K, int MG, typename Emit>
-__device__ __forceinline__ void blend_span_from(const GroupRegs<T, 2, MG> &r, Emit emit) {
-    static_for<0, G>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        constexpr int l = L0 + k;
-        constexpr int KIND = l < K ? 0 : 1;
-        float acc[2];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
-        emit(std::integral_constant<int, l>{}, acc);
-    });
-}
-
-#ifndef SN_RS_ABLATE
-#define SN_RS_ABLATE 0       // timing experiments (wrong results): 1 = consumers skip the MLP, 2 = producers skip gathers and blends
-#endif
-#ifndef SN_RS_BOUNDS
-#define SN_RS_BOUNDS RS_THREADS
-#endif
-#ifndef SN_RS_ONLY
-#define SN_RS_ONLY 0         // register diagnostics: 1 = producer code only, 2 = consumer code only
-#endif
-template <typename TT, int K>
-__global__ __launch_bounds__(SN_RS_BOUNDS, 1) void k_final_stage_rs(FinalArgs a) {
-    constexpr int GEO = 15, NSH = 16, NCOL = GEO + NSH, VH = 32;
-    constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;
-    static_assert(VW0 + VW1 + 3 * PadIn<VH>::value == RS_VIEW_W, "view weight image");
-    using SP = RsSpans<TT>;
-    static_assert(SP::N % 2 == 0 && SP::B[SP::N] == 16 && SP::B[1] <= K, "spans: even count, 16 levels, span 0 dense");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)PACK16_U4; i += (uint32_t)RS_THREADS)
-        reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.mlp_pack)[i];
-    float *lds_vw = lds + RS_OFF_VIEW;
-    stage_weights<NCOL, VH>(lds_vw, a.vw[0]);
-    stage_weights<VH, VH>(lds_vw + VW0, a.vw[1]);
-    stage_weights<VH, 3>(lds_vw + VW0 + VW1, a.vw[2]);
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds + RS_OFF_CNT);      // [0..7] halves published, [8..15] halves taken
-    if (threadIdx.x < 2u * RS_PROD) cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    clock_probe(0);
-
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t wg = tile_id(a.rc);
-    const uint32_t T = a.T, Npad = a.rc.Npad;
-
-    if (SN_RS_ONLY != 2 && wave < (uint32_t)RS_PROD) {
-        // =============================== producer ===============================
-        const uint32_t pw = wave;
-        float *ring = lds + RS_OFF_PROD + pw * RS_PER_PROD;
-        float *extra = ring + RS_RING * RS_HALF;
-        uint32_t *published = cnt + pw;
-        const uint32_t *taken = cnt + RS_PROD + pw;
-        uint32_t n, col;
-        rs_ray_of_lane(a.rc, wg, pw, lane, n, col);
-        RaySetup rs;
-        setup_ray(a.rc, n, rs);
-        const float b0step = 1.0f / (float)T;
-        auto bin_at = [&](uint32_t j) -> float {
-            if (a.bins_in) return a.bins_in[(size_t)j * Npad + col];
-            if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
-            return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
-        };
-        // this lane's row in a half image: 16 floats, 16-byte blocks swizzled by (row >> 2) & 3
-        const uint32_t row_off = lane * 16u, sw = (lane >> 2) & 3u;
-
-        float rb_prev = real_bin(rs, bin_at(0));
-        float rb_next_n = real_bin(rs, bin_at(1));
-        float tmid_n = (rb_next_n + rb_prev) / 2.0f;
-        float p_n[3], x01_n[3];
-        sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-        bool fast_n = all_interior(a.lv, x01_n);
-        GroupRegs<TT, 2, SP::MG> buf[2];
-        issue_span_into<TT, 0, SP::B[1], K, false>(a.lv, x01_n, buf[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t slot = 0;                                  // ring slot of the half being written (= half number mod 3)
-        for (uint32_t j = 0; j < T; ++j) {
-            const float rb_next = rb_next_n, tmid = tmid_n;
-            const float delta = rb_next - rb_prev;
-            const float x01[3] = {x01_n[0], x01_n[1], x01_n[2]};
-            auto sample = [&](auto fast_tag) {
-                constexpr bool FAST = decltype(fast_tag)::value;
-                bool oob = false;
-                if constexpr (!FAST) oob = (x01[0] < 0.0f || x01[0] > 1.0f) || (x01[1] < 0.0f || x01[1] > 1.0f) || (x01[2] < 0.0f || x01[2] > 1.0f);
-                static_for<0, SP::N>([&](auto ss) {
-                    constexpr int s = decltype(ss)::value, L0 = SP::B[s], G = SP::B[s + 1] - L0;
-                    if constexpr (s + 1 < SP::N) {
-                        issue_span_into<TT, SP::B[s + 1], SP::B[s + 2] - SP::B[s + 1], K, FAST>(a.lv, x01, buf[(s + 1) & 1]);
-                    } else {   // geometry of sample j+1 (the last iteration re-issues its own sample: in bounds, unused) and its span 0
-                        const uint32_t jn = j + 2u <= T ? j + 2u : T;
-                        rb_next_n = real_bin(rs, bin_at(jn));
-                        const float rbp = j + 2u <= T ? rb_next : rb_prev;
-                        tmid_n = (rb_next_n + rbp) / 2.0f;
-                        sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-                        fast_n = all_interior(a.lv, x01_n);
-                        issue_span_into<TT, 0, SP::B[1], K, false>(a.lv, x01_n, buf[0]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (L0 == 0 || L0 == 8) {
-                        // half number h = 2j + (L0 == 8) overwrites half h - 3: taken once the consumer's count reached h - 2
-                        rs_wait_ge(taken, 2u * j + (L0 == 8 ? 1u : 0u) - 2u);
-                        if constexpr (L0 == 0) { extra[(j & 1u) * 128u + lane] = delta; extra[(j & 1u) * 128u + 64u + lane] = tmid; }
-                    }
-                    float *half = ring + slot * RS_HALF + row_off;
-                    blend_span_from<TT, L0, G, K>(buf[s & 1], [&](auto ll, const float (&acc)[2]) {
-                        constexpr int l8 = decltype(ll)::value & 7;
-                        float2 v = make_float2(acc[0], acc[1]);
-                        if constexpr (!FAST) { if (oob) v = make_float2(0.0f, 0.0f); }      // gridencoder.cu:105-130: zeros outside [0,1]
-                        *reinterpret_cast<float2 *>(half + (((uint32_t)(l8 >> 1) ^ sw) * 4u) + 2u * (l8 & 1)) = v;
-                    });
-                    if constexpr (SP::B[s + 1] == 8 || SP::B[s + 1] == 16) {
-                        rs_publish(published, 2u * j + (SP::B[s + 1] == 16 ? 2u : 1u));
-                        slot = slot == (uint32_t)(RS_RING - 1) ? 0u : slot + 1u;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            };
-#if SN_RS_ABLATE & 2
-            {   // timing experiment: no gathers, no blends -- geometry, hand-over and the consumer side only
-                for (int hf = 0; hf < 2; ++hf) {
-                    rs_wait_ge(taken, 2u * j + (uint32_t)hf - 2u);
-                    if (hf == 0) { extra[(j & 1u) * 128u + lane] = delta; extra[(j & 1u) * 128u + 64u + lane] = tmid; }
-                    float *half = ring + slot * RS_HALF + row_off;
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(half + 4 * q) = make_float4(x01[0], x01[1], x01[2], tmid);
-                    rs_publish(published, 2u * j + (uint32_t)hf + 1u);
-                    slot = slot == (uint32_t)(RS_RING - 1) ? 0u : slot + 1u;
-                }
-                const uint32_t jn = j + 2u <= T ? j + 2u : T;
-                rb_next_n = real_bin(rs, bin_at(jn));
-                const float rbp = j + 2u <= T ? rb_next : rb_prev;
-                tmid_n = (rb_next_n + rbp) / 2.0f;
-                sample_x01(a.rc, rs, tmid_n, p_n, x01_n);
-            }
-#else
-            if (__builtin_expect(fast_n, 1)) sample(std::true_type{});      // fast_n here: decided for THIS sample one iteration ago
-            else sample(std::false_type{});
-#endif
-            rb_prev = rb_next;
-        }
-        clock_probe(1);                 // (thread 0 is a producer: its exit, a little before the consumers' colour head)
-        return;
-    }
-
-    // =============================== consumer ===============================
-    if (SN_RS_ONLY == 1) return;
-    const uint32_t cw = wave - (uint32_t)RS_PROD;
-    const uint32_t lo = lane & 31u, hi = lane >> 5;
-    float fimg[2][GEO];
-    float dep[2] = {0.0f, 0.0f};
-    double cum[2] = {0.0, 0.0}, wsum[2] = {0.0, 0.0};
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-        for (int c = 0; c < GEO; ++c) fimg[pp][c] = 0.0f;
-    uint32_t slot = 0;
-    for (uint32_t j = 0; j < T; ++j) {
-        const uint32_t slot1 = slot == (uint32_t)(RS_RING - 1) ? 0u : slot + 1u;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const uint32_t pw = cw + 4u * (uint32_t)pp;
-            const float *ring = lds + RS_OFF_PROD + pw * RS_PER_PROD;
-            const float *extra = ring + RS_RING * RS_HALF;
-            rs_wait_ge(cnt + pw, 2u * j + 2u);
-            uint4 b1h[2][2], b1l[2][2];
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const float *half = ring + (st ? slot1 : slot) * RS_HALF;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const uint32_t row = (uint32_t)t * 32u + lo, sw = (row >> 2) & 3u;
-                    const float4 u = *reinterpret_cast<const float4 *>(half + row * 16u + (((2u * hi) ^ sw) * 4u));
-                    const float4 v = *reinterpret_cast<const float4 *>(half + row * 16u + (((2u * hi + 1u) ^ sw) * 4u));
-                    split2(u.x, u.y, b1h[t][st].x, b1l[t][st].x); split2(u.z, u.w, b1h[t][st].y, b1l[t][st].y);
-                    split2(v.x, v.y, b1h[t][st].z, b1l[t][st].z); split2(v.z, v.w, b1h[t][st].w, b1l[t][st].w);
-                }
-            }
-            const float delta = extra[(j & 1u) * 128u + lane], tmid = extra[(j & 1u) * 128u + 64u + lane];
-            rs_publish(cnt + RS_PROD + pw, 2u * j + 2u);
-            float h[16];
-#if SN_RS_ABLATE & 1
-            for (int k = 0; k < 16; ++k) h[k] = __uint_as_float((b1h[k & 1][(k >> 1) & 1].x ^ b1l[k & 1][(k >> 1) & 1].y) & 0x3fffffffu);
-#else
-            grid_mlp_mfma16_regs(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), b1h, b1l, h);
-#endif
-            // network.py:151, renderer.py:308-325 -- the statements of k_final_stage, in its order
-            const float sigma = expf_det(h[0]);
-            float ds = delta * sigma;
-            if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
-            const float alpha = 1.0f - expf_det(-ds);
-            const float tr = expf_det(-(float)cum[pp]);
-            float w = alpha * tr;
-            if (w != w) w = 0.0f;
-            cum[pp] += (double)ds;
-            wsum[pp] += (double)w;
-            dep[pp] = __builtin_fmaf(w, tmid, dep[pp]);
-#pragma unroll
-            for (int c = 0; c < GEO; ++c) fimg[pp][c] = __builtin_fmaf(w, h[1 + c], fimg[pp][c]);
-        }
-        slot = slot1 == (uint32_t)(RS_RING - 1) ? 0u : slot1 + 1u;
-    }
-    // ---- per-ray colour head of both producers' rays (renderer.py:340-357); the producers are done with their rings ----
-#pragma unroll 1
-    for (int pp = 0; pp < 2; ++pp) {
-        const uint32_t pw = cw + 4u * (uint32_t)pp;
-        float *fe = lds + RS_OFF_PROD + pw * RS_PER_PROD + lane;
-        constexpr uint32_t fstride = 64u;
-        uint32_t n, col;
-        const bool ok = rs_ray_of_lane(a.rc, wg, pw, lane, n, col);
-        float dirn[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dirn[k] = a.rc.rays_d[(size_t)n * 3 + k];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {      // normalised twice like the reference (renderer.py:294, sphere_harmonics.py:82)
-            const float aa = dirn[0] * dirn[0], bb = dirn[1] * dirn[1], cc = dirn[2] * dirn[2];
-            const float nrm = sqrtf((aa + bb) + cc);
-            dirn[0] = dirn[0] / nrm; dirn[1] = dirn[1] / nrm; dirn[2] = dirn[2] / nrm;
-        }
-        const float ws = (float)(pp ? wsum[1] : wsum[0]);
-        float col31[NCOL];
-#pragma unroll
-        for (int c = 0; c < GEO; ++c) col31[c] = pp ? fimg[1][c] : fimg[0][c];
-        {
-            float sh[NSH];
-            sh_degree4(dirn[0], dirn[1], dirn[2], sh);
-#pragma unroll
-            for (int c = 0; c < NSH; ++c) col31[GEO + c] = sh[c] * ws;
-        }
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) fe[c * fstride] = col31[c];
-        dense_ldsw_col<NCOL, VH, 1>(lds_vw, fe, fe, fstride);
-        dense_ldsw_col<VH, VH, 1>(lds_vw + VW0, fe, fe, fstride);
-        float rgb[3];
-        {
-            float v2[VH];
-#pragma unroll
-            for (int k = 0; k < VH; ++k) v2[k] = fe[k * fstride];
-            dense_ldsw<VH, 3, 0>(lds_vw + VW0 + VW1, v2, rgb);
-        }
-        if (ok) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float sg = 1.0f / (1.0f + expf_det(-rgb[c]));
-                const float bgm = (1.0f - ws) * a.rc.bg;
-                a.image[(size_t)n * 3 + c] = sg + bgm;
-            }
-            a.depth[n] = pp ? dep[1] : dep[0];
-            a.wsum[n] = ws;
-            if (a.dbg_fimg) {
-#pragma unroll
-                for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = col31[c];
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // final stage with per-ray termination and wave-level compaction of live samples (opt-in: cfg->compact_live)
@@ -2681,6 +2298,7 @@ constexpr uint32_t CMP_KMAX = 4;
 
 template <typename TT, int K>
 __global__ __launch_bounds__(256, 2) void k_final_stage_cmp(FinalArgs a) {
+    SN_POISON_ALL();
     constexpr int L = 16, GEO = 15, NSH = 16, NCOL = GEO + NSH, VH = 32, PG = 4, IN = 32;
     constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;
     constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;
@@ -2920,6 +2538,7 @@ static size_t final_sp_lds_floats(uint32_t spl) {
 
 template <typename TT, int K>
 __global__ __launch_bounds__(256, 1) void k_final_stage_sp(FinalArgs a, uint32_t lpr_log2, uint32_t spl_log2) {
+    SN_POISON_ALL();
     constexpr int L = 16, GEO = 15, NSH = 16, NCOL = GEO + NSH, VH = 32, PG = 4;
     constexpr int VW0 = VH * PadIn<NCOL>::value, VW1 = VH * PadIn<VH>::value;
     constexpr int WAVE_SLAB = 2 * 64 * SLAB_STRIDE;
@@ -3119,6 +2738,7 @@ struct FeatArgs {
 
 template <typename TT, int C, int LG>
 __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
+    SN_POISON_ALL();
     uint32_t n;
     const uint32_t wg = tile_id_x(a.rc, blockIdx.x, gridDim.x);
     const bool ok = ray_of_lane(a.rc, wg, n);
@@ -3207,6 +2827,7 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
 // thread per (level < K, row); 16 bytes per vertex either way
 template <typename T>
 __global__ void k_pack_pairs(const T *__restrict__ table, GridLevels g, PairTab pt, uint32_t K) {
+    SN_POISON_ALL();
     const uint32_t l = blockIdx.y;
     if (l >= K) return;
     const uint32_t res = g.res[l], rows = res * res * res;
@@ -3264,6 +2885,8 @@ static bool build_final_lv(const GridLevels &g, int K, const PairTab &pt, const 
     return true;
 }
 
+static thread_local sn_launch_info g_launch = {};
+
 enum { PK_PACK = 0, PK_PROP0, PK_PROP1, PK_PROP2, PK_FINAL, PK_FEAT, PK_CLASSES };
 struct ProfSpan { hipEvent_t a, b; int cls; };
 static bool g_prof_on = false;
@@ -3311,29 +2934,30 @@ static uint32_t chunk_rays(uint32_t N, uint32_t W) {
     return cap;
 }
 
-// rays per render_rays chunk up to which the proposal stages run sample-parallel; SN_PROP_SP_MAX overrides (0 = never)
-static uint32_t prop_sp_max_rays() {
-    const char *e = getenv("SN_PROP_SP_MAX");
-    return e ? (uint32_t)strtoul(e, nullptr, 10) : 32768u;   // tools/prop_sp_ab.py: faster up to 32k rays, slower from 64k
+// rays per render_rays chunk up to which the stages run sample-parallel (sn_render_tuning: 0 = the default, < 0 = never)
+static uint32_t prop_sp_max_rays(const sn_render_cfg *cfg) {
+    const int32_t v = cfg->tuning.prop_sp_max_rays;
+    return v == 0 ? 32768u : v < 0 ? 0u : (uint32_t)v;        // tools/prop_sp_ab.py: faster up to 32k rays, slower from 64k
 }
 
-static uint32_t final_sp_max_rays() {
-    const char *e = getenv("SN_FINAL_SP_MAX");
-    return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u;
+static uint32_t final_sp_max_rays(const sn_render_cfg *cfg) {
+    const int32_t v = cfg->tuning.final_sp_max_rays;
+    return v == 0 ? 16384u : v < 0 ? 0u : (uint32_t)v;
 }
 
 // the linear-tail form of the default final stage (third layer's geometry rows applied once per ray) is used wherever no
-// per-sample tensor leaves the kernel; SN_RENDER_LT=0 keeps the per-sample form (bit-identical to the compacting / several-lanes-
-// per-ray / role-split kernels, which all evaluate the third layer per sample)
-static bool lt_enabled() {
-    const char *e = getenv("SN_RENDER_LT");
-    return !(e && e[0] == '0');
-}
+// per-sample tensor leaves the kernel; tuning.per_sample_form keeps the per-sample form (bit-identical to the compacting /
+// several-lanes-per-ray / role-split kernels, which all evaluate the third layer per sample)
+static bool lt_enabled(const sn_render_cfg *cfg) { return cfg->tuning.per_sample_form == 0; }
 
-// SN_RENDER_RS=1: the role-split final stage (k_final_stage_rs) where it applies
-static bool rs_enabled() {
-    const char *e = getenv("SN_RENDER_RS");
-    return e && e[0] == '1';
+// the role-split final stage (k_final_stage_rs, experiments builds) where it applies
+static bool rs_enabled(const sn_render_cfg *cfg) {
+#ifdef SN_EXPERIMENTS
+    return cfg->tuning.experiment == SN_EXP_ROLE_SPLIT;
+#else
+    (void)cfg;
+    return false;
+#endif
 }
 
 static uint32_t blocks_for(uint32_t n, uint32_t W) {
@@ -3354,6 +2978,23 @@ static size_t stage_scratch_floats(const sn_render_cfg *cfg, uint32_t Npad) {
 using namespace sn;
 
 extern "C" {
+
+int sn_build_flags(void) {
+    int f = 0;
+#ifdef SN_EXPERIMENTS
+    f |= SN_BUILD_EXPERIMENTS;
+#endif
+#ifdef SN_POISON_LDS
+    f |= SN_BUILD_POISON_LDS;
+#endif
+    return f;
+}
+
+int sn_rm_last_launch_info(sn_launch_info *info) {
+    SN_REQUIRE(info, "last_launch_info: NULL output");
+    *info = g_launch;
+    return SN_OK;
+}
 
 void sn_rm_profile_enable(int on) {
     g_prof_on = on != 0;
@@ -3426,14 +3067,13 @@ int sn_rm_debug_occupancy(int32_t *out, int32_t *lds, int n) {
 // SN_RENDER_DENSIFY: unset = automatic, 0 = never, 1 / 2 = force that many levels.
 constexpr uint64_t DENSIFY_MIN_SAMPLES = 64ull << 20;       // rays x samples of the last stage (the 69 MB pack costs ~55 us more than the plain one and buys 1.6 % of the kernel: break-even near 45 M)
 constexpr uint64_t DENSIFY_MAX_VERTICES = 6ull << 20;       // 96 MB of 16-byte rows
-static int densify_levels(const GridLevels &g, int K, uint64_t samples, bool f16 = true) {
+// mode = sn_render_tuning.densify: 0 automatic, 1 never, 2 whenever the kernel exists
+static int densify_levels(const GridLevels &g, int K, uint64_t samples, bool f16, int mode) {
     if (K != 5 || g.L != 16 || g.C != 2) return K;           // (the K + 2 = 7 instantiation is built for the main grid's shape)
-    const char *e = getenv("SN_RENDER_DENSIFY");
     // automatic for fp16 tables only: 800x800 [128] 6.35 -> 6.22 ms incl. the pack; with fp32 tables the K = 7 instantiation spills 14
     // registers and the call comes out 0.4 % slower (6.957 -> 6.983 ms)
-    int want = (samples >= DENSIFY_MIN_SAMPLES && f16) ? 2 : 0;
-    if (e && e[0] >= '0' && e[0] <= '2') want = e[0] - '0';
-    if (want != 2) return K;                                 // one extra level alone is not instantiated
+    const bool want = mode == 2 || (mode == 0 && samples >= DENSIFY_MIN_SAMPLES && f16);
+    if (!want) return K;                                     // one extra level alone is not instantiated
     uint64_t v = 0;
     for (int l = 0; l < K + 2; ++l) {
         if ((uint64_t)g.res[l] * g.res[l] * 16u >= (1u << 24)) return K;      // dense byte strides go through 24-bit multiplies
@@ -3442,18 +3082,18 @@ static int densify_levels(const GridLevels &g, int K, uint64_t samples, bool f16
     return v <= DENSIFY_MAX_VERTICES ? K + 2 : K;
 }
 
-// floats reserved after the packed MLP weights for the pair / quad rows of one grid's dense (and densified) levels (16 bytes
-// per vertex for either table type)
-static size_t pair_floats_of(const sn_grid_desc *d, uint64_t densify_samples = 0) {
+// floats of a grid's packed pair / quad rows; densify_samples != 0: the main grid, whose levels 5-6 may be densified for this call
+// (sized by the same rule the launch applies: table dtype and tuning.densify)
+static size_t pair_floats_of(const sn_grid_desc *d, uint64_t densify_samples = 0, int densify_mode = 1) {
     GridLevels g;
     if (d->D != 3 || d->C != 2 || build_grid_levels(&g, d->offsets, d->D, d->C, d->L, d->S, d->H, d->gridtype, (int)d->align_corners, d->interp) != SN_OK) return 0;
     if (!levels_fast(g)) return 0;
     uint32_t off[8];
     const int K = dense_prefix(g);
-    return (size_t)pair_layout(g, densify_samples ? densify_levels(g, K, densify_samples) : K, off) * 4u;
+    return (size_t)pair_layout(g, densify_samples ? densify_levels(g, K, densify_samples, d->table_dtype == SN_F16, densify_mode) : K, off) * 4u;
 }
 static size_t pair_region_floats(const sn_render_cfg *cfg, uint64_t main_samples) {
-    size_t f = pair_floats_of(&cfg->grid, main_samples);
+    size_t f = pair_floats_of(&cfg->grid, main_samples, cfg->tuning.densify);
     for (uint32_t k = 0; k + 1 < cfg->num_stages && k < SN_MAX_STAGES; ++k) f += pair_floats_of(&cfg->prop_grid[k]);
     return f;
 }
@@ -3469,6 +3109,7 @@ size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
     SN_REQUIRE(cfg && io, "render_rays: cfg/io is NULL");
     if (io->N == 0) return SN_OK;   // empty batch: nothing to launch, pointers may be NULL
+    g_launch = sn_launch_info{};
     SN_REQUIRE(io->rays_o && io->rays_d, "render_rays: rays must be device pointers");
     if (io->skip_final) SN_REQUIRE(cfg->num_stages >= 2 && io->bins[cfg->num_stages - 1] && !cfg->with_feat,
                                    "render_rays: skip_final needs >= 2 stages, io->bins[last] for the resampled bins, and no feature stage");
@@ -3555,18 +3196,24 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                       "interpolation (network.py:103); use sn_rm_grid_composite for other grids");
             return SN_ERR_UNSUPPORTED;
         }
-        if (const char *e = getenv("SN_FEAT_LEVELS")) feat_lg = atoi(e);
+        if (cfg->tuning.feat_levels) feat_lg = cfg->tuning.feat_levels;
         if (feat_lg != 1 && feat_lg != 2 && feat_lg != 4) feat_lg = 2;
         while (gl_feat.L % (uint32_t)feat_lg) feat_lg >>= 1;
     }
-    // SN_RENDER_MLP = f16x3 (default: fp16 hi/lo split on the matrix cores, fp32 accumulate),
-    //                 mfma32 / mfma (exact fp32 v_mfma_f32_32x32x2_f32), valu (vector-ALU fallback)
-    const char *mode = getenv("SN_RENDER_MLP");
+    // tuning.mlp_mode: SN_MLP_AUTO (fp16 hi/lo split on the matrix cores, fp32 accumulate, unless cfg->mlp_exact_fp32), SN_MLP_F16X3 (forced),
+    //                  SN_MLP_MFMA32 (exact fp32 v_mfma_f32_32x32x2_f32), SN_MLP_VALU (vector-ALU fallback)
     int mlp_mode = cfg->mlp_exact_fp32 ? MLP_F32 : MLP_F16X3;
-    if (mode && strcmp(mode, "valu") == 0) mlp_mode = MLP_VALU;
-    else if (mode && (strcmp(mode, "mfma32") == 0 || strcmp(mode, "mfma") == 0)) mlp_mode = MLP_F32;
-    else if (mode && strcmp(mode, "f16x3") == 0) mlp_mode = MLP_F16X3;
-    else if (mode && mode[0]) { set_error("render_rays: unknown SN_RENDER_MLP=%s", mode); return SN_ERR_INVALID; }
+    switch (cfg->tuning.mlp_mode) {
+        case SN_MLP_AUTO: break;
+        case SN_MLP_F16X3: mlp_mode = MLP_F16X3; break;
+        case SN_MLP_MFMA32: mlp_mode = MLP_F32; break;
+        case SN_MLP_VALU: mlp_mode = MLP_VALU; break;
+        default: set_error("render_rays: unknown tuning.mlp_mode=%d", cfg->tuning.mlp_mode); return SN_ERR_INVALID;
+    }
+    if (cfg->tuning.experiment != SN_EXP_NONE && !(sn_build_flags() & SN_BUILD_EXPERIMENTS)) {
+        set_error("render_rays: tuning.experiment=%d needs a library built with -DSN_EXPERIMENTS (make exp)", cfg->tuning.experiment);
+        return SN_ERR_UNSUPPORTED;
+    }
     const bool use_mfma = mlp_mode != MLP_VALU;
 
     SN_REQUIRE(io->workspace != nullptr, "render_rays: workspace is NULL");
@@ -3575,10 +3222,10 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     const uint64_t main_samples = (uint64_t)io->N * cfg->num_steps[S - 1];
     const size_t pair_floats = pair_region_floats(cfg, main_samples);       // (as sn_rm_render_workspace_bytes sized it)
     // will the last stage run as the plain linear-tail kernel?  Only that one has the instantiation that reads densified levels.
-    const bool plain_lt = mlp_mode == MLP_F16X3 && lt_enabled() && !rs_enabled() && !cfg->with_feat && !cfg->compact_live && !io->skip_final &&
+    const bool plain_lt = mlp_mode == MLP_F16X3 && lt_enabled(cfg) && !rs_enabled(cfg) && !cfg->with_feat && !cfg->compact_live && !io->skip_final &&
                           !(cfg->early_stop_eps > 0.0f && cfg->early_stop_eps < 1.0f) && dense_prefix(gl_main) == 5 &&
                           !(io->bins[S - 1] || io->weights[S - 1] || io->sigmas[S - 1] || io->xyzs_last || io->geo_feat_last);
-    const int Kv_main = plain_lt ? densify_levels(gl_main, 5, main_samples, cfg->grid.table_dtype == SN_F16) : dense_prefix(gl_main);
+    const int Kv_main = plain_lt ? densify_levels(gl_main, 5, main_samples, cfg->grid.table_dtype == SN_F16, cfg->tuning.densify) : dense_prefix(gl_main);
     float *pair_mem = pack + PACK_FLOATS;
     float *scratch = pair_mem + pair_floats;
     const size_t head_floats = (size_t)PACK_FLOATS + pair_floats;
@@ -3617,7 +3264,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         ProfScope ps(st, PK_PACK);
         // (the main grid's region is sized for the densified layout whenever the sample count allows it; levels 5-6 are packed only
         //  when the kernel that reads them will run)
-        int rcp = pack_pairs(&cfg->grid, gl_main, pairs, is_any ? 0 : Kv_main, pair_floats_of(&cfg->grid, main_samples));
+        int rcp = pack_pairs(&cfg->grid, gl_main, pairs, is_any ? 0 : Kv_main, pair_floats_of(&cfg->grid, main_samples, cfg->tuning.densify));
         if (rcp) return rcp;
         for (uint32_t k = 0; k + 1 < S; ++k) {
             rcp = pack_pairs(&cfg->prop_grid[k], gl_prop[k], prop_pairs[k], dense_prefix(gl_prop[k]), pair_floats_of(&cfg->prop_grid[k]));
@@ -3660,9 +3307,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             const float m = frexpf(2.0f * cfg->bound, &e);
             rc.inv_den = (m == 0.5f && e > -100 && e < 100) ? 1.0f / (2.0f * cfg->bound) : 0.0f;
         }
-        {   // SN_RENDER_XCD=0 disables the XCD-aware tile order (A/B switch)
-            const char *xs = getenv("SN_RENDER_XCD");
-            rc.xcd_swizzle = !(xs && xs[0] == '0');
+        {   // tuning.linear_tile_order disables the XCD-aware tile order (A/B switch)
+            rc.xcd_swizzle = cfg->tuning.linear_tile_order == 0;
             // compaction: workgroups differ in cost by the number of live rays of their tile; a contiguous tile range per
             // XCD would leave the XCDs that own empty image bands idle (measured on the small-aabb scene: 4.4 instead of
             // 3.0 ms), so tiles go round-robin over the XCDs in dispatch order
@@ -3698,7 +3344,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 const int K = dense_prefix(gl_prop[k]);
                 const bool h16 = cfg->prop_grid[k].table_dtype != SN_F32;
                 // few rays in linear order (training batches): 8 lanes per ray instead of one (k_prop_stage_sp)
-                const bool sp = W == 0 && n <= prop_sp_max_rays() && pa.T <= SP_MAX_T;
+                const bool sp = W == 0 && n <= prop_sp_max_rays(cfg) && pa.T <= SP_MAX_T;
                 const uint32_t nblk_sp = Npad / 32u;            // every scratch column, like the one-lane-per-ray launch
 #define SN_LAUNCH_PROP(KK)                                                                                         \
                 do {                                                                                               \
@@ -3738,8 +3384,17 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         const bool per_sample_out = fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo || fa.w_out;
         fa.stop_cum = (cfg->early_stop_eps > 0.0f && cfg->early_stop_eps < 1.0f && !per_sample_out) ? -logf(cfg->early_stop_eps) : 0.0f;
         const bool f16 = cfg->grid.table_dtype == SN_F16;
+        // what runs as the last stage (sn_rm_last_launch_info): gather instructions of one wave-sample = dense levels as packed rows
+        // (fp32 tables: pair rows, 4 loads; fp16: quad rows, 2 loads) + 8 corners per hashed level
+        auto lv_gathers = [&](int kd) -> uint32_t { return (uint32_t)kd * (f16 ? 2u : 4u) + (uint32_t)(16 - kd) * 8u; };
+        auto note = [&](const char *name, uint32_t wgs, size_t lds, int dense, uint32_t gpw) {
+            snprintf(g_launch.final_kernel, sizeof(g_launch.final_kernel), "%s", name);
+            g_launch.workgroups = wgs; g_launch.lds_bytes = (uint32_t)lds; g_launch.dense_levels = (uint32_t)(dense < 0 ? 0 : dense);
+            g_launch.gathers_per_wave_sample = gpw; g_launch.launches += 1u;
+        };
         if (is_any) {     // sizes at run time
             ProfScope ps_final(st, PK_FINAL);
+            note("k_final_stage_any", nblk, (size_t)(2u * any_shape.rows + (any_shape.dg[any_shape.ng] - 1u)) * 256u * sizeof(float), 0, cfg->grid.L * 8u);
             const uint32_t geo = any_shape.dg[any_shape.ng] - 1u;
             fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * geo : nullptr;
             fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * (geo + 16u) : nullptr;
@@ -3778,7 +3433,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = (SN_FINAL_LV && !lv_ok) ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
         // few rays in linear order: lanes share rays (k_final_stage_sp); fewer samples per lane while CUs would idle
-        const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && !use_cmp && n <= final_sp_max_rays() &&
+        const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && !use_cmp && n <= final_sp_max_rays(cfg) &&
                               fa.T <= 64u * FSP_MAX_SPL;
         if (final_sp) {
             auto lpr_log2_of = [&](uint32_t sl) { const uint32_t need = div_up(fa.T, 1u << sl); uint32_t l2 = 0; while ((1u << l2) < need) ++l2; return l2; };
@@ -3796,9 +3451,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             if (Kmain == 5) { if (f16) SN_LAUNCH_FINAL_SP(__half, 5); else SN_LAUNCH_FINAL_SP(float, 5); }
             else { if (f16) SN_LAUNCH_FINAL_SP(__half, -1); else SN_LAUNCH_FINAL_SP(float, -1); }
 #undef SN_LAUNCH_FINAL_SP
+            note("k_final_stage_sp", blocks, lds_bytes, Kmain, Kmain == 5 ? lv_gathers(5) : 16u * 8u);
         } else if (use_cmp) {
             // per-ray termination + live-sample compaction (k_final_stage_cmp); f_image stays available
             const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
+            note("k_final_stage_cmp", nblk, lds_bytes, 5, lv_gathers(5));
             if (f16) {
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_cmp<__half, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL((k_final_stage_cmp<__half, 5>), dim3(nblk), dim3(256), lds_bytes, st, fa);
@@ -3806,10 +3463,12 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_cmp<float, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL((k_final_stage_cmp<float, 5>), dim3(nblk), dim3(256), lds_bytes, st, fa);
             }
-        } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !aux && !per_sample_out && rs_enabled()) {
+#ifdef SN_EXPERIMENTS
+        } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !aux && !per_sample_out && rs_enabled(cfg)) {
             // role-split waves (k_final_stage_rs): 768-thread workgroups over 32x16-pixel tiles (512 rays in linear order)
             const uint32_t nblk_rs = W ? ((W + 31u) >> 5) * ((rc.rows + 15u) >> 4) : div_up(n, (uint32_t)(RS_PROD * 64));
             const size_t lds_bytes = (size_t)RS_LDS_FLOATS * sizeof(float);
+            note("k_final_stage_rs", nblk_rs, lds_bytes, 5, lv_gathers(5));
             if (f16) {
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_rs<__half, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL((k_final_stage_rs<__half, 5>), dim3(nblk_rs), dim3(RS_THREADS), lds_bytes, st, fa);
@@ -3817,7 +3476,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_rs<float, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL((k_final_stage_rs<float, 5>), dim3(nblk_rs), dim3(RS_THREADS), lds_bytes, st, fa);
             }
-        } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !(fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo) && lt_enabled()) {
+#endif
+        } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !(fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo) && lt_enabled(cfg)) {
             // linear tail: layer 3 off the matrix cores (per-sample geometry features are not available in this form)
 #define SN_LAUNCH_FINAL_LT(TT_, AUX_)                                                                                          \
             do {                                                                                                             \
@@ -3830,8 +3490,13 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             // SLOWER than the texture path (800x800 [128]: 6.44 -> 6.58 ms, profiles/r03/ab_round3_experiments.txt): with fp16 tables the
             // kernel is not bound by the texture addressers, and the 8 ds_read_b32 + swizzled slab addressing cost more than 2 gathers save
             const uint64_t rows0 = (uint64_t)gl_main.res[0] * gl_main.res[0] * gl_main.res[0];
-            const char *l0e = getenv("SN_RENDER_L0");
-            const bool l0 = f16 && rows0 <= (uint64_t)L0_MAX_ROWS && (l0e && l0e[0] == '1');
+#ifdef SN_EXPERIMENTS
+            const bool l0 = f16 && rows0 <= (uint64_t)L0_MAX_ROWS && cfg->tuning.experiment == SN_EXP_LDS_LEVEL0;
+#else
+            const bool l0 = false;
+            (void)rows0;
+#endif
+#ifdef SN_EXPERIMENTS
 #define SN_LAUNCH_FINAL_LT_L0(AUX_)                                                                                            \
             do {                                                                                                             \
                 const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * 16 + L0_MAX_ROWS) * sizeof(float);              \
@@ -3839,9 +3504,12 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
                 hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, true>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
             } while (0)
+#endif
             FinalArgs fa7 = fa;
             const bool dens = Kv_main == 7 && !aux && !l0 && !final_sp &&
                               build_final_lv(gl_main, 7, pairs, cfg->grid.embeddings, 2u * (f16 ? 2u : 4u), fa7.lv);
+            if (!l0) note(dens ? "k_final_stage<lt,K=7>" : aux ? "k_final_stage<lt,K=5,aux>" : "k_final_stage<lt,K=5>", nblk,
+                          (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float), dens ? 7 : 5, lv_gathers(dens ? 7 : 5));
             if (dens) {     // levels 5 and 6 densified for this call (densify_levels)
                 const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
                 if (f16) {
@@ -3852,16 +3520,25 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                     hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), dim3(nblk), dim3(256), lds_bytes, st, fa7);
                 }
             }
-            else if (l0) { if (aux) SN_LAUNCH_FINAL_LT_L0(true); else SN_LAUNCH_FINAL_LT_L0(false); }
+#ifdef SN_EXPERIMENTS
+            else if (l0) { note("k_final_stage<lt,K=5,lds-level0>", nblk, (size_t)(PACK_FLOATS + 4 * 2 * 64 * 16 + L0_MAX_ROWS) * sizeof(float), 5, lv_gathers(5) - 2u);
+                           if (aux) SN_LAUNCH_FINAL_LT_L0(true); else SN_LAUNCH_FINAL_LT_L0(false); }
+#endif
             else if (aux) { if (f16) SN_LAUNCH_FINAL_LT(__half, true); else SN_LAUNCH_FINAL_LT(float, true); }
             else { if (f16) SN_LAUNCH_FINAL_LT(__half, false); else SN_LAUNCH_FINAL_LT(float, false); }
+#ifdef SN_EXPERIMENTS
 #undef SN_LAUNCH_FINAL_LT_L0
+#endif
 #undef SN_LAUNCH_FINAL_LT
         } else if (mlp_mode == MLP_F16X3) {
+            note(Kmain == 5 ? "k_final_stage<per-sample,K=5>" : "k_final_stage<per-sample,generic>", nblk, (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float),
+                 Kmain, Kmain == 5 ? lv_gathers(5) : (uint32_t)dense_prefix(gl_main) * 4u + (16u - (uint32_t)dense_prefix(gl_main)) * 8u);
             if (Kmain == 5) SN_LAUNCH_FINAL_AUX(MLP_F16X3, 5, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);     // 72 KiB; main grid: levels 0-4 dense
             else SN_LAUNCH_FINAL_AUX(MLP_F16X3, -1, PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE);
-        } else if (mlp_mode == MLP_F32) SN_LAUNCH_FINAL(MLP_F32, -1, PACK_FLOATS + 4 * 32 * 64);       // 64 KiB
-        else SN_LAUNCH_FINAL(MLP_VALU, -1, 2 * 64 * 256 + VIEW_W);                                      // 136 KiB
+        } else if (mlp_mode == MLP_F32) { note("k_final_stage<mfma32>", nblk, (size_t)(PACK_FLOATS + 4 * 32 * 64) * sizeof(float), -1, 16u * 8u);
+                                          SN_LAUNCH_FINAL(MLP_F32, -1, PACK_FLOATS + 4 * 32 * 64); }   // 64 KiB
+        else { note("k_final_stage<valu>", nblk, (size_t)(2 * 64 * 256 + VIEW_W) * sizeof(float), -1, 16u * 8u);
+               SN_LAUNCH_FINAL(MLP_VALU, -1, 2 * 64 * 256 + VIEW_W); }                                  // 136 KiB
 #undef SN_LAUNCH_FINAL_AUX
 #undef SN_LAUNCH_FINAL
 #undef SN_LAUNCH_FINAL_T

@@ -58,6 +58,25 @@ int build_grid_levels(GridLevels *g, const int32_t *offsets_host, uint32_t D, ui
                       float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp);
 uint32_t level_resolution(uint32_t level, float S, uint32_t H);
 
+// ---- debug build -DSN_POISON_LDS (`make poison`): every kernel fills the workgroup's whole LDS allocation (static + dynamic, the size is
+// read from the dispatch packet) with signalling NaNs before its first statement, so that a read-before-write -- invisible when the
+// previous workgroup happened to leave finite values behind, e.g. a stale row multiplied by a zero weight (the round-3 bug of
+// k_final_stage_any) -- turns into NaN in the result.  The fuzzers and the GPU tests are run under this build once per round.
+#ifdef SN_POISON_LDS
+__device__ __forceinline__ void poison_lds_all() {
+    typedef __attribute__((address_space(4))) const uint32_t cst_u32;
+    const uint32_t bytes = ((cst_u32 *)__builtin_amdgcn_dispatch_ptr())[7];      // hsa_kernel_dispatch_packet_t::group_segment_size (byte 28)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32 *base = (lds_u32 *)0;
+    const uint32_t nthreads = blockDim.x * blockDim.y * blockDim.z, tid = (threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x;
+    for (uint32_t i = tid; i < bytes / 4u; i += nthreads) base[i] = 0x7fa00000u;
+    __syncthreads();
+}
+#define SN_POISON_ALL() ::sn::poison_lds_all()
+#else
+#define SN_POISON_ALL() do { } while (0)
+#endif
+
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float expf_det(float x) {
     // branch-free: the polynomial runs on the clamped argument; scaling is ONE v_ldexp_f32, which also produces the

@@ -15,7 +15,6 @@ Two execution paths:
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, Optional
 
 import torch
@@ -181,6 +180,8 @@ class NeRFRenderer(nn.Module):
     # A subclass whose forward() is NOT "grid -> grid_mlp -> [trunc_exp(sigma) | geo_feat], colour = view_mlp(cat(geo_feat, SH(d)))"
     # (network.py:146-186) sets this to False: the fused kernels restate that structure, they do not call forward().
     standard_field = True
+    fused_mask_head = True        # inference: sn_rm_mask_head (one kernel); False = the three-kernel route (A/B, tests)
+    fused_proposals = True        # training calls whose proposal networks get no gradient run those stages in the fused kernels
     fused_min_rays = 16384        # fields of other sizes than the reference network's: batches below this take the operator chain (see run())
 
     def _fused_shape(self) -> bool:
@@ -214,7 +215,8 @@ class NeRFRenderer(nn.Module):
             if (g.num_levels == 16 and g.gridtype_id == 0 and not g.align_corners and g.interp_id == 0
                     and dg == [32, 64, 64, 16] and dv == [31, 32, 32, 3]):
                 return "main"
-            relu = all(type(m).__name__ == "MLP" for m in (self.grid_mlp, self.view_mlp))      # network.py:9-29: ReLU between the layers
+            from .network import MLP                                                            # network.py:9-29: ReLU between the layers
+            relu = all(type(m) is MLP for m in (self.grid_mlp, self.view_mlp))                  # (a subclass may change forward(): exact type)
             if (dg is not None and dv is not None and relu and g.num_levels * 2 <= 64 and len(dg) <= 5 and len(dv) <= 5
                     and max(dg) <= 64 and max(dv) <= 64 and dg[0] == g.num_levels * 2 and 2 <= dg[-1] <= 32
                     and dv[0] == dg[-1] - 1 + 16 and dv[-1] == 3 and getattr(self, "geom_feat_dim", dg[-1] - 1) == dg[-1] - 1):
@@ -288,7 +290,7 @@ class NeRFRenderer(nn.Module):
                 mlp = self.mask_mlp[0]
                 if (not torch.is_grad_enabled() and weights.is_cuda and len(self.mask_mlp) == 1
                         and rm.mask_head_fusable(self.m_grid, mlp, weights.shape[1], geo_feat.shape[-1])
-                        and os.environ.get("SN_MASK_HEAD", "fused") != "unfused"):
+                        and self.fused_mask_head):
                     # inference: grid gather -> matrix-core MLP -> compositing in one kernel, nothing per-sample written
                     results["instance_mask_logits"] = rm.mask_head(weights, xyzs, geo_feat, self.m_grid, mlp, self.bound)
                     return
@@ -353,7 +355,7 @@ class NeRFRenderer(nn.Module):
         wants_prop_loss = self.training and not opt.with_mask and not opt.with_sam and opt.lambda_proposal > 0 and update_proposal
         first_stage = 0
         if (len(steps) > 1 and not prop_needs_grad and not wants_prop_loss and rays_o.is_cuda and self._fused_shape()
-                and os.environ.get("SN_FUSED_PROPOSALS", "1") != "0"):
+                and self.fused_proposals):
             b0 = torch.linspace(0, 1, steps[0] + 1, device=device)
             u_tabs = None
             if perturb:

@@ -416,6 +416,7 @@ class _small_linear(Function):
 
 
 WIDE_MLP_BACKWARD_MIN_ROWS = 16384
+WIDE_MLP_BACKWARD_FUSED = True      # False: the wide training MLP differentiates through torch (A/B, tests)
 _wide_bwd_ws: dict = {}
 
 
@@ -499,7 +500,7 @@ def wide_mlp_fusable(x: torch.Tensor, layers, skip_layers) -> bool:
             and all(l.weight.shape[0] == 256 for l in layers[:-1]) and layers[-1].weight.shape[0] <= 256
             and all(l.weight.shape[1] == 256 for l in layers[1:]) and layers[0].weight.shape[1] <= 256   # the backward plans the transposed MLP: its last width is dim_in
             and any(l.weight.requires_grad for l in layers)
-            and os.environ.get("SN_WIDE_MLP_BACKWARD", "fused") != "torch")
+            and WIDE_MLP_BACKWARD_FUSED)
 
 
 def wide_mlp_train(x: torch.Tensor, layers, leaky: bool) -> torch.Tensor:

@@ -52,7 +52,7 @@ class Adam(torch.optim.Optimizer):
                 lr = group["lr"]
                 _lib.check(lib.sn_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                                             float(lr), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                            int(st["step"].item()), int(bool(group["maximize"])), 2 if group.get("lazy", False) else 0, _lib.stream()), "sn_adam_step")
+                                            int(st["step"].item()), int(bool(group["maximize"])), _lib.ADAM_LAZY if group.get("lazy", False) else 0, _lib.stream()), "sn_adam_step")
                 # the kernel wrote through the raw pointer: tell autograd / version-keyed caches (RenderPlan.check_range's fp16
                 # range guard, memoised host copies) that the tensor changed, as an in-place torch op would have
                 torch.autograd.graph.increment_version(p)

@@ -28,6 +28,51 @@ from torch.autograd import Function
 from .. import _lib
 
 
+class Tuning:
+    """Kernel selection of the fused render (sn_render_tuning in include/sanerf_hip.h): plain attributes, copied into the call's
+    config right before every launch.  `raymarching.tuning` is the process default; `RenderPlan(..., tuning=Tuning(...))` /
+    `render_rays(..., tuning=...)` override it per plan / per call (two threads or two plans may differ -- rounds 1-3 read
+    environment variables inside the library instead).  Every field 0 / False = the shipped default; none changes WHAT is
+    computed beyond fp32 round-off.
+        mlp_mode           _lib.MLP_AUTO | MLP_F16X3 (forces split-fp16 past the range guard) | MLP_MFMA32 (exact fp32) | MLP_VALU
+        per_sample_form    the last stage evaluates the third MLP layer per sample everywhere (bit-identical to the compacting and
+                           several-lanes-per-ray kernels; the default "linear tail" differs by fp32 round-off)
+        densify            0 automatic, 1 never, 2 whenever the kernel exists (levels 5-6 of the main grid re-laid out per call)
+        linear_tile_order  no XCD-aware workgroup -> tile remap
+        prop_sp_max_rays / final_sp_max_rays   ray-count thresholds of the several-lanes-per-ray kernels (0 default, < 0 never)
+        feat_levels        levels per pass of the feature stage (0 default)
+        experiment         _lib.EXP_*: measured-and-rejected variants, experiments builds only (SN_LIB=.../libsanerf_hip_exp.so)"""
+    FIELDS = ("mlp_mode", "per_sample_form", "densify", "linear_tile_order", "prop_sp_max_rays", "final_sp_max_rays", "feat_levels", "experiment")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, 0)
+        for k, v in kw.items():
+            if k not in self.FIELDS:
+                raise TypeError(f"Tuning: unknown field {k!r} (fields: {', '.join(self.FIELDS)})")
+            setattr(self, k, int(v))
+
+    def write(self, ct) -> None:
+        for f in self.FIELDS:
+            setattr(ct, f, int(getattr(self, f)))
+
+    def __repr__(self):
+        return "Tuning(" + ", ".join(f"{f}={getattr(self, f)}" for f in self.FIELDS if getattr(self, f)) + ")"
+
+
+tuning = Tuning()          # process default; tests and A/B tools set attributes on it (monkeypatch.setattr(rm.tuning, "per_sample_form", 1))
+check_range_default = False   # mlp_forward(check_range=None): read the overflow flag after every call (one device sync each)
+
+
+def last_launch_info() -> dict:
+    """What the last render_rays call of this thread launched as its last stage (kernel variant, workgroups, LDS bytes, gather
+    instructions per wave-sample): sn_rm_last_launch_info."""
+    info = _lib.LaunchInfo()
+    _lib.check(_lib.lib().sn_rm_last_launch_info(C.byref(info)), "last_launch_info")
+    return dict(final_kernel=info.final_kernel.decode(), workgroups=int(info.workgroups), lds_bytes=int(info.lds_bytes),
+                dense_levels=int(info.dense_levels), gathers_per_wave_sample=int(info.gathers_per_wave_sample), launches=int(info.launches))
+
+
 def _flat3(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(-1, 3).contiguous().float()
 
@@ -371,7 +416,7 @@ def mlp_forward(x: torch.Tensor, mlp, layer_norm: Optional[torch.nn.LayerNorm] =
     _lib.check(L.sn_mlp_wide_forward(C.byref(desc), _lib.dev(lw, "ln.weight"), _lib.dev(lb, "ln.bias"), eps,
                                      _lib.dev(x, "x"), x.shape[0], _lib.dev(out, "out"), ws.data_ptr(), ws.numel(),
                                      _lib.stream()), "sn_mlp_wide_forward")
-    if check_range if check_range is not None else os.environ.get("SN_CHECK_RANGE") == "1":
+    if check_range if check_range is not None else check_range_default:
         if mlp_wide_overflow():
             raise RuntimeError("mlp_forward: an activation left the fp16 range of the split-fp16 matrix-core arithmetic "
                                "(|v| >= 65504): outputs are not finite; run this head through the torch module instead")
@@ -440,8 +485,9 @@ class RenderPlan:
     the module keeps its fp32 parameters); arithmetic stays fp32 either way."""
 
     def __init__(self, model, num_steps: Sequence[int], table_dtype=torch.float32, feat_encoder=None,
-                 early_stop_eps: float = 0.0, compact_live: bool = False):
+                 early_stop_eps: float = 0.0, compact_live: bool = False, tuning: Optional["Tuning"] = None):
         self.keep: list = []
+        self.tuning = tuning            # None: the module default `raymarching.tuning` at call time
         cfg = _lib.RenderCfg()
         S = len(num_steps)
         if not 1 <= S <= _lib.MAX_STAGES:
@@ -539,6 +585,7 @@ class RenderPlan:
             copy.copy_(src.detach())
 
     def workspace(self, N: int, tile_w: int, device) -> torch.Tensor:
+        (self.tuning or tuning).write(self.cfg.tuning)
         need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(self.cfg), N, tile_w))
         if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(device):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -548,7 +595,7 @@ class RenderPlan:
 def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: float = 1.0, tile_w: int = 0,
                 want: Sequence[str] = (), u_tables: Optional[Dict[int, torch.Tensor]] = None,
                 bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None,
-                skip_final: bool = False):
+                skip_final: bool = False, tuning: Optional["Tuning"] = None):
     """Fused render of N rays.  Returns dict(image [N,3], depth [N], weights_sum [N]) plus the
     per-stage tensors named in `want`: 'bins', 'weights', 'sigmas', 'inds' (all stages),
     'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'; a plan built with `feat_encoder` also
@@ -621,7 +668,13 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         io.f_image = buf("f_image", (N, plan.ncol)).data_ptr()
     if plan.cfg.with_feat and not skip_final:
         io.f_feat = buf("f_feat", (N, plan.feat_dim)).data_ptr()
+    eff = tuning or plan.tuning or globals()["tuning"]           # per call > per plan > process default
+    eff.write(plan.cfg.tuning)
+    need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(plan.cfg), N, int(tile_w)))
     ws = plan.workspace(N, int(tile_w), device)
+    if ws.numel() < need:                                          # (a per-call tuning that needs more than the plan's own)
+        plan._ws = ws = torch.empty(need, dtype=torch.uint8, device=device)
+    eff.write(plan.cfg.tuning)
     io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.cfg.bg_color = float(bg_color)
     _lib.check(_lib.lib().sn_rm_render_rays(C.byref(plan.cfg), C.byref(io), _lib.stream()), "render_rays")

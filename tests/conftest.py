@@ -34,10 +34,20 @@ def gpu():
 
 
 @pytest.fixture
+def experiments_build(gpu):
+    """Tests of the measured-and-rejected kernel variants need a library built with -DSN_EXPERIMENTS (make -C sanerf-hq_amd/csrc exp,
+    SN_LIB=sanerf-hq_amd/libsanerf_hip_exp.so): the product library does not carry those kernels."""
+    from sanerf_hq_amd import _lib
+    if not (_lib.lib().sn_build_flags() & _lib.BUILD_EXPERIMENTS):
+        pytest.skip("needs the experiments build of the library (SN_LIB=.../libsanerf_hip_exp.so)")
+
+
+@pytest.fixture
 def per_sample_form(monkeypatch):
     """The default final stage applies the third MLP layer's geometry rows once per ray to the weight-accumulated hidden vector
     (the "linear tail", render.hip / DESIGN.md section 5) wherever no per-sample tensor leaves the kernel.  The other final-stage
     kernels (several lanes per ray, live-sample compaction, role-split waves) and every call that exports per-sample tensors keep
     the per-sample form; their BIT identity with the default kernel is a statement about that form, so tests that assert it pin
     the default kernel to it.  (test_linear_tail_form_* bounds the difference between the two forms: fp32 round-off.)"""
-    monkeypatch.setenv("SN_RENDER_LT", "0")
+    from sanerf_hq_amd import raymarching as rm
+    monkeypatch.setattr(rm.tuning, "per_sample_form", 1)

@@ -30,10 +30,11 @@ def _render(model, ro, rd, want=("bins", "weights", "sigmas", "inds", "xyzs_last
 
 
 @pytest.mark.parametrize("mlp", ["f16x3", "mfma32", "valu"])
-def test_sref_vs_oracle_and_reference(gpu, orc, mlp):
+def test_sref_vs_oracle_and_reference(gpu, orc, mlp, monkeypatch):
     """Reference schedule [128, 64, 32] with both proposal grids, 256 rays of the sref fixture."""
-    os.environ["SN_RENDER_MLP"] = mlp
-    try:
+    from sanerf_hq_amd import _lib, raymarching as rm
+    monkeypatch.setattr(rm.tuning, "mlp_mode", {"f16x3": _lib.MLP_F16X3, "mfma32": _lib.MLP_MFMA32, "valu": _lib.MLP_VALU}[mlp])
+    if True:
         g = golden("render_sref")
         params = params_from_spec(spec_of(g))
         model = product_model(params, [128, 64, 32], False, gpu)
@@ -41,8 +42,6 @@ def test_sref_vs_oracle_and_reference(gpu, orc, mlp):
         got = _render(model, T(g["rays_o"], gpu), T(g["rays_d"], gpu), u_tables=u_tables)
         cfg = oracle_cfg(orc, params, [128, 64, 32])
         want = orc.render(cfg, g["rays_o"], g["rays_d"], debug=True, u_tables={k: g[f"u{k}"] for k in (1, 2)})
-    finally:
-        os.environ.pop("SN_RENDER_MLP", None)
     # --- vs oracle: everything that decides the sample indices is bit-identical ---
     for k in (0, 1):
         assert np.array_equal(got[f"sigmas{k}"], want[f"sigmas{k}"]), f"proposal sigma stage {k}"
@@ -81,30 +80,25 @@ def test_flat128_vs_oracle_and_reference(gpu, orc):
     np.testing.assert_allclose(got["depth"], g["depth"], rtol=1e-5, atol=1e-4)
 
 
-def test_mlp_paths_agree(gpu, orc):
+def test_mlp_paths_agree(gpu, orc, monkeypatch):
     """The three implementations of the 32-64-64-16 MLP (fp16 hi/lo split MFMA = default, exact fp32 MFMA,
     vector ALU) give the same picture; the proposal stages (which decide the indices) are shared."""
     params = synthetic_params([128, 64, 32], seed=3)
     model = product_model(params, [128, 64, 32], False, gpu)
     _, _, ro, rd = camera_rays(orc, 48, 48)
     outs = {}
-    for mode in ("f16x3", "mfma32", "valu"):
-        os.environ["SN_RENDER_MLP"] = mode
-        try:
-            outs[mode] = _render(model, T(ro, gpu), T(rd, gpu), want=("inds", "weights", "sigmas"))
-        finally:
-            os.environ.pop("SN_RENDER_MLP", None)
+    from sanerf_hq_amd import _lib, raymarching as rm
+    for mode, val in (("f16x3", _lib.MLP_F16X3), ("mfma32", _lib.MLP_MFMA32), ("valu", _lib.MLP_VALU)):
+        monkeypatch.setattr(rm.tuning, "mlp_mode", val)
+        outs[mode] = _render(model, T(ro, gpu), T(rd, gpu), want=("inds", "weights", "sigmas"))
     for mode in ("mfma32", "valu"):
         assert np.array_equal(outs["f16x3"]["inds2"], outs[mode]["inds2"])
         np.testing.assert_allclose(outs["f16x3"]["sigmas2"], outs[mode]["sigmas2"], rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(outs["f16x3"]["image"], outs[mode]["image"], rtol=0, atol=5e-6)
         np.testing.assert_allclose(outs["f16x3"]["weights2"], outs[mode]["weights2"], rtol=0, atol=5e-6)
-    os.environ["SN_RENDER_MLP"] = "bogus"
-    try:
-        with pytest.raises(RuntimeError, match="unknown SN_RENDER_MLP"):
-            _render(model, T(ro, gpu), T(rd, gpu), want=())
-    finally:
-        os.environ.pop("SN_RENDER_MLP", None)
+    monkeypatch.setattr(rm.tuning, "mlp_mode", 17)
+    with pytest.raises(RuntimeError, match="unknown tuning.mlp_mode"):
+        _render(model, T(ro, gpu), T(rd, gpu), want=())
 
 
 def test_model_render_api_and_staging(gpu, orc, per_sample_form):
@@ -165,14 +159,14 @@ def test_heads_vs_reference_fixture(gpu, orc):
 
 def test_mask_head_fused_and_unfused_routes_agree(gpu, orc, monkeypatch):
     """NeRFRenderer._heads at inference: the one-kernel mask head (default) vs the three-kernel route it replaced
-    (SN_MASK_HEAD=unfused), both against the reference fixture."""
+    (NeRFRenderer.fused_mask_head = False), both against the reference fixture."""
     g = golden("render_heads")
     params = params_from_spec(spec_of(g))
     model = product_model(params, [128, 64, 32], True, gpu)
     n_side = int(g["HW"][2])
     outs = {}
     for route in ("fused", "unfused"):
-        monkeypatch.setenv("SN_MASK_HEAD", route)
+        monkeypatch.setattr(model, "fused_mask_head", route == "fused")
         with torch.no_grad():
             outs[route] = model.render(T(g["rays_o"], gpu), T(g["rays_d"], gpu), staged=False, perturb=False, return_mask=1,
                                        H=n_side, W=n_side)["instance_mask_logits"].clone()
@@ -263,7 +257,7 @@ def test_training_step_with_frozen_proposals_uses_the_fused_proposal_stages(gpu,
     N = ro_t.shape[0]
     res = {}
     for route in ("1", "0"):
-        monkeypatch.setenv("SN_FUSED_PROPOSALS", route)
+        monkeypatch.setattr(model, "fused_proposals", route == "1")
         for p in model.parameters():
             p.grad = None
         out = model.render(ro_t, rd_t, staged=False, perturb=False, update_proposal=False)
@@ -278,7 +272,7 @@ def test_training_step_with_frozen_proposals_uses_the_fused_proposal_stages(gpu,
     # the sparse table gradient gets the wider bound)
     for a_, b_, tol in zip(res["1"][1:], res["0"][1:], (1e-2, 1e-3, 1e-3)):
         assert float((a_ - b_).double().norm() / b_.double().norm()) <= tol
-    monkeypatch.setenv("SN_FUSED_PROPOSALS", "1")
+    monkeypatch.setattr(model, "fused_proposals", True)
     pert = model.render(ro_t, rd_t, staged=False, perturb=True, update_proposal=False)
     assert torch.isfinite(pert["image"]).all() and float((pert["image"] - res["1"][0]).abs().max()) > 0
     # per-ray tables: the fused stages against the operator chain on the SAME perturbed inputs
@@ -968,13 +962,13 @@ def test_sample_parallel_stages_are_bit_identical(gpu, orc, steps, f16, monkeypa
     want = ("bins", "weights", "sigmas", "inds", "xyzs_last", "geo_feat_last", "f_image")
 
     def run(limit):
-        monkeypatch.setenv("SN_PROP_SP_MAX", limit)
-        monkeypatch.setenv("SN_FINAL_SP_MAX", limit)
+        monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", int(limit))
+        monkeypatch.setattr(rm.tuning, "final_sp_max_rays", int(limit))
         res = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, want=want, out={})
         plain = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, out={})       # no per-sample outputs requested
         assert torch.equal(res["image"], plain["image"]) and torch.equal(res["depth"], plain["depth"])
         return {k: v.clone() for k, v in res.items()}
-    lane, sp = run("0"), run("1000000")
+    lane, sp = run("-1"), run("1000000")
     assert set(lane) == set(sp)
     for k in lane:
         assert torch.equal(lane[k], sp[k]), k
@@ -993,9 +987,9 @@ def test_sample_parallel_final_stage_feeds_the_feature_stage(gpu, orc, monkeypat
     _, _, ro, rd = camera_rays(orc, 19, 27)
     plan = rm.RenderPlan(model, steps, feat_encoder=model.s_grid)
     outs = []
-    for limit in ("0", "1000000"):
-        monkeypatch.setenv("SN_PROP_SP_MAX", limit)
-        monkeypatch.setenv("SN_FINAL_SP_MAX", limit)
+    for limit in ("-1", "1000000"):
+        monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", int(limit))
+        monkeypatch.setattr(rm.tuning, "final_sp_max_rays", int(limit))
         res = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, out={})
         outs.append({k: v.clone() for k, v in res.items()})
     assert float(outs[0]["f_feat"].abs().max()) > 0
@@ -1051,10 +1045,9 @@ def test_split_fp16_range_guard(gpu, orc, monkeypatch):
     want = orc.render(oracle_cfg(orc, params, steps), ro, rd)
     assert torch.isfinite(out["image"]).all()
     np.testing.assert_allclose(out["image"].cpu().numpy(), want["image"], rtol=0, atol=2e-5)
-    monkeypatch.setenv("SN_RENDER_MLP", "f16x3")                       # override the guard: fp16 halves overflow
-    bad = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32, out={})
+    from sanerf_hq_amd import _lib
+    bad = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32, out={}, tuning=rm.Tuning(mlp_mode=_lib.MLP_F16X3))   # override the guard: fp16 halves overflow
     assert not torch.isfinite(bad["image"]).all() or float((bad["image"] - out["image"]).abs().max()) > 1e-2
-    monkeypatch.delenv("SN_RENDER_MLP")
     # an ordinary field keeps the fast path
     ok_model = product_model(synthetic_params(steps, seed=21), steps, False, gpu)
     assert rm.RenderPlan(ok_model, steps).cfg.mlp_exact_fp32 == 0

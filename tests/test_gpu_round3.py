@@ -44,32 +44,31 @@ def test_full_size_both_table_precisions_and_schedules(gpu, orc, steps, f16):
 
 
 @pytest.mark.parametrize("steps", [[128], [128, 64, 32], [7], [33, 17, 9]])
-def test_role_split_final_stage_is_bit_identical(gpu, orc, steps, monkeypatch, per_sample_form):
-    """k_final_stage_rs (SN_RENDER_RS=1: producer waves gather and blend, consumer waves run the matrix-core MLP and composite,
+def test_role_split_final_stage_is_bit_identical(gpu, orc, steps, monkeypatch, per_sample_form, experiments_build):
+    """k_final_stage_rs (experiments builds, tuning.experiment = EXP_ROLE_SPLIT: producer waves gather and blend, consumer waves run the matrix-core MLP and composite,
     hand-over through LDS rings) performs the arithmetic of k_final_stage in its order: every output must be equal bit for bit,
     for ragged image shapes, tiled and linear lane mapping and both table precisions."""
     from sanerf_hq_amd import raymarching as rm, synth
     params = synthetic_params(steps, seed=23)
     model = product_model(params, steps, False, gpu)
     pose = synth.orbit_pose(1.0, 20.0, 30.0)
+    from sanerf_hq_amd import _lib
+    rs = rm.Tuning(per_sample_form=1, experiment=_lib.EXP_ROLE_SPLIT)
     for tdt in (torch.float32, torch.float16):
         plan = rm.RenderPlan(model, steps, tdt)
         for (H, W) in ((64, 64), (48, 80), (200, 104), (16, 32), (40, 24)):
             intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
             ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
             for tile in (W, 0):
-                monkeypatch.setenv("SN_RENDER_RS", "0")
                 a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",)).items()}
-                monkeypatch.setenv("SN_RENDER_RS", "1")
-                b = rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",))
+                b = rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",), tuning=rs)
                 for k in ("image", "depth", "weights_sum", "f_image"):
                     assert torch.equal(a[k], b[k]), (steps, tdt, H, W, tile, k, float((a[k] - b[k]).abs().max()))
     # against the oracle directly as well (one shape)
-    monkeypatch.setenv("SN_RENDER_RS", "1")
-    monkeypatch.setenv("SN_RENDER_LT", "0")
     _, _, ro, rd = camera_rays(orc, 32, 32)
-    plan = rm.RenderPlan(model, steps)
+    plan = rm.RenderPlan(model, steps, tuning=rs)
     got = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=32)
+    assert rm.last_launch_info()["final_kernel"] == "k_final_stage_rs"
     want = orc.render(oracle_cfg(orc, params, steps), ro, rd)
     np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
 
@@ -234,7 +233,7 @@ def test_rccl_leg_on_one_gpu():
 def test_linear_tail_form_vs_per_sample_form_and_oracle(gpu, orc, steps, monkeypatch):
     """The default final stage (no per-sample outputs) takes the third layer off the matrix cores: density row per sample as an
     fp32 dot product, geometry rows once per ray on sum_j w_j relu(h2_j).  A re-association (like SH(d) * sum_j w_j): it must stay
-    in the fp32 round-off class -- against the per-sample form (SN_RENDER_LT=0) and against the oracle -- for ragged shapes, both
+    in the fp32 round-off class -- against the per-sample form (Tuning.per_sample_form) and against the oracle -- for ragged shapes, both
     lane mappings and both table precisions, with and without the feature stage."""
     from sanerf_hq_amd import raymarching as rm, synth
     params = synthetic_params(steps, heads=True, seed=29)
@@ -246,10 +245,10 @@ def test_linear_tail_form_vs_per_sample_form_and_oracle(gpu, orc, steps, monkeyp
             for (H, W) in ((64, 64), (40, 24)):
                 intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
                 ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
-                monkeypatch.setenv("SN_RENDER_LT", "0")
-                a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={}).items()}
-                monkeypatch.setenv("SN_RENDER_LT", "1")
+                a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={}, tuning=rm.Tuning(per_sample_form=1)).items()}
+                assert "per-sample" in rm.last_launch_info()["final_kernel"]
                 b = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
+                assert "<lt" in rm.last_launch_info()["final_kernel"]
                 assert float((a["image"] - b["image"]).abs().max()) <= 4e-6
                 assert float((a["weights_sum"] - b["weights_sum"]).abs().max()) <= 1e-6
                 np.testing.assert_allclose(b["depth"].cpu().numpy(), a["depth"].cpu().numpy(), rtol=2e-6, atol=2e-6)
@@ -269,8 +268,8 @@ def test_linear_tail_form_vs_reference_fixtures(gpu, orc, monkeypatch):
     RGB within the north-star tolerance 1e-4, depth / weights_sum within 1e-4."""
     from helpers import golden, params_from_spec, spec_of
     from sanerf_hq_amd import raymarching as rm
-    monkeypatch.setenv("SN_FINAL_SP_MAX", "0")
-    monkeypatch.setenv("SN_PROP_SP_MAX", "0")
+    monkeypatch.setattr(rm.tuning, "final_sp_max_rays", -1)
+    monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", -1)
     for name, steps in (("render_sref", [128, 64, 32]), ("render_flat128", [128])):
         g = golden(name)
         model = product_model(params_from_spec(spec_of(g)), steps, False, gpu)
@@ -319,8 +318,8 @@ def test_lazy_adam_updates_touched_elements_only(gpu):
         bad.step()
 
 
-def test_lds_resident_level0_is_bit_identical(gpu, orc, monkeypatch):
-    """SN_RENDER_L0=1 (opt-in; north_star "LDS staging of per-tile grid voxels"): with fp16 tables the coarsest level of the main
+def test_lds_resident_level0_is_bit_identical(gpu, orc, monkeypatch, experiments_build):
+    """tuning.experiment = EXP_LDS_LEVEL0 (experiments builds; north_star "LDS staging of per-tile grid voxels"): with fp16 tables the coarsest level of the main
     grid (16^3 vertices, 16 KiB) is staged in LDS by every workgroup and read with ds_read_b32 instead of gathers; same arithmetic
     as the texture-path form, so every output is equal bit for bit (feature slabs move to their unpadded XOR-swizzled layout)."""
     from sanerf_hq_amd import raymarching as rm, synth
@@ -333,23 +332,22 @@ def test_lds_resident_level0_is_bit_identical(gpu, orc, monkeypatch):
             for (H, W) in ((64, 64), (48, 80), (40, 24)):
                 intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
                 ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
-                monkeypatch.setenv("SN_RENDER_L0", "0")
                 a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={}).items()}
-                monkeypatch.setenv("SN_RENDER_L0", "1")
-                b = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
+                b = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={}, tuning=rm.Tuning(experiment=2))
+                assert "lds-level0" in rm.last_launch_info()["final_kernel"]
                 for k in a:
                     assert torch.equal(a[k], b[k]), (steps, feat is not None, H, W, k)
 
 
 def test_densified_levels_are_bit_identical(gpu, orc, monkeypatch):
-    """SN_RENDER_DENSIFY (automatic for large fp16-table renders): the first two hashed levels of the main grid (102^3 and 148^3
+    """Tuning.densify (automatic for large fp16-table renders): the first two hashed levels of the main grid (102^3 and 148^3
     vertices) are re-laid out per call as 16-byte pair / quad rows -- fetched through the hash once per vertex by the pack kernel --
     and the final stage reads them like dense levels (4 / 2 coherent gathers instead of 8 scattered ones).  Same values, same
     arithmetic: every output equals the hashed-lookup form bit for bit, both table precisions, tiled and linear lane mapping."""
     from sanerf_hq_amd import raymarching as rm, synth
     pose = synth.orbit_pose(1.0, 20.0, 30.0)
-    monkeypatch.setenv("SN_FINAL_SP_MAX", "0")             # small linear batches would take the several-lanes-per-ray kernels
-    monkeypatch.setenv("SN_PROP_SP_MAX", "0")
+    monkeypatch.setattr(rm.tuning, "final_sp_max_rays", -1)             # small linear batches would take the several-lanes-per-ray kernels
+    monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", -1)
     for steps in ([128], [128, 64, 32], [7]):
         params = synthetic_params(steps, seed=37)
         model = product_model(params, steps, False, gpu)
@@ -359,10 +357,12 @@ def test_densified_levels_are_bit_identical(gpu, orc, monkeypatch):
                 intr = synth.pinhole_intrinsics(H, W)[:2] + (W / 2.0, H / 2.0)
                 ro, rd = rm.generate_rays(pose, intr, H, W, device=gpu)
                 for tile in (W, 0):
-                    monkeypatch.setenv("SN_RENDER_DENSIFY", "0")
+                    monkeypatch.setattr(rm.tuning, "densify", 1)
                     a = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",), out={}).items()}
-                    monkeypatch.setenv("SN_RENDER_DENSIFY", "2")
+                    assert rm.last_launch_info()["dense_levels"] == 5
+                    monkeypatch.setattr(rm.tuning, "densify", 2)
                     b = rm.render_rays(plan, ro, rd, tile_w=tile, want=("f_image",), out={})
+                    assert rm.last_launch_info()["dense_levels"] == 7 and rm.last_launch_info()["gathers_per_wave_sample"] == (86 if tdt == torch.float16 else 100)
                     for k in a:
                         assert torch.equal(a[k], b[k]), (steps, tdt, H, W, tile, k)
     # and against the oracle, with the switch forced on
@@ -405,7 +405,7 @@ def test_bench_line_schema():
     (700, 256, 4, [1, 2], True, False, 259),  # input too wide for LDS (read per k-step), two skip layers
     (17, 7, 1, [], True, False, 5),           # a single layer
 ])
-def test_wide_mlp_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, din, dout, nlayers, skip, bias, ln, N):
+def test_wide_mlp_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, din, dout, nlayers, skip, bias, ln, N, experiments_build):
     """k_mlp_wide_j (operands made between the MFMAs of the previous k-step, layers handed over through `prev`) computes every
     output with the same products in the same order as k_mlp_wide: the two kernels must agree bit for bit in every input mode."""
     from sanerf_hq_amd import raymarching as rm
@@ -414,9 +414,12 @@ def test_wide_mlp_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, din, do
     mlp = SkipConnMLP(din, dout, 256, nlayers, skip_layers=skip, bias=bias).to(gpu)
     norm = torch.nn.LayerNorm(dout).to(gpu) if ln else None
     x = torch.randn(N, din, device=gpu)
-    monkeypatch.setenv("SN_WIDE_JIT", "0")
-    a = rm.mlp_forward(x, mlp, norm)
-    monkeypatch.setenv("SN_WIDE_JIT", "1")
+    from sanerf_hq_amd import _lib
+    try:
+        _lib.check(_lib.lib().sn_debug_set(b"wide_jit", 0), "debug_set")
+        a = rm.mlp_forward(x, mlp, norm)
+    finally:
+        _lib.check(_lib.lib().sn_debug_set(b"wide_jit", 1), "debug_set")
     b = rm.mlp_forward(x, mlp, norm)
     assert torch.isfinite(a).all() and torch.equal(a, b)
     with torch.no_grad():
@@ -425,7 +428,7 @@ def test_wide_mlp_just_in_time_kernel_is_bit_identical(gpu, monkeypatch, din, do
 
 
 @pytest.mark.parametrize("N,T_,n_inst,L", [(300, 32, 2, 16), (37, 128, 3, 16), (64, 16, 32, 16), (100, 8, 2, 6)])
-def test_fused_mask_head_just_in_time_kernel_agrees(gpu, monkeypatch, N, T_, n_inst, L):
+def test_fused_mask_head_just_in_time_kernel_agrees(gpu, monkeypatch, N, T_, n_inst, L, experiments_build):
     """The fused mask head in k_mlp_wide_j<3>: lanes n and n + 32 share the corner rows of sample n (each fetches one 16-byte half of the
     rows of both levels of a k-step: half the rows per gather instruction), which permutes the first layer's input columns inside a
     k-step -- same products, another summation order within 16 terms: round-off agreement with k_mlp_wide<3>, not bit identity."""
@@ -441,9 +444,12 @@ def test_fused_mask_head_just_in_time_kernel_agrees(gpu, monkeypatch, N, T_, n_i
     xyz = torch.rand(N, T_, 3, device=gpu) * 2.2 - 1.1        # some samples outside the grid's box
     extra = torch.randn(N, T_, E, device=gpu)
     w = torch.rand(N, T_, device=gpu)
-    monkeypatch.setenv("SN_WIDE_JIT", "0")
-    a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
-    monkeypatch.setenv("SN_WIDE_JIT", "1")
+    from sanerf_hq_amd import _lib
+    try:
+        _lib.check(_lib.lib().sn_debug_set(b"wide_jit", 0), "debug_set")
+        a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
+    finally:
+        _lib.check(_lib.lib().sn_debug_set(b"wide_jit", 1), "debug_set")
     b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
     assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
 

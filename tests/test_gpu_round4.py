@@ -35,8 +35,8 @@ def test_wave_tile_workgroups_any_band_shape(gpu, orc, H, W, steps, f16, monkeyp
     linear = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, want=("inds", "weights"), out={})
     for k in tiled:
         assert torch.equal(tiled[k], linear[k]), k
-    monkeypatch.setenv("SN_FINAL_SP_MAX", "0")       # (small linear-order batches would take the several-lanes-per-ray kernels: per-sample form)
-    monkeypatch.setenv("SN_PROP_SP_MAX", "0")
+    monkeypatch.setattr(rm.tuning, "final_sp_max_rays", -1)       # (small linear-order batches would take the several-lanes-per-ray kernels: per-sample form)
+    monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", -1)
     plain_t = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W).items()}      # the default (linear-tail) kernel
     plain_l = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, out={})
     for k in plain_t:
@@ -52,8 +52,8 @@ def test_wave_tile_workgroups_feature_stage_and_compaction(gpu, orc, monkeypatch
     """The feature stage and the compacting final stage share the lane -> ray mapping with the stages in front of them (scratch columns):
     odd band shape, tile order == linear order."""
     from sanerf_hq_amd import raymarching as rm
-    monkeypatch.setenv("SN_FINAL_SP_MAX", "0")       # (small linear-order batches would take the several-lanes-per-ray kernels: per-sample form)
-    monkeypatch.setenv("SN_PROP_SP_MAX", "0")
+    monkeypatch.setattr(rm.tuning, "final_sp_max_rays", -1)       # (small linear-order batches would take the several-lanes-per-ray kernels: per-sample form)
+    monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", -1)
     steps = [64, 32]
     params = synthetic_params(steps, heads=True, seed=5)
     model = product_model(params, steps, True, gpu)

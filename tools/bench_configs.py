@@ -80,10 +80,8 @@ def c1_entry(dev):
     return res
 
 
-def main():
-    dev = torch.device("cuda:0")
-    out = {}
-    # ---- C3 ----
+def c3_entry(dev, warm=3, iters=10):
+    """BASELINE configs[2]: 400x400 rays + 256-d SAM-feature head (feature_container path), reference schedule [128,64,32]."""
     model = build(True, False, dev).eval()
     H = W = 400
     ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
@@ -91,35 +89,94 @@ def main():
     def c3():
         with torch.no_grad():
             return model.render(ro, rd, staged=False, perturb=False, return_feats=1, H=H, W=W, tile_w=W)
-    t = timeit(c3)
+    t = timeit(c3, warm, iters)
     with torch.no_grad():
-        t_rgb = timeit(lambda: rm.render_rays(model._get_plan(), ro, rd, tile_w=W))
-    out["C3_sam_head_400x400"] = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
+        t_rgb = timeit(lambda: rm.render_rays(model._get_plan(), ro, rd, tile_w=W), warm, iters)
+    out = {"rays_per_s": round(H * W / t, 1), "ms": round(t * 1e3, 3), "rgb_only_ms": round(t_rgb * 1e3, 3)}
     # configs[2] names "same grid" as configs[1] (the fp16 configuration): tables in half (radiance, proposal and SAM-feature grids), arithmetic fp32
     model.render_table_dtype = torch.float16
-    t16 = timeit(c3)
-    out["C3_sam_head_400x400"].update({"ms_f16_tables": round(t16 * 1e3, 3), "rays_per_s_f16_tables": round(H * W / t16, 1)})
-    model.render_table_dtype = torch.float32
-    del model
-    torch.cuda.empty_cache()
-    # ---- C1 = BASELINE configs[0] (64x64, L=8 T=2^14 grid, 16-32-16 / 31-32-3 MLPs, 32 samples per ray) on the GPU: the fused call
-    #      (size-agnostic last stage, k_final_stage_any) vs the stage loop over the stand-alone operators; also at 400x400 ----
-    out["C1_small_field"] = c1_entry(dev)
-    # ---- mask head at inference (renderer.py:304-305, 376-385): 400x400, [128,64,32]: the one-kernel head vs the three-kernel route ----
+    t16 = timeit(c3, warm, iters)
+    out.update({"ms_f16_tables": round(t16 * 1e3, 3), "rays_per_s_f16_tables": round(H * W / t16, 1)})
+    return out
+
+
+def mask_head_entry(dev, warm=3, iters=10):
+    """Mask head at inference (renderer.py:304-305, 376-385): 400x400, [128,64,32]: the one-kernel head vs the three-kernel route."""
     model = build(False, True, dev).eval()
+    H = W = 400
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
 
     def mask_render():
         with torch.no_grad():
             return model.render(ro, rd, staged=False, perturb=False, return_mask=1, H=H, W=W, tile_w=W)
-    os.environ["SN_MASK_HEAD"] = "unfused"
-    t_unf = timeit(mask_render)
+    model.fused_mask_head = False
+    t_unf = timeit(mask_render, warm, iters)
     ref_logits = mask_render()["instance_mask_logits"].clone()
-    os.environ["SN_MASK_HEAD"] = "fused"
-    t_fus = timeit(mask_render)
+    model.fused_mask_head = True
+    t_fus = timeit(mask_render, warm, iters)
     dlog = float((mask_render()["instance_mask_logits"] - ref_logits).abs().max())
-    out["mask_head_400x400"] = {"ms_fused_head": round(t_fus * 1e3, 3), "ms_three_kernel_head": round(t_unf * 1e3, 3),
-                                "rgb_only_ms": round(t_rgb * 1e3, 3), "max_abs_logit_diff": dlog}
-    del model
+    with torch.no_grad():
+        t_rgb = timeit(lambda: rm.render_rays(model._get_plan(), ro, rd, tile_w=W), warm, iters)
+    return {"ms_fused_head": round(t_fus * 1e3, 3), "ms_three_kernel_head": round(t_unf * 1e3, 3),
+            "rgb_only_ms": round(t_rgb * 1e3, 3), "max_abs_logit_diff": dlog}
+
+
+def c5_setup(dev):
+    model = build(False, True, dev).train()
+    for n_, p in model.named_parameters():
+        p.requires_grad_(n_.startswith("m_grid") or n_.startswith("mask_mlp"))
+    H = W = 512
+    N = 4096
+    roF, rdF = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
+    pix = torch.from_numpy((synth.hash_u01(N, 99) * (H * W)).astype(np.int64)).to(dev)
+    ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
+    labels = torch.from_numpy((synth.hash_u01(N, 100) < 0.5).astype(np.int64)).to(dev)
+    return model, ro, rd, labels, N
+
+
+def c5_entry(dev, warm=3, iters=10, optimisers=True):
+    """BASELINE configs[4]: mask-field training step, 4096 rays (fwd + bwd of m_grid + mask_mlp under the mask NLL, field frozen)."""
+    from sanerf_hq_amd.optim import Adam as HipAdam   # (csrc/optim.hip: the same dense update, one pass per tensor)
+    model, ro, rd, labels, N = c5_setup(dev)
+    optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
+
+    def fwd_bwd():
+        optim.zero_grad(set_to_none=True)
+        o = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=False, return_mask=1)
+        pm = torch.softmax(o["instance_mask_logits"], dim=-1).clamp(min=1e-6, max=1 - 1e-6)
+        loss = (-torch.log(torch.gather(pm, -1, labels[..., None]))).mean()
+        loss.backward()
+        return loss
+
+    def step():
+        fwd_bwd()
+        optim.step()
+    t_fb = timeit(fwd_bwd, warm, iters)
+    out = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "rays_per_s_fwd_bwd": round(N / t_fb, 1),
+           "fwd_bwd_single_pass_adam_ms": round(timeit(step, warm, iters) * 1e3, 3)}
+    if optimisers:
+        optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
+        out["fwd_bwd_adam_ms"] = round(timeit(step, warm, iters) * 1e3, 3)
+        # opt-in touched-elements-only update (SN_ADAM_LAZY; torch.optim.SparseAdam's semantics, NOT the reference's optimiser)
+        optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15, lazy=True)
+        out["fwd_bwd_lazy_adam_ms"] = round(timeit(step, warm, iters) * 1e3, 3)
+        try:   # torch's single-kernel Adam over the 160 MiB table (same update rule; the reference constructs the default one)
+            optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15, fused=True)
+            out["fwd_bwd_fused_adam_ms"] = round(timeit(step, warm, iters) * 1e3, 3)
+        except Exception as e:   # noqa: BLE001
+            out["fwd_bwd_fused_adam_ms"] = f"unavailable: {type(e).__name__}"
+    return out
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = {}
+    out["C3_sam_head_400x400"] = c3_entry(dev)
+    torch.cuda.empty_cache()
+    # ---- C1 = BASELINE configs[0] (64x64, L=8 T=2^14 grid, 16-32-16 / 31-32-3 MLPs, 32 samples per ray) on the GPU: the fused call
+    #      (size-agnostic last stage, k_final_stage_any) vs the stage loop over the stand-alone operators; also at 400x400 ----
+    out["C1_small_field"] = c1_entry(dev)
+    out["mask_head_400x400"] = mask_head_entry(dev)
     torch.cuda.empty_cache()
     # ---- opt-in early termination (SURVEY 8f-1) on an opaque field: 800x800, [128], MLP gain 40 (sigma ~0 or huge) ----
     from helpers import product_model  # noqa: E402
@@ -157,45 +214,10 @@ def main():
             "image_max_abs_diff": float((o0["image"] - o1["image"]).abs().max())}   # (per-sample third layer vs linear tail: fp32 round-off)
         del soft
     # ---- C5 ----
-    model = build(False, True, dev).train()
-    for n_, p in model.named_parameters():
-        p.requires_grad_(n_.startswith("m_grid") or n_.startswith("mask_mlp"))
-    H = W = 512
-    N = 4096
-    roF, rdF = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=dev)
-    pix = torch.from_numpy((synth.hash_u01(N, 99) * (H * W)).astype(np.int64)).to(dev)
-    ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
-    labels = torch.from_numpy((synth.hash_u01(N, 100) < 0.5).astype(np.int64)).to(dev)
-    optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
-
-    def fwd_bwd():
-        optim.zero_grad(set_to_none=True)
-        o = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=False, return_mask=1)
-        pm = torch.softmax(o["instance_mask_logits"], dim=-1).clamp(min=1e-6, max=1 - 1e-6)
-        loss = (-torch.log(torch.gather(pm, -1, labels[..., None]))).mean()
-        loss.backward()
-        return loss
-
-    def step():
-        fwd_bwd()
-        optim.step()
-    t_fb = timeit(fwd_bwd)
-    t_step = timeit(step)
-    out["C5_mask_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_step * 1e3, 3),
-                                               "rays_per_s_fwd_bwd": round(N / t_fb, 1)}
-    from sanerf_hq_amd.optim import Adam as HipAdam  # noqa: E402   (csrc/optim.hip: the same dense update, one pass per tensor)
-    optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
-    out["C5_mask_training_step_4096_rays"]["fwd_bwd_single_pass_adam_ms"] = round(timeit(step) * 1e3, 3)
-    # opt-in touched-elements-only update (SN_ADAM_LAZY; torch.optim.SparseAdam's semantics, NOT the reference's optimiser)
-    optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15, lazy=True)
-    out["C5_mask_training_step_4096_rays"]["fwd_bwd_lazy_adam_ms"] = round(timeit(step) * 1e3, 3)
-    try:   # torch's single-kernel Adam over the 160 MiB table (same update rule; the reference constructs the default one)
-        optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15, fused=True)
-        out["C5_mask_training_step_4096_rays"]["fwd_bwd_fused_adam_ms"] = round(timeit(step) * 1e3, 3)
-    except Exception as e:   # noqa: BLE001
-        out["C5_mask_training_step_4096_rays"]["fwd_bwd_fused_adam_ms"] = f"unavailable: {type(e).__name__}"
+    out["C5_mask_training_step_4096_rays"] = c5_entry(dev)
+    _, ro, rd, _, N = c5_setup(dev)
+    from sanerf_hq_amd.optim import Adam as HipAdam  # noqa: E402
     # ---- RGB-mode training step (trainer.py:360-392): 4096 rays, [128,64,32], everything trainable, MSE + proposal loss ----
-    del model
     torch.cuda.empty_cache()
     opt = make_opt(with_sam=False, with_mask=False)
     opt.lambda_proposal, opt.lambda_distort = 1.0, 0.0

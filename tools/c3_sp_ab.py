@@ -10,6 +10,8 @@ if len(sys.argv) > 1:
         sys.path.insert(0, p)
     from bench_configs import build, timeit
     from sanerf_hq_amd import raymarching as rm, synth
+    import _tuning
+    _tuning.apply_default()
     dev = torch.device("cuda:0")
     model = build(False, False, dev).eval()
     H = W = 400
@@ -20,9 +22,9 @@ if len(sys.argv) > 1:
         ref = rm.render_rays(plan, ro, rd, tile_w=W)["image"].clone()
         t = timeit(lambda: rm.render_rays(plan, ro, rd, tile_w=tw), 3, 20)
         img = rm.render_rays(plan, ro, rd, tile_w=tw)["image"]
-    print(f"{sys.argv[1]:6s} PROP_SP_MAX={os.environ.get('SN_PROP_SP_MAX', '-'):7s} FINAL_SP_MAX={os.environ.get('SN_FINAL_SP_MAX', '-'):7s} {t * 1e3:.3f} ms  bit-equal to the tile-order image: {bool(torch.equal(img, ref))}")
+    print(f"{sys.argv[1]:6s} tuning {os.environ.get('SN_TUNING', '-'):48s} {t * 1e3:.3f} ms  bit-equal to the tile-order image: {bool(torch.equal(img, ref))}")
 else:
-    for mode, env in (("tile", {}), ("linear", {}), ("linear", {"SN_PROP_SP_MAX": "200000"}), ("linear", {"SN_FINAL_SP_MAX": "200000"}),
-                      ("linear", {"SN_PROP_SP_MAX": "200000", "SN_FINAL_SP_MAX": "200000"})):
+    for mode, env in (("tile", {}), ("linear", {}), ("linear", {"SN_TUNING": "prop_sp_max_rays=200000"}), ("linear", {"SN_TUNING": "final_sp_max_rays=200000"}),
+                      ("linear", {"SN_TUNING": "prop_sp_max_rays=200000,final_sp_max_rays=200000"})):
         e = dict(os.environ); e.update(env)
         subprocess.run([sys.executable, os.path.abspath(__file__), mode], env=e)

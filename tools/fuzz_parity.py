@@ -100,10 +100,10 @@ def main():
         plan = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32)
         kw = dict(cam_near_far=None if cnf is None else T(cnf, dev), want=("inds",))
         # the default kernel's linear-tail form (third layer's geometry rows once per ray) first: oracle tolerances apply to it as well
-        os.environ["SN_RENDER_LT"] = "1"
+        rm.tuning.per_sample_form = 0
         lt = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=W, out={}, **kw).items()}
         # bit identity between the kernels (tile / linear lane mapping, several lanes per ray, compaction) is a property of the per-sample form
-        os.environ["SN_RENDER_LT"] = "0"
+        rm.tuning.per_sample_form = 1
         tiled = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=W, **kw).items()}
         linear = rm.render_rays(plan, T(ro, dev), T(rd, dev), tile_w=0, out={}, **kw)
         want = orc.render(oracle_cfg(orc, params, steps, table_f16=f16), ro, rd, cam_near_far=cnf, debug=True)

@@ -15,9 +15,15 @@ from sanerf_hq_amd.nerf.network import SkipConnMLP  # noqa: E402
 
 
 def both(fn):
-    os.environ["SN_WIDE_JIT"] = "0"
+    """(k_mlp_wide, k_mlp_wide_j) results with the experiments build (SN_LIB=sanerf-hq_amd/libsanerf_hip_exp.so); the product library
+    carries k_mlp_wide_j only: its result twice (the comparison with the torch modules below is what then checks it)."""
+    from sanerf_hq_amd import _lib
+    if not (_lib.lib().sn_build_flags() & _lib.BUILD_EXPERIMENTS):
+        b = fn()
+        return b, b
+    _lib.check(_lib.lib().sn_debug_set(b"wide_jit", 0), "debug_set")
     a = fn()
-    os.environ["SN_WIDE_JIT"] = "1"
+    _lib.check(_lib.lib().sn_debug_set(b"wide_jit", 1), "debug_set")
     b = fn()
     return a, b
 

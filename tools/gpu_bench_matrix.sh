@@ -2,7 +2,7 @@
 # usage (on the GPU box, from the repo root): tools/gpu_bench_matrix.sh "<modes>" "<schedules>" "<tables>"
 mkdir -p gpurun_out
 for m in $1; do for sch in $2; do for tb in ${3:-f32}; do
-  SN_RENDER_MLP=$m timeout 300 python bench.py --steps 10 --warmup 3 --schedule $sch --tables $tb --no-cpu-baseline > gpurun_out/bench_${m}_${sch}_${tb}.log 2>&1
+  timeout 300 python bench.py --tuning mlp_mode=$m --steps 10 --warmup 3 --schedule $sch --tables $tb --no-cpu-baseline > gpurun_out/bench_${m}_${sch}_${tb}.log 2>&1
   python - <<PY
 import json
 try:

@@ -1,4 +1,4 @@
-"""Linear-tail final stage (SN_RENDER_LT=1) against the per-sample form and the oracle: max differences, then timing.
+"""Linear-tail final stage (the default) against the per-sample form and the oracle: max differences, then timing.
 usage (GPU box, repo root): python tools/lt_check.py [--hw 800]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,8 +11,7 @@ from sanerf_hq_amd import raymarching as rm, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--hw", type=int, default=800)
 ap.add_argument("--iters", type=int, default=30)
-ap.add_argument("--env", default="SN_RENDER_LT")
-ap.add_argument("--on", default="1", help="value of the switch for the B side (the A side is 0)")
+ap.add_argument("--field", default="per_sample_form", help="Tuning field that differs between the A side (1) and the B side (0)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 pose = synth.orbit_pose(1.0, 20.0, 30.0)
@@ -29,7 +28,7 @@ for steps in ([128], [128, 64, 32], [7]):
             ro, rd = rm.generate_rays(pose, intr, H, W, device=dev)
             outs = {}
             for v in ("0", "1"):
-                os.environ[args.env] = "0" if v == "0" else args.on
+                setattr(rm.tuning, args.field, 1 if v == "0" else 0)
                 o = rm.render_rays(plan, ro, rd, tile_w=W, want=("f_image",), out={})
                 torch.cuda.synchronize()
                 outs[v] = {k: t.clone() for k, t in o.items()}
@@ -48,7 +47,7 @@ for steps in ([128], [128, 64, 32]):
         plan = rm.RenderPlan(model, steps, tdt)
         res = {}
         for v in (0, 1, 0, 1):
-            os.environ[args.env] = "0" if v == 0 else args.on
+            setattr(rm.tuning, args.field, 1 if v == 0 else 0)
             out = {}
             for _ in range(5):
                 rm.render_rays(plan, ro, rd, tile_w=W, out=out)

@@ -1,4 +1,4 @@
-"""A/B of the two proposal-stage kernels on linear-order ray batches of growing size (picks SN_PROP_SP_MAX's default).
+"""A/B of the two proposal-stage kernels on linear-order ray batches of growing size (picks the default of Tuning.prop_sp_max_rays).
 Run on the GPU box: python tools/prop_sp_ab.py [N]"""
 import json
 import os
@@ -40,8 +40,8 @@ def main():
             ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
             row = {}
             for name, v, vf in (("lane", "0", "0"), ("sp_prop", "100000000", "0"), ("sp", "100000000", "100000000")):
-                os.environ["SN_PROP_SP_MAX"] = v
-                os.environ["SN_FINAL_SP_MAX"] = vf
+                rm.tuning.prop_sp_max_rays = int(v) if int(v) else -1
+                rm.tuning.final_sp_max_rays = int(vf) if int(vf) else -1
                 row[name + "_ms"] = round(timeit(lambda: rm.render_rays(plan, ro, rd, tile_w=0)) * 1e3, 4)
             out[f"{str(dt).split('.')[-1]}_N{N}"] = row
     print(json.dumps(out))
