@@ -41,21 +41,23 @@ constexpr uint32_t BIN_FLOATS = 16128;          // contribution floats one work 
 constexpr uint32_t BIN_ROWS_MAX = 4096;         // rows per bin (LDS counters of k_bin_accum: 16 KiB; with the 64 KiB above two workgroups per CU)
 constexpr uint32_t BIN_MAX_PER_LEVEL = 4096;    // LDS histogram of the count / scatter kernels
 constexpr uint32_t SPT = 4;                     // samples per thread of the count / scatter kernels (1024 samples = 8192 pairs per block)
-constexpr uint32_t PLAN_THREADS = 1024;
+constexpr uint32_t PLAN_THREADS = 256;
+constexpr uint32_t SMALL_BIN_FLOATS = 256;      // split bins up to this size flush with global atomics instead of slabs + merge
 
 __host__ __device__ constexpr uint32_t e_cap(uint32_t C) { return BIN_FLOATS / C; }
 
 struct BinGeom {
     uint32_t shift[SN_MAX_LEVELS];   // log2(rows per bin) of each level
     uint32_t nb[SN_MAX_LEVELS];      // bins of each level
-    uint32_t nbs;                    // stride of the [level][bin] arrays = max bins per level
+    uint32_t boff[SN_MAX_LEVELS + 1]; // first slot of each level in the bin-indexed arrays (counts, cursors): levels back to back
     uint32_t ecap;                   // entries per work item (E_CAP of this C)
     uint32_t C;
 };
 
 struct BinHdr { uint32_t n_items, n_shared_items, n_shared_bins, n_entries; };
 struct BinItem { uint32_t level_bin, begin, end, slab_off; };   // slab_off = first float of the item's partial-sum slab, or ~0u: the item owns its bin
-struct BinShared { uint32_t level_bin, slab_off, n_slabs, pad; };   // the bin's slabs are consecutive: slab_off + k * (rows per bin * C)
+struct BinShared { uint32_t level_bin, slab_off, n_slabs, item0, begin, end, pad0, pad1; };   // a split bin: n_slabs items (first one = item item0 of the work list) of E_CAP
+                                                                                            // entries each over [begin, end); slabs consecutive: slab_off + k * (rows per bin * C)
 
 template <uint32_t D>
 __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint32_t b, const GridLevels &g, uint32_t level,
@@ -109,35 +111,52 @@ __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inp
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nb; i += 256u) {
         const uint32_t c = hist[i];
-        if (c) atomicAdd(&counts[level * bg.nbs + i], c);
+        if (c) atomicAdd(&counts[bg.boff[level] + i], c);
     }
 }
 
-// exclusive scan over all (level, bin) counts; emits write cursors and the work lists.  Items of split bins come first
-// in the list.  One workgroup; thread t owns the run of bins [t * per, (t + 1) * per); five running sums (entries, items of split
-// bins, items of whole bins, split bins, slab floats) are scanned with wave shuffles + one hop through LDS.
-__global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ cursor, uint32_t total_bins,
-                                                           BinHdr *__restrict__ hdr, BinItem *__restrict__ items, BinShared *__restrict__ shared_bins,
-                                                           BinGeom bg) {
-    SN_POISON_ALL();
+// Exclusive scan over all (level, bin) counts -> entry offsets, write cursors and the work lists (items of split bins first).  Five running
+// sums: entries, items of split bins, items of whole bins, split bins, slab floats.  Two launches of PLAN_BLOCK_BINS-bin workgroups (one
+// 1024-thread workgroup doing all of it kept a single CU busy for 55-70 us): k_bin_plan_sums leaves every workgroup's totals,
+// k_bin_plan_emit turns them into its base, scans its own bins with wave shuffles and writes.  A thread owns PLAN_PER consecutive bins.
+constexpr uint32_t PLAN_PER = 8, PLAN_BLOCK_BINS = PLAN_THREADS * PLAN_PER;
+
+struct PlanTables { uint32_t boff[SN_MAX_LEVELS + 1], slab[SN_MAX_LEVELS]; };
+
+// per-lane indexing of a kernel-argument array is a dependent memory load per access: the level table goes to LDS, and a thread's run of
+// bins is consecutive, so its level only ever steps forward.  A split bin's items hand their partial sums over through slabs when the bin
+// is large, and add them to the table with atomics when it is small (<= SMALL_BIN_FLOATS floats: coarse levels, where one row gets
+// thousands of contributions and a bin splits into hundreds of items).
+__device__ __forceinline__ void plan_tables(PlanTables &t, const BinGeom &bg) {
+    if (threadIdx.x <= SN_MAX_LEVELS) t.boff[threadIdx.x] = bg.boff[threadIdx.x];
+    if (threadIdx.x < SN_MAX_LEVELS) { const uint32_t f = bg.C << bg.shift[threadIdx.x]; t.slab[threadIdx.x] = f > SMALL_BIN_FLOATS ? f : 0u; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void plan_thread_sums(const uint32_t *__restrict__ counts, uint32_t total_bins, const BinGeom &bg, const PlanTables &tb,
+                                                 uint32_t lo, uint32_t (&c8)[PLAN_PER], uint32_t &lvl0, uint32_t (&v)[5]) {
+#pragma unroll
+    for (uint32_t j = 0; j < PLAN_PER; ++j) c8[j] = lo + j < total_bins ? counts[lo + j] : 0u;      // independent loads, in flight together
+    lvl0 = 0;
+    while (lvl0 + 1u < SN_MAX_LEVELS && lo >= tb.boff[lvl0 + 1u]) ++lvl0;
+    uint32_t lvl = lvl0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < PLAN_PER; ++j) {
+        const uint32_t c = c8[j];
+        if (lo + j < total_bins) while (lo + j >= tb.boff[lvl + 1u]) ++lvl;
+        v[0] += c;
+        if (c > bg.ecap) { const uint32_t k = (c + bg.ecap - 1u) / bg.ecap; v[1] += k; ++v[3]; v[4] += k * tb.slab[lvl]; }
+        else if (c) ++v[2];
+    }
+}
+
+// workgroup-wide sums (total) and this thread's exclusive prefix (excl) of five values: wave shuffles + one hop through LDS
+__device__ __forceinline__ void plan_block_scan(const uint32_t (&v)[5], uint32_t (&excl)[5], uint32_t (&total)[5]) {
     constexpr uint32_t NW = PLAN_THREADS / 64u;
     __shared__ uint32_t s_w[NW][5];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, cap = bg.ecap, nbs = bg.nbs;
-    const uint32_t per = (total_bins + PLAN_THREADS - 1u) / PLAN_THREADS;
-    const uint32_t lo = t * per < total_bins ? t * per : total_bins, hi = lo + per < total_bins ? lo + per : total_bins;
-    uint32_t v[5] = {0u, 0u, 0u, 0u, 0u};            // entries, items of split bins, items of whole bins, split bins, slab floats
-    for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
-        uint32_t c8[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) c8[j] = i0 + j < hi ? counts[i0 + j] : 0u;       // eight independent loads in flight
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) {
-            const uint32_t c = c8[j];
-            v[0] += c;
-            if (c > cap) { const uint32_t k = (c + cap - 1u) / cap; v[1] += k; ++v[3]; v[4] += k * (bg.C << bg.shift[(i0 + j) / nbs]); }
-            else if (c) ++v[2];
-        }
-    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t inc[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) inc[q] = v[q];
@@ -151,40 +170,60 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan(const uint32_t *__res
         for (int q = 0; q < 5; ++q) s_w[wave][q] = inc[q];
     }
     __syncthreads();
-    uint32_t base[5], tot[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         uint32_t bsum = 0, all = 0;
         for (uint32_t w2 = 0; w2 < NW; ++w2) { const uint32_t x = s_w[w2][q]; if (w2 < wave) bsum += x; all += x; }
-        base[q] = bsum + inc[q] - v[q];              // exclusive prefix of this thread's run
-        tot[q] = all;
+        excl[q] = bsum + inc[q] - v[q];
+        total[q] = all;
     }
-    uint32_t off = base[0], ish = base[1], iex = tot[1] + base[2], isb = base[3], isl = base[4];
-    for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
-        uint32_t c8[8];
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_sums(const uint32_t *__restrict__ counts, uint32_t total_bins, BinGeom bg, uint32_t *__restrict__ block_sums) {
+    SN_POISON_ALL();
+    __shared__ PlanTables tb;
+    plan_tables(tb, bg);
+    uint32_t c8[PLAN_PER], lvl0, v[5], excl[5], total[5];
+    plan_thread_sums(counts, total_bins, bg, tb, blockIdx.x * PLAN_BLOCK_BINS + threadIdx.x * PLAN_PER, c8, lvl0, v);
+    plan_block_scan(v, excl, total);
+    if (threadIdx.x < 5u) block_sums[blockIdx.x * 5u + threadIdx.x] = total[threadIdx.x];
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_emit(const uint32_t *__restrict__ counts, uint32_t *__restrict__ cursor, uint32_t total_bins,
+                                                                const uint32_t *__restrict__ block_sums, BinHdr *__restrict__ hdr, BinItem *__restrict__ items,
+                                                                BinShared *__restrict__ shared_bins, BinGeom bg) {
+    SN_POISON_ALL();
+    __shared__ PlanTables tb;
+    plan_tables(tb, bg);
+    const uint32_t lo = blockIdx.x * PLAN_BLOCK_BINS + threadIdx.x * PLAN_PER;
+    uint32_t c8[PLAN_PER], lvl, v[5], excl[5], total[5], base[5], all[5];
+    plan_thread_sums(counts, total_bins, bg, tb, lo, c8, lvl, v);
+    plan_block_scan(v, excl, total);
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) c8[j] = i0 + j < hi ? counts[i0 + j] : 0u;
+    for (int q = 0; q < 5; ++q) { base[q] = 0u; all[q] = 0u; }
+    for (uint32_t bq = 0; bq < gridDim.x; ++bq) {              // (at most 128 workgroups' totals: uniform loads)
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) {
-            const uint32_t i = i0 + j, c = c8[j];
-            if (i >= hi) break;
-            cursor[i] = off;
-            const uint32_t level = i / nbs, bin = i - level * nbs, lb = (level << 16) | bin;
-            if (c > cap) {
-                const uint32_t k = (c + cap - 1u) / cap, slab = bg.C << bg.shift[level];
-                shared_bins[isb++] = BinShared{lb, isl, k, 0u};
-                for (uint32_t q = 0; q < k; ++q) {
-                    const uint32_t b0 = off + q * cap, b1 = (q + 1u == k) ? off + c : b0 + cap;
-                    items[ish++] = BinItem{lb, b0, b1, isl};
-                    isl += slab;
-                }
-            } else if (c) {
-                items[iex++] = BinItem{lb, off, off + c, 0xffffffffu};
-            }
-            off += c;
+        for (int q = 0; q < 5; ++q) { const uint32_t x = block_sums[bq * 5u + q]; all[q] += x; if (bq < blockIdx.x) base[q] += x; }
+    }
+    uint32_t off = base[0] + excl[0], ish = base[1] + excl[1], iex = all[1] + base[2] + excl[2], isb = base[3] + excl[3], isl = base[4] + excl[4];
+#pragma unroll
+    for (uint32_t j = 0; j < PLAN_PER; ++j) {
+        const uint32_t i = lo + j, c = c8[j];
+        if (i >= total_bins) break;
+        while (i >= tb.boff[lvl + 1u]) ++lvl;
+        cursor[i] = off;
+        const uint32_t lb = (lvl << 16) | (i - tb.boff[lvl]);
+        if (c > bg.ecap) {                       // split bin: one record, its k items are implicit (k_bin_accum finds the record of item i by bisection)
+            const uint32_t k = (c + bg.ecap - 1u) / bg.ecap, slab = tb.slab[lvl];
+            shared_bins[isb++] = BinShared{lb, slab ? isl : 0xffffffffu, k, ish, off, off + c, 0u, 0u};
+            ish += k;
+            isl += k * slab;
+        } else if (c) {
+            items[iex++] = BinItem{lb, off, off + c, 0xffffffffu};
         }
+        off += c;
     }
-    if (t == 0u) *hdr = BinHdr{tot[1] + tot[2], tot[1], tot[3], tot[0]};
+    if (blockIdx.x == 0 && threadIdx.x == 0u) *hdr = BinHdr{all[1] + all[2], all[1], all[3], all[0]};
 }
 
 template <uint32_t D, uint32_t C>
@@ -212,31 +251,58 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ i
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nb; i += 256u) {
         const uint32_t c = hist[i];
-        if (c) hist[i] = atomicAdd(&cursor[level * bg.nbs + i], c);
+        if (c) hist[i] = atomicAdd(&cursor[bg.boff[level] + i], c);
     }
     __syncthreads();
     const uint32_t mask = (1u << shift) - 1u;
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (uint32_t s = 0; s < SPT; ++s) {
-        if (!live[s]) continue;
         const uint32_t b = blockIdx.x * (256u * SPT) + s * 256u + threadIdx.x;
         float gs[C];
-        load_row<float, (int)C>(layout == SN_LAYOUT_LBC ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * g.L + level) * C, gs);
+        if (live[s]) load_row<float, (int)C>(layout == SN_LAYOUT_LBC ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * g.L + level) * C, gs);
+        else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) gs[c] = 0.0f;
+        }
 #pragma unroll
         for (uint32_t i = 0; i < NC; ++i) {
-            const size_t slot = (size_t)hist[row[s][i] >> shift] + rank[s][i];
-            ekey[slot] = (uint16_t)(row[s][i] & mask);
-            float *dst = econtrib + slot * C;
+            const uint32_t slot = live[s] ? hist[row[s][i] >> shift] + rank[s][i] : 0xffffffffu;      // (n < 2^31: slots fit 32 bits)
+            if (live[s]) ekey[slot] = (uint16_t)(row[s][i] & mask);
             const float ww = w[s][i];
-            if constexpr (C % 4 == 0) {
+            if constexpr (C == 8) {
+                // a pair's 32-byte row leaves through TWO NEIGHBOURING LANES (16 bytes each): a store instruction then touches 32 distinct rows
+                // instead of 64 -- what a scattered store costs follows the number of lines it touches (tools/ubench/gathers.hip).  Round k:
+                // lane j writes half (j & 1) of the pair that lane 32 k + (j >> 1) owns.
+                float v[8];
 #pragma unroll
-                for (uint32_t q = 0; q < C / 4; ++q)
-                    reinterpret_cast<float4 *>(dst)[q] = make_float4(ww * gs[4 * q], ww * gs[4 * q + 1], ww * gs[4 * q + 2], ww * gs[4 * q + 3]);
-            } else if constexpr (C == 2) {
-                *reinterpret_cast<float2 *>(dst) = make_float2(ww * gs[0], ww * gs[1]);
+                for (uint32_t c = 0; c < 8; ++c) v[c] = ww * gs[c];
+#pragma unroll
+                for (uint32_t k = 0; k < 2u; ++k) {
+                    const int src = (int)(32u * k + (lane >> 1));
+                    const uint32_t sl = (uint32_t)__shfl((int)slot, src);
+                    float o[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) {
+                        const float lo = __shfl(v[q], src), hi = __shfl(v[4 + q], src);
+                        o[q] = (lane & 1u) ? hi : lo;
+                    }
+                    if (sl != 0xffffffffu)
+                        *reinterpret_cast<float4 *>(econtrib + (size_t)sl * 8u + (lane & 1u) * 4u) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             } else {
+                if (!live[s]) continue;
+                float *dst = econtrib + (size_t)slot * C;
+                if constexpr (C % 4 == 0) {
 #pragma unroll
-                for (uint32_t c = 0; c < C; ++c) dst[c] = ww * gs[c];
+                    for (uint32_t q = 0; q < C / 4; ++q)
+                        reinterpret_cast<float4 *>(dst)[q] = make_float4(ww * gs[4 * q], ww * gs[4 * q + 1], ww * gs[4 * q + 2], ww * gs[4 * q + 3]);
+                } else if constexpr (C == 2) {
+                    *reinterpret_cast<float2 *>(dst) = make_float2(ww * gs[0], ww * gs[1]);
+                } else {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; ++c) dst[c] = ww * gs[c];
+                }
             }
         }
     }
@@ -262,13 +328,23 @@ __device__ __forceinline__ void store_row(float *dst, const float (&v)[C]) {
 //   d. rows are summed from LDS by the thread(s) that own them: one thread per row when the bin has >= 256 rows, else 256 / rows threads per
 //      row (coarse levels: a bin of 4 rows holds ~1000 entries) folded with wave shuffles and, beyond 64 threads per row, one LDS hop.
 template <uint32_t C>
-__global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__ hdr, const BinItem *__restrict__ items, GridLevels g, BinGeom bg,
+__global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__ hdr, const BinItem *__restrict__ items, const BinShared *__restrict__ shared_bins,
+                                                      GridLevels g, BinGeom bg,
                                                       const uint16_t *__restrict__ ekey, const float *__restrict__ econtrib,
                                                       float *__restrict__ slabs, float *__restrict__ grad_table) {
     SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
-    if (blockIdx.x >= hdr->n_items) return;
-    const BinItem it = items[blockIdx.x];
+    const BinHdr h = *hdr;
+    if (blockIdx.x >= h.n_items) return;
+    BinItem it;
+    if (blockIdx.x < h.n_shared_items) {         // an item of a split bin: bisect the records' first-item indices (ascending)
+        uint32_t lo = 0, hi = h.n_shared_bins;
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (shared_bins[mid].item0 <= blockIdx.x) lo = mid; else hi = mid; }
+        const BinShared sb = shared_bins[lo];
+        const uint32_t j = blockIdx.x - sb.item0, b0 = sb.begin + j * bg.ecap;
+        it = BinItem{sb.level_bin, b0, umin(b0 + bg.ecap, sb.end),
+                     sb.slab_off == 0xffffffffu ? 0xfffffffeu : sb.slab_off + j * (bg.C << bg.shift[sb.level_bin >> 16])};   // ...fe: small split bin, atomics
+    } else it = items[blockIdx.x];
     const uint32_t level = it.level_bin >> 16, bin = it.level_bin & 0xffffu, shift = bg.shift[level], brows = 1u << shift;
     uint32_t *end = lds_u;
     float *sorted = reinterpret_cast<float *>(lds_u + BIN_ROWS_MAX);
@@ -314,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__
     }
     __syncthreads();
     const uint32_t row0 = bin << shift, rows = umin(brows, g.size[level] - row0);
-    const bool to_slab = it.slab_off != 0xffffffffu;
+    const bool to_slab = it.slab_off < 0xfffffffeu, atomic_out = it.slab_off == 0xfffffffeu;
     float *out = to_slab ? slabs + it.slab_off : grad_table + ((size_t)g.off[level] + row0) * C;     // slab: [row][C] like the table
     if (brows >= 256u) {
         for (uint32_t r = tid; r < rows; r += 256u) {
@@ -329,7 +405,10 @@ __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__
 #pragma unroll
                 for (uint32_t c = 0; c < C; ++c) acc[c] += v[c];
             }
-            store_row<C>(out + (size_t)r * C, acc);
+            if (atomic_out) {
+#pragma unroll
+                for (uint32_t c = 0; c < C; ++c) if (acc[c] != 0.0f) unsafeAtomicAdd(out + (size_t)r * C + c, acc[c]);
+            } else store_row<C>(out + (size_t)r * C, acc);
         }
     } else {
         const uint32_t tpr_log2 = 8u - shift, tpr = 1u << tpr_log2;           // threads per row
@@ -359,25 +438,54 @@ __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__
 #pragma unroll
             for (uint32_t c = 0; c < C; ++c) { float t2 = 0.0f; for (uint32_t k = 0; k < wpr; ++k) t2 += red[w0 + k][c]; acc[c] = t2; }
         }
-        if (sub == 0u && r < rows && (s1 > s0 || to_slab)) store_row<C>(out + (size_t)r * C, acc);
+        if (sub == 0u && r < rows && (s1 > s0 || to_slab)) {
+            if (atomic_out) {                     // one of several items of a small bin: its partial row joins the others' in the table
+#pragma unroll
+                for (uint32_t c = 0; c < C; ++c) if (acc[c] != 0.0f) unsafeAtomicAdd(out + (size_t)r * C + c, acc[c]);
+            } else store_row<C>(out + (size_t)r * C, acc);
+        }
     }
 }
 
+// A split bin's rows = the sum of its items' slabs.  Coarse bins are small (4 rows x 8 channels) and split into MANY items, fine bins large
+// and split into few: the 256 threads are dealt out as (floats of the bin, rounded up to a power of two F <= 256) x (256 / F slab subsets);
+// partial sums meet in LDS.  Slab order within a subset is fixed, so the result does not depend on scheduling.
 template <uint32_t C>
 __global__ __launch_bounds__(256) void k_bin_merge(const BinHdr *__restrict__ hdr, const BinShared *__restrict__ shared_bins, GridLevels g, BinGeom bg,
                                                    const float *__restrict__ slabs, float *__restrict__ grad_table) {
     SN_POISON_ALL();
+    __shared__ float part[256];
     const uint32_t nsb = hdr->n_shared_bins;
     for (uint32_t sbi = blockIdx.x; sbi < nsb; sbi += gridDim.x) {
         const BinShared sb = shared_bins[sbi];
+        if (sb.slab_off == 0xffffffffu) continue;                              // small bin: its items added their rows with atomics
         const uint32_t level = sb.level_bin >> 16, bin = sb.level_bin & 0xffffu, shift = bg.shift[level], brows = 1u << shift;
         const uint32_t row0 = bin << shift, rows = umin(brows, g.size[level] - row0);
         float *base = grad_table + ((size_t)g.off[level] + row0) * C;
-        const uint32_t stride = brows * C;
-        for (uint32_t i = threadIdx.x; i < rows * C; i += 256u) {               // one float per thread: sum over the bin's slabs in slab order
+        const uint32_t stride = brows * C, nf = rows * C;
+        uint32_t F = 1;
+        while (F < nf && F < 256u) F <<= 1;
+        const uint32_t subsets = 256u / F, sub = threadIdx.x / F, fi = threadIdx.x & (F - 1u);
+        for (uint32_t i0 = 0; i0 < nf; i0 += F) {
+            const uint32_t i = i0 + fi;
             float v = 0.0f;
-            for (uint32_t k = 0; k < sb.n_slabs; ++k) v += slabs[(size_t)sb.slab_off + (size_t)k * stride + i];
-            if (v != 0.0f) base[i] = v;
+            if (i < nf) {
+                const float *src = slabs + (size_t)sb.slab_off + i;
+                for (uint32_t k0 = sub; k0 < sb.n_slabs; k0 += 8u * subsets) {          // eight slabs' loads in flight, summed in slab order
+                    float t8[8];
+#pragma unroll
+                    for (uint32_t q = 0; q < 8u; ++q) { const uint32_t k = k0 + q * subsets; t8[q] = k < sb.n_slabs ? src[(size_t)k * stride] : 0.0f; }
+#pragma unroll
+                    for (uint32_t q = 0; q < 8u; ++q) v += t8[q];
+                }
+            }
+            if (subsets > 1u) {
+                part[threadIdx.x] = v;
+                __syncthreads();
+                if (sub == 0u) for (uint32_t q = 1; q < subsets; ++q) v += part[q * F + fi];
+                __syncthreads();
+            }
+            if (sub == 0u && i < nf && v != 0.0f) base[i] = v;
         }
     }
 }
@@ -387,7 +495,8 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // rows per bin of every level: about half of an item's capacity in expected entries (density = pairs per row of the level), so that
 // uneven occupancy rarely splits a bin; power of two; at most BIN_ROWS_MAX rows and BIN_MAX_PER_LEVEL bins
 static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t max_level, uint64_t *bins_used, uint64_t *rows_total) {
-    bg->ecap = e_cap(C); bg->C = C; bg->nbs = 0;
+    bg->ecap = e_cap(C); bg->C = C;
+    for (uint32_t l = 0; l <= SN_MAX_LEVELS; ++l) bg->boff[l] = 0;
     *bins_used = 0; *rows_total = 0;
     for (uint32_t l = 0; l < SN_MAX_LEVELS; ++l) { bg->shift[l] = 0; bg->nb[l] = 0; }
     const uint32_t rmax = bg->ecap < BIN_ROWS_MAX ? bg->ecap : BIN_ROWS_MAX;
@@ -401,30 +510,32 @@ static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, u
         while (((size + (1ull << s) - 1) >> s) > BIN_MAX_PER_LEVEL) { if ((2u << s) > rmax) return false; ++s; }
         bg->shift[l] = s;
         bg->nb[l] = (uint32_t)((size + (1ull << s) - 1) >> s);
-        if (bg->nb[l] > bg->nbs) bg->nbs = bg->nb[l];
+        bg->boff[l + 1] = bg->boff[l] + bg->nb[l];
         *bins_used += bg->nb[l];
         *rows_total += size;
     }
-    return bg->nbs > 0;
+    for (uint32_t l = max_level; l < SN_MAX_LEVELS; ++l) bg->boff[l + 1] = bg->boff[max_level];
+    return bg->boff[max_level] > 0;
 }
 
 struct BinLayout {
-    size_t counts, cursor, hdr, items, shared_bins, ekey, econtrib, slabs, total;
+    size_t counts, cursor, hdr, block_sums, items, shared_bins, ekey, econtrib, slabs, total;
     uint32_t max_items, max_shared_bins, total_bins;
 };
 
 // worst-case sizes: items <= n / E_CAP + bins; split bins <= n / E_CAP; slab floats <= 2 x the table's floats (a split
 // bin's items hold >= E_CAP entries each, and rows per bin <= E_CAP / (2 density))
-static BinLayout bin_layout(uint64_t n, uint32_t C, uint32_t levels, uint32_t nbs, uint64_t bins_used, uint64_t rows_total) {
+static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t rows_total) {
     BinLayout l;
     const uint32_t cap = e_cap(C);
-    l.total_bins = levels * nbs;
+    l.total_bins = (uint32_t)bins_used;
     l.max_items = (uint32_t)(n / cap + bins_used + 1);
     l.max_shared_bins = (uint32_t)(n / cap + 1);
     size_t o = 0;
     l.counts = o; o += align256((size_t)l.total_bins * 4);
     l.cursor = o; o += align256((size_t)l.total_bins * 4);
     l.hdr = o; o += 256;
+    l.block_sums = o; o += align256((size_t)(l.total_bins / (PLAN_THREADS * 8u) + 1) * 5 * 4);
     l.items = o; o += align256((size_t)l.max_items * sizeof(BinItem));
     l.shared_bins = o; o += align256((size_t)l.max_shared_bins * sizeof(BinShared));
     l.ekey = o; o += align256((size_t)n * 2);
@@ -449,7 +560,7 @@ size_t sn_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t 
     uint64_t bins_used = 0, rows_total = 0;
     if (!bin_geometry(&bg, offsets_host, B, D, C, max_level, &bins_used, &rows_total)) return 0;   // a level beyond 4096 bins of 4096 rows: use the atomic path
     if (2 * rows_total * C + 2 * (uint64_t)BIN_FLOATS >= (1ull << 32)) return 0;                      // slab offsets are 32-bit
-    return bin_layout(n, C, max_level, bg.nbs, bins_used, rows_total).total;
+    return bin_layout(n, C, bins_used, rows_total).total;
 }
 
 int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
@@ -474,7 +585,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
                   BIN_MAX_PER_LEVEL, BIN_ROWS_MAX);
         return SN_ERR_UNSUPPORTED;
     }
-    const BinLayout lay = bin_layout(n64, C, max_level, bg.nbs, bins_used, rows_total);
+    const BinLayout lay = bin_layout(n64, C, bins_used, rows_total);
     SN_REQUIRE(table_aligned(grad) && table_aligned(workspace), "grid_encode_backward_binned: grad / workspace must be 16-byte aligned");
     if (workspace_bytes < lay.total) { set_error("grid_encode_backward_binned: workspace too small (%zu bytes, need %zu)", workspace_bytes, lay.total); return SN_ERR_WORKSPACE; }
     char *w = reinterpret_cast<char *>(workspace);
@@ -490,7 +601,10 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     if (D == 3) hipLaunchKernelGGL((k_bin_count<3>), gs, blk, 0, st, inputs, B, g, bg, counts);
     else hipLaunchKernelGGL((k_bin_count<2>), gs, blk, 0, st, inputs, B, g, bg, counts);
     SN_LAUNCH_CHECK("k_bin_count");
-    hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(PLAN_THREADS), 0, st, counts, cursor, lay.total_bins, hdr, items, shared_bins, bg);
+    uint32_t *block_sums = reinterpret_cast<uint32_t *>(w + lay.block_sums);
+    const dim3 gp(div_up(lay.total_bins, PLAN_BLOCK_BINS));
+    hipLaunchKernelGGL(k_bin_plan_sums, gp, dim3(PLAN_THREADS), 0, st, counts, lay.total_bins, bg, block_sums);
+    hipLaunchKernelGGL(k_bin_plan_emit, gp, dim3(PLAN_THREADS), 0, st, counts, cursor, lay.total_bins, block_sums, hdr, items, shared_bins, bg);
     SN_LAUNCH_CHECK("k_bin_plan");
     const size_t lds = (size_t)(BIN_ROWS_MAX + BIN_FLOATS) * sizeof(float);      // 80 KiB: two workgroups per CU
     const dim3 ga(lay.max_items), gm(lay.max_shared_bins < 2048u ? lay.max_shared_bins : 2048u);
@@ -498,7 +612,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     do {                                                                                                                         \
         hipLaunchKernelGGL((k_bin_scatter<DD, CC>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, ekey, econtrib);     \
         SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accum<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_bin_accum<CC>), ga, blk, lds, st, hdr, items, g, bg, ekey, econtrib, slabs, grad_embeddings);      \
+        hipLaunchKernelGGL((k_bin_accum<CC>), ga, blk, lds, st, hdr, items, shared_bins, g, bg, ekey, econtrib, slabs, grad_embeddings);      \
         hipLaunchKernelGGL((k_bin_merge<CC>), gm, blk, 0, st, hdr, shared_bins, g, bg, slabs, grad_embeddings);                  \
     } while (0)
 #define SN_BIN_D(DD)                                                                                                             \

@@ -240,8 +240,8 @@ def main():
     def rgb_step():
         rgb_fwd_bwd()
         optim.step()
-    t_fb = timeit(rgb_fwd_bwd)
-    t_st = timeit(rgb_step)
+    t_fb = min(timeit(rgb_fwd_bwd) for _ in range(3))      # (the first measurement after construction allocates workspaces: 10+ ms)
+    t_st = min(timeit(rgb_step) for _ in range(2))
     out["RGB_training_step_4096_rays"] = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "fwd_bwd_adam_ms": round(t_st * 1e3, 3),
                                           "rays_per_s_step": round(N / t_st, 1)}
     # trainer.py:372-373: after step 3000 the proposal networks are updated on every 5th step only; the other four run this:

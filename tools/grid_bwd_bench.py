@@ -19,12 +19,19 @@ dev = torch.device("cuda:0")
 CASES = [("mask / SAM grid  C=8 L=16 T=2^19, 4096 rays x 32", dict(L=16, C=8, log2T=19, desired=512), 4096, 32),
          ("main grid        C=2 L=16 T=2^19, 4096 rays x 32", dict(L=16, C=2, log2T=19, desired=4096), 4096, 32),
          ("proposal grid 0  C=2 L=5  T=2^17, 4096 rays x 128", dict(L=5, C=2, log2T=17, desired=128), 4096, 128),
-         ("proposal grid 1  C=2 L=5  T=2^17, 4096 rays x 64", dict(L=5, C=2, log2T=17, desired=256), 4096, 64)]
+         ("proposal grid 1  C=2 L=5  T=2^17, 4096 rays x 64", dict(L=5, C=2, log2T=17, desired=256), 4096, 64),
+         ("mask grid, samples piled near a surface (a trained field's last stage)", dict(L=16, C=8, log2T=19, desired=512, surface=True), 4096, 32)]
 for name, cfg, R, T in CASES:
     rng = np.random.default_rng(3)
     offs, pls = orc.grid_layout(3, cfg["L"], cfg["C"], 2, 16, cfg["log2T"], cfg["desired"])
     o = rng.uniform(0.1, 0.9, (R, 1, 3)); d = rng.normal(size=(R, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
     t = np.sort(rng.uniform(-0.5, 0.5, (R, T, 1)), axis=1)
+    if cfg.pop("surface", False):          # rays from one side onto a sphere of radius 0.2: 32 samples within +-0.01 of the hit
+        o = np.array([0.5, 0.5, 0.02]) + rng.normal(0, 0.002, (R, 1, 3)); tgt = np.array([0.5, 0.5, 0.5]) + rng.uniform(-0.18, 0.18, (R, 1, 3)); tgt[..., 2] = 0.5
+        d = tgt - o; d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        bq = np.sum((o - 0.5) * d, -1, keepdims=True); cq = np.sum((o - 0.5) ** 2, -1, keepdims=True) - 0.04
+        th = -bq - np.sqrt(np.maximum(bq * bq - cq, 0.0))
+        t = th + np.sort(rng.normal(0, 0.004, (R, T, 1)), axis=1)
     x = np.clip(o + d * t, 0.0, 1.0).reshape(-1, 3).astype(np.float32)
     B = x.shape[0]
     xt = torch.from_numpy(x).to(dev)
