@@ -177,6 +177,12 @@ int sn_rm_proposal_loss(const float *bins, const float *weights, const float *re
 int sn_rm_distort_loss(const float *bins, const float *weights, uint32_t N, uint32_t T, float *loss_per_ray, float *grad_weights,
                        sn_stream_t stream);
 
+/* Mask-field NLL per ray (nerf/trainer.py:419-428): loss_per_ray[n] = -log(clamp(softmax(logits[n, :])[labels[n]], eps, 1 - eps)) -- the
+ * reference's `loss` before its .mean() -- and, when grad_logits != NULL, d loss_per_ray[n] / d logits[n, :] in the same pass (zero where
+ * the clamp binds, like torch.clamp's backward).  logits [N,K] f32, labels [N] int64 (a label outside 0..K-1: loss 0, no gradient). */
+int sn_rm_mask_nll(const float *logits, const int64_t *labels, uint32_t N, uint32_t K, float eps, float *loss_per_ray, float *grad_logits,
+                   sn_stream_t stream);
+
 /* One stage's sample geometry (renderer.py:277-285): bins [N,T+1] in [0,1] -> real_bins [N,T+1] (distances along the
  * ray through the Mip-360 spacing of nears/fars [N]), rays_t [N,T] (mid-points), xyzs [N,T,3] (positions, contracted
  * into [-2,2]^3 like sn_rm_contract if `contract`).  Nothing here is differentiated by the reference. */
@@ -387,7 +393,9 @@ int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uin
  * exp_avg_sq = beta2 * exp_avg_sq + (1-beta2) g^2; param -= lr / (1-beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1-beta2^step) + eps)
  * -- with 16-byte accesses, 4 streams read and 3 written.  Same dense semantics (untouched rows keep moving by their
  * momentum); elements whose gradient and both moments are exactly zero are skipped (their update is exactly zero).
- * Hyper-parameters are doubles like the Python floats torch derives its scalars from.  step counts from 1.
+ * Hyper-parameters are doubles like the Python floats torch derives its scalars from.  step counts from 1.  step_device != NULL
+ * (capturable form, like torch.optim.Adam(capturable=True)): the count is read from that device float when the kernel RUNS and `step` is
+ * ignored, so that the launch can be captured in a HIP graph and replayed.
  * flags: SN_ADAM_ZERO_GRAD -- the gradient is cleared in the same pass (for callers that accumulate in place);
  *        SN_ADAM_LAZY -- opt-in touched-elements-only update (NOT the reference's optimiser): an element whose gradient
  *        is exactly zero in this step is skipped altogether (moments do not decay, the parameter does not move) -- the semantics of
@@ -395,7 +403,7 @@ int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint32_t K, uin
 #define SN_ADAM_ZERO_GRAD 1
 #define SN_ADAM_LAZY 2
 int sn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, double lr, double beta1, double beta2,
-                 double eps, double weight_decay, uint32_t step, int maximize, int flags, sn_stream_t stream);
+                 double eps, double weight_decay, uint32_t step, const float *step_device, int maximize, int flags, sn_stream_t stream);
 
 /* Measurement hook (bench.py): bracket every kernel sn_rm_render_rays launches with hipEvents on the
  * caller's stream.  Classes: 0 weight pack, 1..3 proposal stage k, 4 final stage.  profile_read

@@ -112,7 +112,7 @@ _SIGNATURES = {
     "sn_mlp_wide_backward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _u32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_mask_head_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "sn_rm_mask_head": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _f32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _vp, _vp, C.c_size_t, _vp]),
-    "sn_adam_step": (_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _u32, _int, _int, _vp]),
+    "sn_adam_step": (_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _u32, _vp, _int, _int, _vp]),
     "sn_linear_wgrad_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32]),
     "sn_linear_wgrad": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_render_workspace_bytes": (C.c_size_t, [C.POINTER(RenderCfg), _u32, _u32]),
@@ -120,6 +120,7 @@ _SIGNATURES = {
     "sn_rm_profile_enable": (None, [_int]),
     "sn_rm_profile_read": (_int, [_vp, _vp, _int]),
     "sn_rm_profile_shader_clock": (_int, [_vp, _vp]),
+    "sn_rm_mask_nll": (_int, [_vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp]),
     "sn_rm_debug_occupancy": (_int, [_vp, _vp, _int]),
     "sn_rm_last_launch_info": (_int, [_vp]),
     "sn_debug_eval": (_int, [_int, _vp, _vp, _u32, _vp, _vp]),

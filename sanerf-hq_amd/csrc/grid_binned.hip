@@ -90,6 +90,11 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
     return true;
 }
 
+__global__ __launch_bounds__(256) void k_bin_zero(uint32_t *__restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 template <uint32_t D>
 __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inputs, uint32_t B, GridLevels g, BinGeom bg,
                                                    uint32_t *__restrict__ counts) {
@@ -596,7 +601,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     uint16_t *ekey = reinterpret_cast<uint16_t *>(w + lay.ekey);
     float *econtrib = reinterpret_cast<float *>(w + lay.econtrib), *slabs = reinterpret_cast<float *>(w + lay.slabs);
     hipStream_t st = (hipStream_t)stream;
-    SN_HIP_OK(hipMemsetAsync(counts, 0, (size_t)lay.total_bins * 4, st));
+    hipLaunchKernelGGL(k_bin_zero, dim3(div_up(lay.total_bins, 256u)), dim3(256), 0, st, counts, lay.total_bins);   // (a kernel, not hipMemsetAsync: one node type in a captured graph)
     const dim3 gs(div_up(B, 256u * SPT), max_level), blk(256);
     if (D == 3) hipLaunchKernelGGL((k_bin_count<3>), gs, blk, 0, st, inputs, B, g, bg, counts);
     else hipLaunchKernelGGL((k_bin_count<2>), gs, blk, 0, st, inputs, B, g, bg, counts);

@@ -23,6 +23,8 @@ struct AdamArgs {
     uint64_t n;
     float one_minus_beta1, beta2, one_minus_beta2, step_size, inv_bc2_sqrt, eps, weight_decay;
     int zero_grad, maximize, lazy;
+    const float *step_dev;        // capturable form: the step count lives on the device (a captured HIP graph replays this launch with other counts)
+    double lr, beta1_d, beta2_d;  // ... and the two bias corrections are formed from it in the kernel, in double like the host path
 };
 
 __device__ __forceinline__ bool adam_one(float &p, float g, float &m, float &v, const AdamArgs &a) {
@@ -39,6 +41,12 @@ __device__ __forceinline__ bool adam_one(float &p, float g, float &m, float &v, 
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     SN_POISON_ALL();
+    if (a.step_dev) {
+        const double step = (double)*a.step_dev;
+        const double bc1 = 1.0 - pow(a.beta1_d, step), bc2 = 1.0 - pow(a.beta2_d, step);
+        a.step_size = (float)(a.lr / bc1);
+        a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    }
     const uint64_t nq = a.n >> 2;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
@@ -69,16 +77,18 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 using namespace sn;
 
 extern "C" int sn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, double lr, double beta1, double beta2,
-                            double eps, double weight_decay, uint32_t step, int maximize, int flags, sn_stream_t stream) {
+                            double eps, double weight_decay, uint32_t step, const float *step_device, int maximize, int flags, sn_stream_t stream) {
     if (n == 0) return SN_OK;
     SN_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam_step: param/grad/exp_avg/exp_avg_sq must be device pointers");
     SN_REQUIRE(table_aligned(param) && table_aligned(grad) && table_aligned(exp_avg) && table_aligned(exp_avg_sq), "adam_step: tensors must be 16-byte aligned");
-    SN_REQUIRE(step >= 1, "adam_step: step counts from 1");
+    SN_REQUIRE(step >= 1 || step_device, "adam_step: step counts from 1");
     SN_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && lr >= 0.0 && eps >= 0.0, "adam_step: invalid hyper-parameters");
     // scalars exactly as torch/optim/adam.py computes them: Python doubles (hence double arguments: 1 - beta2 formed from a
     // float beta2 is off by 1e-5 relative), rounded to fp32 where they meet the tensors
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double hstep = step_device ? 1.0 : (double)step;             // (device step: the kernel recomputes both corrections)
+    const double bc1 = 1.0 - pow(beta1, hstep), bc2 = 1.0 - pow(beta2, hstep);
     AdamArgs a;
+    a.step_dev = step_device; a.lr = lr; a.beta1_d = beta1; a.beta2_d = beta2;
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
     a.one_minus_beta1 = (float)(1.0 - beta1);
     a.beta2 = (float)beta2;

@@ -504,6 +504,35 @@ __global__ __launch_bounds__(256) void k_composite_backward(const float *__restr
     grad_values[t] = weights[nt] * grad_out[(size_t)n * K + k];
 }
 
+
+// Mask-field NLL of one ray (nerf/trainer.py:419-428): p = softmax(logits); c = clamp(p[label], eps, 1 - eps); loss = -log(c).
+// One lane per ray, K <= 32 logits in registers; value and d loss / d logits in one pass (the clamp passes no gradient where it binds, as
+// torch.clamp's backward).  Replaces softmax -> clamp -> gather -> log -> neg and their five backward kernels.
+__global__ __launch_bounds__(256) void k_mask_nll(const float *__restrict__ logits, const int64_t *__restrict__ labels, uint32_t N, uint32_t K, float eps,
+                                                  float *__restrict__ loss, float *__restrict__ grad_logits) {
+    SN_POISON_ALL();
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *row = logits + (size_t)n * K;
+    float mx = row[0];
+    for (uint32_t k = 1; k < K; ++k) mx = fmaxf(mx, row[k]);
+    float sum = 0.0f;
+    for (uint32_t k = 0; k < K; ++k) sum += expf(row[k] - mx);           // torch's softmax: exp(x - max) / sum
+    const int64_t y = labels[n];
+    const bool valid = y >= 0 && y < (int64_t)K;
+    const float py = valid ? expf(row[(uint32_t)y] - mx) / sum : 1.0f;
+    const float c = fminf(fmaxf(py, eps), 1.0f - eps);
+    loss[n] = valid ? -logf(c) : 0.0f;
+    if (grad_logits) {
+        const bool pass = valid && py >= eps && py <= 1.0f - eps;         // clamp backward: gradient where min <= x <= max
+        const float g = pass ? -1.0f / c : 0.0f;                           // d loss / d p_y
+        for (uint32_t k = 0; k < K; ++k) {
+            const float pk = expf(row[k] - mx) / sum;
+            grad_logits[(size_t)n * K + k] = g * py * ((k == (uint32_t)y ? 1.0f : 0.0f) - pk);    // softmax backward for a one-hot upstream
+        }
+    }
+}
+
 }  // namespace sn
 
 using namespace sn;
@@ -661,6 +690,16 @@ int sn_rm_composite_backward(const float *weights, const float *grad_out, uint32
     if (N == 0 || K == 0 || T == 0) return SN_OK;
     hipLaunchKernelGGL(k_composite_backward, dim3(div_up((uint64_t)N * T * K, 256)), dim3(256), 0, (hipStream_t)stream, weights, grad_out, N, T, K, grad_values);
     SN_LAUNCH_CHECK("k_composite_backward");
+    return SN_OK;
+}
+
+int sn_rm_mask_nll(const float *logits, const int64_t *labels, uint32_t N, uint32_t K, float eps, float *loss_per_ray, float *grad_logits,
+                   sn_stream_t stream) {
+    SN_REQUIRE(logits && labels && loss_per_ray, "mask_nll: NULL pointer");
+    SN_REQUIRE(K >= 1, "mask_nll: at least one instance logit");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_mask_nll, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, logits, labels, N, K, eps, loss_per_ray, grad_logits);
+    SN_LAUNCH_CHECK("k_mask_nll");
     return SN_OK;
 }
 

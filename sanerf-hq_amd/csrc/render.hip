@@ -1498,7 +1498,7 @@ __device__ __forceinline__ uint32_t slab_dword(uint32_t row, uint32_t d) {
 // level-major launch, gridencoder.cu:383-399).  The coarsest level of the main grid is 16^3 vertices = 16 KiB of fp16 rows: every
 // workgroup stages it once and its 2 x 128 samples per lane read their 8 corners with ds_read_b32 instead of two 16-byte gathers
 // through the texture path (98 -> 96 gather instructions per wave-sample).  Arithmetic as issue_level_lv's dense branch.
-constexpr int L0_MAX_ROWS = 4096;
+[[maybe_unused]] constexpr int L0_MAX_ROWS = 4096;   // (used by experiments builds only)
 template <int l>
 __device__ __forceinline__ void issue_level0_lds(const FinalLv &lv, const uint32_t *__restrict__ l0tab, const float (&x01)[3], float (&pos)[3],
                                                  Corner<__half, 2> (&cv)[8]) {

@@ -305,6 +305,35 @@ def distort_loss(bins, weights):
     return _distort_loss.apply(bins, weights)
 
 
+class _mask_nll(Function):
+    """-log(clamp(softmax(logits)[label], eps, 1 - eps)) per ray, value and gradient in one kernel (sn_rm_mask_nll)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, eps):
+        shape = logits.shape[:-1]
+        lg = logits.reshape(-1, logits.shape[-1]).contiguous().float()
+        lb = labels.reshape(-1).contiguous().long()
+        N, K = lg.shape
+        loss = torch.empty(N, device=lg.device, dtype=torch.float32)
+        grad = torch.empty_like(lg) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.lib().sn_rm_mask_nll(_lib.dev(lg, "logits"), _lib.dev(lb, "labels", torch.int64), N, K, float(eps), _lib.dev(loss, "loss"),
+                                             _lib.dev(grad, "grad_logits"), _lib.stream()), "mask_nll")
+        ctx.save_for_backward(grad)
+        ctx.lshape = logits.shape
+        return loss.view(*shape, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return (grad * grad_out.reshape(-1, 1)).view(ctx.lshape), None, None
+
+
+def mask_nll(logits, labels, eps: float = 1e-6):
+    """The mask-field training loss of nerf/trainer.py:419-428, per ray: logits [..., n_inst], labels [...] (int) ->
+    [..., 1] = -log(gather(clamp(softmax(logits, -1), eps, 1 - eps), -1, labels[..., None])); the trainer takes its .mean()."""
+    return _mask_nll.apply(logits, labels, eps)
+
+
 class _composite(Function):
     """out[n,k] = sum_t w[n,t] * v[n,t,k]."""
 

@@ -143,8 +143,7 @@ def c5_entry(dev, warm=3, iters=10, optimisers=True):
     def fwd_bwd():
         optim.zero_grad(set_to_none=True)
         o = model.render(ro, rd, staged=False, bg_color=1, perturb=False, update_proposal=False, return_mask=1)
-        pm = torch.softmax(o["instance_mask_logits"], dim=-1).clamp(min=1e-6, max=1 - 1e-6)
-        loss = (-torch.log(torch.gather(pm, -1, labels[..., None]))).mean()
+        loss = rm.mask_nll(o["instance_mask_logits"], labels, 1e-6).mean()     # trainer.py:419-428 in one kernel (fwd) + one multiply (bwd)
         loss.backward()
         return loss
 
@@ -154,6 +153,13 @@ def c5_entry(dev, warm=3, iters=10, optimisers=True):
     t_fb = timeit(fwd_bwd, warm, iters)
     out = {"fwd_bwd_ms": round(t_fb * 1e3, 3), "rays_per_s_fwd_bwd": round(N / t_fb, 1),
            "fwd_bwd_single_pass_adam_ms": round(timeit(step, warm, iters) * 1e3, 3)}
+    # the whole step (zero_grad, render, loss, backward, Adam) captured once as a HIP graph and replayed (sanerf_hq_amd.graph)
+    from sanerf_hq_amd.graph import GraphedStep
+    optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15, capturable=True)
+    g = GraphedStep(step, warmup=3)
+    out["step_as_hip_graph_ms"] = round(timeit(g, warm, iters) * 1e3, 3)
+    del g
+    optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
     if optimisers:
         optim = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
         out["fwd_bwd_adam_ms"] = round(timeit(step, warm, iters) * 1e3, 3)
@@ -258,6 +264,15 @@ def main():
     opt.lambda_distort = 0.0
     optim = HipAdam(model.get_params(1e-2), eps=1e-15)             # csrc/optim.hip: one pass per tensor
     out["RGB_training_step_4096_rays"]["fwd_bwd_single_pass_adam_ms"] = round(best(rgb_step) * 1e3, 3)
+    try:   # the whole step as one HIP graph (capturable Adam; perturb=True draws its jitter inside the graph)
+        from sanerf_hq_amd.graph import GraphedStep
+        optim = HipAdam(model.get_params(1e-2), eps=1e-15, capturable=True)
+        g = GraphedStep(rgb_step, warmup=3)
+        out["RGB_training_step_4096_rays"]["step_as_hip_graph_ms"] = round(best(g) * 1e3, 3)
+        del g
+    except Exception as e:   # noqa: BLE001
+        out["RGB_training_step_4096_rays"]["step_as_hip_graph_ms"] = f"failed: {type(e).__name__}: {e}"
+    optim = HipAdam(model.get_params(1e-2), eps=1e-15)
     try:   # torch's single-kernel Adam (same update rule; the reference constructs the default multi-tensor one)
         optim = torch.optim.Adam(model.get_params(1e-2), eps=1e-15, fused=True)
         out["RGB_training_step_4096_rays"]["fwd_bwd_fused_adam_ms"] = round(best(rgb_step) * 1e3, 3)
