@@ -1225,20 +1225,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         const uint32_t level = umin(2u * kx + half, a.g.L - 1u);
         const uint32_t res = lds_lv[level], size = lds_lv[SN_MAX_LEVELS + level], mode = lds_lv[2 * SN_MAX_LEVELS + level];
         const uint32_t base = lds_lv[3 * SN_MAX_LEVELS + level];
-        float pos[3], deriv[3];
-        uint32_t cell[3];
-        grid_locate<3>(x01, res, a.g.align_corners != 0, a.g.interp, pos, deriv, cell);
-        const float *tabh = a.table + 4u * half;                        // this lane's half of every row
+        // Addresses without branches (round 4): the host admits only grids of the fast-path shape (levels_fast: hashed levels of power-of-two
+        // size, dense levels over all three dimensions, align_corners = False, linear interpolation), so the 8 row offsets are 6 partial
+        // terms combined by xor / add (corner_offsets, as in the fused render stages) instead of 8 calls of the generic grid_row, whose
+        // hash / dense / modulo branches diverge between the half-waves (they work on different levels): ~560 -> ~90 vector instructions
+        // per k-step and no basic-block boundaries between the gathers.  Same rows, same weights ((wx wy) wz).
+        float pos[3];
+        uint32_t cell[3], offs[8];
+        locate_linear(x01, res, pos, cell);
+        corner_offsets<-1, 32u>(cell, res, size, mode, offs);           // bytes from the level's first row
+        const float wx[2] = {1.0f - pos[0], pos[0]}, wy[2] = {1.0f - pos[1], pos[1]}, wz[2] = {1.0f - pos[2], pos[2]};
+        const float wxy[4] = {wx[0] * wy[0], wx[1] * wy[0], wx[0] * wy[1], wx[1] * wy[1]};
+        const char *tabh = reinterpret_cast<const char *>(a.table) + 16u * half;                         // this lane's half of every row
 #pragma unroll
         for (uint32_t idx = 0; idx < 8u; ++idx) {
-            uint32_t q[3];
-            float w = 1.0f;
-#pragma unroll
-            for (uint32_t d = 0; d < 3u; ++d) {                            // weights as k_mlp_wide's blend_level forms them (grid.hip:k_grid_forward)
-                q[d] = (idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
-                w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
-            }
-            const uint32_t off = (base + grid_row<3>(q, res, size, mode)) * 8u;     // floats from the table's start (< 2^32: checked on the host)
+            const float w = wxy[idx & 3u] * wz[idx >> 2];
+            const uint32_t off = base * 32u + offs[idx];                  // bytes from the table's start (< 2^32: checked on the host)
             const auto po = __builtin_amdgcn_permlane32_swap(off, off, false, false);                                   // [A | A], [B | B]
             const auto pw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
             r.wA[idx] = __uint_as_float(pw[0]); r.wB[idx] = __uint_as_float(pw[1]);
@@ -1788,7 +1790,11 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     const uint32_t rows = (uint32_t)rows64, width = mlp->dims[0];
     hipStream_t st = (hipStream_t)stream;
     pa.din = width; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0;
-    const bool jit3 = wide_jit(3) && T >= 4u;       // (T is a power of two: the ray-major tiling needs 4 samples of a ray per tile)
+    GridLevels gl_probe;
+    rc = build_grid_levels(&gl_probe, grid->offsets, grid->D, grid->C, grid->L, grid->S, grid->H, grid->gridtype, (int)grid->align_corners, grid->interp);
+    if (rc) return rc;
+    // (T is a power of two: the ray-major tiling needs 4 samples of a ray per tile; its branch-free addressing needs the fast-path grid shape)
+    const bool jit3 = wide_jit(3) && T >= 4u && levels_fast(gl_probe) && (uint64_t)grid->offsets[grid->L] * 32u < (1ull << 32);
     pa.pair_ks = jit3 ? (grid->L + 1u) >> 1 : 0u;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
