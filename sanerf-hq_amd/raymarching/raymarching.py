@@ -605,6 +605,12 @@ class RenderPlan:
                           f"(>= {FP16_SPLIT_LIMIT:.0f}): using the exact fp32 matrix-core path instead of split-fp16")
         self.cfg.mlp_exact_fp32 = int(exact)
 
+    def invalidate_range(self) -> None:
+        """Forget the cached range-guard decision: the next render re-evaluates it.  For writers that change the field's parameters WITHOUT
+        moving their version counters -- `param.data.copy_()` (torch_ema's copy_to / restore around an evaluation, as the reference's trainer
+        uses it), raw-pointer writers, a load_state_dict into .data -- which check_range's (data_ptr, _version) key cannot see."""
+        self._range_versions = None
+
     @torch.no_grad()
     def refresh_tables(self) -> None:
         """Re-convert the table copies (render_table_dtype != the parameters' dtype) from the live parameters, in place:
