@@ -367,6 +367,9 @@ def main():
                                    "kernel_ms": {"final": round(r["final_ms"], 4),
                                                  "prop0": round(r["prop_ms"][0], 4) if r["prop_ms"][0] else None,
                                                  "prop1": round(r["prop_ms"][1], 4) if r["prop_ms"][1] else None}}
+            if r["final_launches"] > max(3, args.steps // 2):     # (two row bands on two HIP streams, sn_render_tuning.band_streams)
+                also[f"{sch}_{tb}"]["kernel_ms_note"] = ("the image is rendered as two row bands on two HIP streams: kernel_ms are sums of spans that "
+                                                         "OVERLAP in time (their sum exceeds ms_per_step)")
         # BASELINE configs[3] at one GPU = the base of the N > 1 strong-scaling lines: 1600 x 1600 rays of the same view
         # (same field of view: rays twice as dense, neighbouring lanes share more table lines -> higher rays/s)
         H4 = 1600

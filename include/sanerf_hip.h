@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 7
+#define SN_ABI_VERSION 8
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -232,6 +232,11 @@ typedef struct sn_render_tuning {
                                   * 0 default (32768), < 0 never */
     int32_t final_sp_max_rays;   /* the same for the last stage (several lanes per ray, per-sample form): 0 default (16384), < 0 never */
     int32_t feat_levels;         /* levels per workgroup pass of the feature stage: 0 default (2), 1, 2 or 4 (bit-neutral) */
+    int32_t band_streams;        /* image mode, schedules with proposal stages: the image is rendered as two row bands whose kernels go to TWO HIP streams
+                                  * (the caller's and a library-owned one, forked and joined with events inside the call: capturable), so that
+                                  * the vector-ALU-bound proposal stages of one band overlap the texture-path-bound last stage of the other
+                                  * (bit-neutral): 0 automatic (>= 2048 workgroups: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 fp16;
+                                  * nothing to gain at 625), 1 never, 2 whenever the image has two bands of whole tile rows */
     int32_t experiment;          /* SN_EXP_*: variants that were built, verified bit-identical and measured SLOWER; honoured only by
                                   * a library built with -DSN_EXPERIMENTS (sn_build_flags), SN_ERR_UNSUPPORTED otherwise */
 } sn_render_tuning;

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -2973,6 +2975,68 @@ static size_t stage_scratch_floats(const sn_render_cfg *cfg, uint32_t Npad) {
     return f;
 }
 
+
+// Row bands on two streams (round 4, tuning.band_streams).  A schedule with proposal stages is three kernels of different character --
+// the proposal stages are bound by the vector ALU, the last stage by the texture path and the matrix cores -- that a single stream runs one
+// after the other, each with its own ramp and tail.  Rendered as TWO row bands on two streams the kernels of one band overlap those of the
+// other (measured through captured graphs, tools/band_streams_ab.py: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 ms fp16; 1600x1600
+// 14.76 -> 14.04 / 13.43 -> 12.98; nothing at 400x400, where the stages' latency floors decide).  Same kernels over sub-ranges of the tiles:
+// bit-identical images.  The second stream is owned by the library (one per device), forked from and joined to the caller's stream with
+// events inside the call, so the call stays asynchronous, ordered on the caller's stream and capturable into a HIP graph.
+struct BandPlan { uint32_t chunk, slots; };
+static BandPlan band_plan(const sn_render_cfg *cfg, uint32_t N, uint32_t W) {
+    BandPlan p;
+    p.chunk = chunk_rays(N, W);
+    p.slots = 1;
+    const int mode = cfg ? cfg->tuning.band_streams : 1;
+    if (mode == 1 || W == 0 || !cfg || cfg->num_stages < 2 || N % W != 0) return p;
+    if (mode == 0 && blocks_for(N, W) < 2048u) return p;
+    const uint32_t rows = N / W;
+    const uint32_t half_rows = ((rows / 2u + 15u) / 16u) * 16u;          // whole 16-row tile rows; the first band takes the odd one
+    if (half_rows == 0u || half_rows >= rows) return p;
+    const uint64_t c = (uint64_t)half_rows * W;
+    if (c < p.chunk) p.chunk = (uint32_t)c;                               // (images beyond the scratch cap keep its chunks and alternate them)
+    p.slots = 2;
+    return p;
+}
+
+static hipStream_t band_side_stream() {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(dev);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    streams[dev] = s;
+    return s;
+}
+
+// fork on construction (the side stream waits for everything the caller's stream holds so far), join on destruction -- on every path out
+// of sn_rm_render_rays, error returns included (an unjoined fork would invalidate a stream capture)
+struct BandFork {
+    hipStream_t main_st, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    BandFork(hipStream_t m, bool want) : main_st(m) {
+        if (!want) return;
+        hipStream_t s = band_side_stream();
+        if (!s) return;
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { ev_fork = nullptr; return; }
+        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ev_fork); ev_fork = ev_join = nullptr; return; }
+        if (hipEventRecord(ev_fork, main_st) != hipSuccess || hipStreamWaitEvent(s, ev_fork, 0) != hipSuccess) {
+            (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); ev_fork = ev_join = nullptr; return;
+        }
+        side = s;
+    }
+    ~BandFork() {
+        if (!side) return;
+        (void)hipEventRecord(ev_join, side);
+        (void)hipStreamWaitEvent(main_st, ev_join, 0);
+        (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join);      // (released by the runtime once the recorded work has passed)
+    }
+};
 }  // namespace sn
 
 using namespace sn;
@@ -3100,10 +3164,11 @@ static size_t pair_region_floats(const sn_render_cfg *cfg, uint64_t main_samples
 
 size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32_t tile_w) {
     if (!cfg || N == 0) return (size_t)PACK_FLOATS * sizeof(float);
-    const uint32_t nc = chunk_rays(N, tile_w);
+    const BandPlan bp = band_plan(cfg, N, tile_w);
+    const uint32_t nc = bp.chunk < N ? bp.chunk : N;
     const size_t npad = (size_t)blocks_for(nc, tile_w) * 256u;
     const uint64_t samples = (uint64_t)N * cfg->num_steps[cfg->num_stages ? cfg->num_stages - 1 : 0];
-    return (stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS + pair_region_floats(cfg, samples)) * sizeof(float);
+    return ((size_t)bp.slots * stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS + pair_region_floats(cfg, samples)) * sizeof(float);
 }
 
 int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_stream_t stream) {
@@ -3126,7 +3191,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     for (uint32_t k = 1; k < S; ++k)
         SN_REQUIRE(io->u_ray_stride[k] == 0 || (io->u_table[k] && io->u_ray_stride[k] >= cfg->num_steps[k] + 1u),
                    "render_rays: u_ray_stride[%u]=%u needs u_table[%u] and at least num_steps[%u]+1=%u values per ray", k, io->u_ray_stride[k], k, k, cfg->num_steps[k] + 1u);
-    hipStream_t st = (hipStream_t)stream;
+    const hipStream_t st_main = (hipStream_t)stream;
+    hipStream_t st = st_main;      // (the chunk loop below shadows it with the chunk's own stream when the image is rendered as bands on two streams)
 
     // ---- which kernel instantiations does this configuration map to? ----
     static const uint32_t d_prop[3] = {10, 16, 1};
@@ -3285,14 +3351,21 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                   build_final_lv(gl_main, 5, pairs, cfg->grid.embeddings, 2u * (cfg->grid.table_dtype == SN_F16 ? 2u : 4u), probe);
     }
     const uint32_t W = io->tile_w;
-    const uint32_t chunk = chunk_rays(io->N, W);
-    for (uint32_t first = 0; first < io->N; first += chunk) {
+    const BandPlan bplan = band_plan(cfg, io->N, W);
+    const uint32_t chunk = bplan.chunk;
+    // two bands on two streams: everything above (weight and pair packs) is on the caller's stream, the fork waits for it
+    BandFork fork(st_main, bplan.slots == 2u && chunk < io->N);
+    uint32_t chunk_index = 0;
+    for (uint32_t first = 0; first < io->N; first += chunk, ++chunk_index) {
         const uint32_t n = (io->N - first) < chunk ? (io->N - first) : chunk;
         const uint32_t nblk = blocks_for(n, W);
         const uint32_t Npad = nblk * 256u;
-        if (stage_scratch_floats(cfg, Npad) > scratch_floats_avail) {
+        const uint32_t slot = fork.side ? (chunk_index & 1u) : 0u;
+        hipStream_t st = slot ? fork.side : st_main;                        // shadows the function-level `st`: this chunk's kernels and profile spans
+        const size_t slot_floats = stage_scratch_floats(cfg, blocks_for(chunk < io->N ? chunk : io->N, W) * 256u);
+        if ((size_t)(fork.side ? 2u : 1u) * slot_floats > scratch_floats_avail || stage_scratch_floats(cfg, Npad) > slot_floats) {
             set_error("render_rays: workspace too small (%zu bytes, need %zu)", io->workspace_bytes,
-                      (stage_scratch_floats(cfg, Npad) + head_floats) * sizeof(float));
+                      ((size_t)bplan.slots * slot_floats + head_floats) * sizeof(float));
             return SN_ERR_WORKSPACE;
         }
         RayCommon rc;
@@ -3317,7 +3390,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
 
         // scratch carve-up
         float *w_scr[SN_MAX_STAGES] = {nullptr}, *b_scr[SN_MAX_STAGES] = {nullptr};
-        float *cur = scratch;
+        float *cur = scratch + (size_t)slot * slot_floats;                    // (bands in flight on two streams: a scratch region each)
         for (uint32_t k = 0; k + 1 < S; ++k) { w_scr[k] = cur; cur += (size_t)cfg->num_steps[k] * Npad; }
         for (uint32_t k = 1; k < S; ++k) { b_scr[k] = cur; cur += (size_t)(cfg->num_steps[k] + 1) * Npad; }
         if (cfg->with_feat) { w_scr[S - 1] = cur; cur += (size_t)cfg->num_steps[S - 1] * Npad; }

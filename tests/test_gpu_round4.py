@@ -243,3 +243,44 @@ def test_mask_training_step_replayed_as_a_hip_graph(gpu):
             # (tools/graph_vs_eager.py: Adam's normalisation amplifies last-bit differences of near-zero gradients); bound: one step of lr = 1e-3
             assert d <= 1e-3, (n1, d)
             assert float((p1 - p2).double().norm() / (p1.double().norm() + 1e-12)) <= 1e-4, n1
+
+
+@pytest.mark.parametrize("H,W,steps,f16,feat", [(72, 104, [128, 64, 32], True, False), (40, 64, [48, 24], False, False), (33, 40, [32, 16], True, False),
+                                                 (48, 48, [128, 64, 32], False, True)])
+def test_row_bands_on_two_streams_are_bit_identical(gpu, H, W, steps, f16, feat):
+    """tuning.band_streams: a schedule with proposal stages rendered as two row bands whose kernels go to two HIP streams (forked from and joined
+    to the caller's stream inside sn_rm_render_rays) -- every output, the per-stage tensors included, equals the single-stream render bit for
+    bit (forced on for small images here; automatic from 2048 workgroups); also with the in-render feature stage, and from inside a captured
+    HIP graph with allocator traffic between replays."""
+    from sanerf_hq_amd import raymarching as rm
+    params = synthetic_params(steps, heads=feat, seed=17)
+    model = product_model(params, steps, feat, gpu)
+    ro, rd = rm.generate_rays(__import__("sanerf_hq_amd").synth.orbit_pose(1.1, 15.0, 75.0), __import__("sanerf_hq_amd").synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    plan = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32, feat_encoder=model.s_grid if feat else None)
+    want = ("inds", "weights", "bins") if not feat else ()
+    one = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=want, tuning=rm.Tuning(band_streams=1)).items()}
+    two = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=want, tuning=rm.Tuning(band_streams=2), out={}).items()}
+    assert set(one) == set(two) and "image" in one
+    for k in one:
+        assert torch.equal(one[k], two[k]), k
+    # inside a captured graph: the fork and the join are part of the capture (no per-stage tensors here: the default linear-tail kernel)
+    plain = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, tuning=rm.Tuning(band_streams=1), out={}).items()}
+    out = {}
+    t2 = rm.Tuning(band_streams=2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        rm.render_rays(plan, ro, rd, tile_w=W, tuning=t2, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rm.render_rays(plan, ro, rd, tile_w=W, tuning=t2, out=out)
+    for _ in range(3):
+        out["image"].fill_(float("nan"))
+        g.replay()
+        junk = torch.full((1 << 20,), float("nan"), device=gpu)
+        del junk
+    torch.cuda.synchronize()
+    for k in plain:
+        assert torch.equal(out[k], plain[k]), k

@@ -29,8 +29,11 @@ for f16 in (False, True):
     base = rm.render_rays(plan, ro, rd, tile_w=W)["image"].clone()
     t1 = timeit(lambda: rm.render_rays(plan, ro, rd, tile_w=W))
     print(f"{H}x{W} {sch} {'f16' if f16 else 'f32'}: one call {t1:.3f} ms", flush=True)
-    for nb in (2, 3, 4, 5):
+    outs1 = {}
+    for nb, frac in ((2, None), (2, 0.4), (2, 0.3), (2, 0.6), (3, None), (4, None)):
         rows = [((H // 8) * i // nb) * 8 for i in range(nb + 1)]
+        if frac is not None:
+            rows[1] = int(H * frac) // 16 * 16
         rows[-1] = H
         plans = [rm.RenderPlan(model, sch, td) for _ in range(nb)]
         streams = [torch.cuda.Stream() for _ in range(nb)]
@@ -51,6 +54,23 @@ for f16 in (False, True):
             for i in range(nb):
                 cur.wait_stream(streams[i])
         ts, tp = timeit(seq), timeit(par)
+        # the same as captured HIP graphs (no host launch cost: what an in-library implementation could reach)
+        def graphed(fn):
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn(); fn()
+            torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            return g
+        try:
+            g1 = graphed(lambda: rm.render_rays(plan, ro, rd, tile_w=W, out=outs1))
+            gp = graphed(par)
+            tg1, tgp = timeit(g1.replay), timeit(gp.replay)
+            print(f"      as HIP graphs: one call {tg1:.3f} ms, {nb} bands on {nb} streams {tgp:.3f} ms", flush=True)
+        except Exception as e:  # noqa: BLE001
+            print("      graph capture failed:", type(e).__name__, str(e)[:200], flush=True)
         par(); torch.cuda.synchronize()
         img = torch.cat([o["image"] for o in outs])
         print(f"   {nb} bands {rows}: one stream {ts:.3f} ms, {nb} streams {tp:.3f} ms, max|d image| {float((img - base).abs().max()):.1e}", flush=True)
