@@ -236,7 +236,8 @@ typedef struct sn_render_tuning {
                                   * (the caller's and a library-owned one, forked and joined with events inside the call: capturable), so that
                                   * the vector-ALU-bound proposal stages of one band overlap the texture-path-bound last stage of the other
                                   * (bit-neutral): 0 automatic (>= 2048 workgroups: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 fp16;
-                                  * nothing to gain at 625), 1 never, 2 whenever the image has two bands of whole tile rows */
+                                  * >= 512 with the feature stage: 400x400 + SAM head 3.00 -> 2.82 ms), 1 never, 2 whenever the image has two bands
+                                  * of whole tile rows */
     int32_t experiment;          /* SN_EXP_*: variants that were built, verified bit-identical and measured SLOWER; honoured only by
                                   * a library built with -DSN_EXPERIMENTS (sn_build_flags), SN_ERR_UNSUPPORTED otherwise */
 } sn_render_tuning;

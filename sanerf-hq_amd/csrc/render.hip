@@ -2990,7 +2990,9 @@ static BandPlan band_plan(const sn_render_cfg *cfg, uint32_t N, uint32_t W) {
     p.slots = 1;
     const int mode = cfg ? cfg->tuning.band_streams : 1;
     if (mode == 1 || W == 0 || !cfg || cfg->num_stages < 2 || N % W != 0) return p;
-    if (mode == 0 && blocks_for(N, W) < 2048u) return p;
+    // automatic: from 2048 workgroups (800x800); with the in-render feature stage -- a fourth kernel, bound by the texture path alone -- from 512
+    // (400x400 + SAM-feature head, BASELINE configs[2]: 3.00 -> 2.82 ms, 2.58 -> 2.41 with fp16 tables; without it 400x400 gains nothing)
+    if (mode == 0 && blocks_for(N, W) < (cfg->with_feat ? 512u : 2048u)) return p;
     const uint32_t rows = N / W;
     const uint32_t half_rows = ((rows / 2u + 15u) / 16u) * 16u;          // whole 16-row tile rows; the first band takes the odd one
     if (half_rows == 0u || half_rows >= rows) return p;
