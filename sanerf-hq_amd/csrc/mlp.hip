@@ -924,7 +924,9 @@ __device__ __forceinline__ void dma16x4(const void *gptr, uint32_t lds_byte_offs
                  "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" : : "v"(gptr), "s"(base) : "memory");
 }
 
-template <int XMODE>
+template <int XMODE, bool N1 = false>      // N1: the narrow last layer has <= 32 outputs -- ONE output tile per k-step instead of the padded pair (fused mask head:
+                                           // n_inst = 2; a template so that the two forms of the layer are never both in one kernel: accumulators that meet at a
+                                           // control-flow merge get copied wholesale)
 __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     SN_POISON_ALL();
     static_assert(XMODE >= 0 && XMODE <= 3, "the backward mode keeps k_mlp_wide");
@@ -1340,6 +1342,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         const WideLayer L = a.layer[l];
         if (tile == 0u) wide_trace(128u + l);
         if (L.narrow) {
+            {
             // last layer with <= 64 outputs: 4 chunks of 4 k-steps x 1 tile pair (k_pack_mlp_wide); the operand of k-step k+1 is split
             // between the six MFMAs of k-step k.  Tiles 6 and 7 of the previous layer leave the accumulators first.
             escape_tile(int_tag<6>{}); escape_tile(int_tag<7>{});
@@ -1355,7 +1358,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
                     constexpr int sl = decltype(slc)::value, k = 4 * c + sl, cb = sl & 1, nb = cb ^ 1;
                     if constexpr (sl < 3) {
                         ah[nb][0] = buf[(sl + 1) * 256]; al[nb][0] = buf[(sl + 1) * 256 + 64];
-                        ah[nb][1] = buf[(sl + 1) * 256 + 128]; al[nb][1] = buf[(sl + 1) * 256 + 192];
+                        if constexpr (!N1) { ah[nb][1] = buf[(sl + 1) * 256 + 128]; al[nb][1] = buf[(sl + 1) * 256 + 192]; }
                     } else {
                         if (g + 1u < total_chunks) sync_and_prefetch(g + 1u, int_tag<0>{});
                         __builtin_amdgcn_sched_barrier(0);
@@ -1365,18 +1368,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
                     const half8_t A1h = __builtin_bit_cast(half8_t, ah[cb][1]), A1l = __builtin_bit_cast(half8_t, al[cb][1]);
                     const half8_t Bh = __builtin_bit_cast(half8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                     const half8_t Bl = __builtin_bit_cast(half8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                    if constexpr (N1) {       // <= 32 outputs: tile 1 is padding (c1 keeps its zero bias; its weight rows are never read)
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+                    } else {
                     c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
                     c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
                     c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
                     c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
                     c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
                     c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+                    }
                     if constexpr (k + 1 < WIDE_HKS) static_for<4>([&](auto pc) { h_piece(int_tag<k + 1>{}, pc, nbh, nbl); });
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
+                    for (int i = 0; i < (N1 ? 3 : 6); ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+                        if (i < (N1 ? 2 : 4)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, N1 ? 2 * SN_WIDE_JV : SN_WIDE_JV, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1387,6 +1396,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
                 ++g;
             });
             acc[0] = c0; acc[1] = c1;
+            }
         } else {
             const bool has_x = L.x_ks != 0u;
             static_for<WIDE_HKS>([&](auto kc) {
@@ -1538,15 +1548,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 // the backward-data pass is k_mlp_wide<4>.)
 #ifdef SN_EXPERIMENTS
 static int g_wide_jit = 1;
+static int g_wide_narrow1 = 1;       // sn_debug_set("wide_narrow1", 0): the fused mask head's last layer as a padded tile PAIR as before (A/B)
 static bool wide_jit(int xmode) { (void)xmode; return g_wide_jit != 0; }
 #else
 static constexpr bool wide_jit(int) { return true; }
+static constexpr int g_wide_narrow1 = 1;
 #endif
 
 extern "C" int sn_debug_set(const char *key, int value) {
     SN_REQUIRE(key, "debug_set: NULL key");
 #ifdef SN_EXPERIMENTS
     if (strcmp(key, "wide_jit") == 0) { g_wide_jit = value; return SN_OK; }
+    if (strcmp(key, "wide_narrow1") == 0) { g_wide_narrow1 = value; return SN_OK; }
     set_error("debug_set: unknown key '%s'", key);
     return SN_ERR_INVALID;
 #else
@@ -1811,6 +1824,8 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     wa.out = out; wa.pack = pa.pack;
     wa.N = rows; wa.din = width; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
     for (uint32_t l = 0; l < nl; ++l) { wa.bias[l] = mlp->bias[l]; wa.layer[l] = pa.layer[l]; }
+    // <= 32 outputs (the reference's n_inst = 2): the narrow last layer multiplies ONE output tile per k-step instead of the padded pair
+    const bool narrow1 = jit3 && nl >= 2u && pa.layer[nl - 1u].narrow != 0u && mlp->dims[nl] <= 32u && g_wide_narrow1 != 0;
     wa.xyz = xyzs; wa.extra = extra; wa.wts = weights; wa.table = reinterpret_cast<const float *>(grid->embeddings);
     wa.T = T; wa.E = E; wa.bound = bound;
     {
@@ -1822,8 +1837,13 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     if (rc) return rc;
     const size_t lds = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 4u * SN_MAX_LEVELS * sizeof(uint32_t);
     if (jit3) {          // a workgroup = 32 consecutive rays, all their samples (T / 4 tiles of 128 rows)
-        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mlp_wide_j<3>, dim3(div_up(N, 32u)), dim3(256), lds, st, wa);
+        if (narrow1) {
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_mlp_wide_j<3, true>), dim3(div_up(N, 32u)), dim3(256), lds, st, wa);
+        } else {
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_mlp_wide_j<3>, dim3(div_up(N, 32u)), dim3(256), lds, st, wa);
+        }
     } else {
         SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_mlp_wide<3>, dim3(div_up(rows, WIDE_ROWS)), dim3(256), lds, st, wa);
