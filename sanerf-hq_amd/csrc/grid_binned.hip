@@ -59,7 +59,10 @@ struct BinItem { uint32_t level_bin, begin, end, slab_off; };   // slab_off = fi
 struct BinShared { uint32_t level_bin, slab_off, n_slabs, item0, begin, end, pad0, pad1; };   // a split bin: n_slabs items (first one = item item0 of the work list) of E_CAP
                                                                                             // entries each over [begin, end); slabs consecutive: slab_off + k * (rows per bin * C)
 
-template <uint32_t D>
+// FAST (D = 3, grids of the fused kernels' shape -- levels_fast(): hashed levels of power-of-two size, dense levels over all three dimensions,
+// align_corners = False, linear interpolation): the 8 rows come from 6 partial terms (corner_offsets: 2 full-rate 24-bit multiplies per
+// level) instead of 8 calls of the generic grid_row (7 quarter-rate v_mul_lo_u32 per corner: 56 per sample-level).  Same rows, same weights.
+template <uint32_t D, bool FAST>
 __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint32_t b, const GridLevels &g, uint32_t level,
                                           uint32_t (&row)[1u << D], float (&w)[1u << D]) {
     float x01[D];
@@ -71,6 +74,17 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
     }
     if (oob) return false;                                        // gridencoder.cu:290: no gradient outside [0,1]
     const uint32_t res = g.res[level], size = g.size[level], mode = g.mode[level];
+    if constexpr (FAST && D == 3) {
+        float pos[3];
+        uint32_t cell[3];
+        locate_linear(x01, res, pos, cell);
+        if (mode & 1u) corner_offsets<1, 1u>(cell, res, size, mode, row);          // (the level is the block's: a uniform branch)
+        else corner_offsets<0, 1u>(cell, res, size, mode, row);
+        const float wx[2] = {1.0f - pos[0], pos[0]}, wy[2] = {1.0f - pos[1], pos[1]}, wz[2] = {1.0f - pos[2], pos[2]};
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8u; ++idx) w[idx] = (wx[idx & 1u] * wy[(idx >> 1) & 1u]) * wz[idx >> 2];     // gridencoder.cu:315-327: ((1 wx) wy) wz
+        return true;
+    } else {
     float pos[D], deriv[D];
     uint32_t cell[D];
     grid_locate<D>(x01, res, g.align_corners != 0, g.interp, pos, deriv, cell);
@@ -88,6 +102,7 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
         w[idx] = ww;
     }
     return true;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bin_zero(uint32_t *__restrict__ p, uint32_t n) {
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(256) void k_bin_zero(uint32_t *__restrict__ p, uint
     if (i < n) p[i] = 0u;
 }
 
-template <uint32_t D>
+template <uint32_t D, bool FAST>
 __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inputs, uint32_t B, GridLevels g, BinGeom bg,
                                                    uint32_t *__restrict__ counts) {
     SN_POISON_ALL();
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inp
         const uint32_t b = blockIdx.x * (256u * SPT) + s * 256u + threadIdx.x;
         uint32_t row[1u << D];
         float w[1u << D];
-        if (b < B && pair_rows<D>(inputs, b, g, level, row, w)) {
+        if (b < B && pair_rows<D, FAST>(inputs, b, g, level, row, w)) {
 #pragma unroll
             for (uint32_t i = 0; i < (1u << D); ++i) atomicAdd(&hist[row[i] >> shift], 1u);
         }
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_emit(const uint32_t *
     if (blockIdx.x == 0 && threadIdx.x == 0u) *hdr = BinHdr{all[1] + all[2], all[1], all[3], all[0]};
 }
 
-template <uint32_t D, uint32_t C>
+template <uint32_t D, uint32_t C, bool FAST>
 __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ inputs, const float *__restrict__ grad, uint32_t B,
                                                      GridLevels g, BinGeom bg, int layout, uint32_t *__restrict__ cursor,
                                                      uint16_t *__restrict__ ekey, float *__restrict__ econtrib) {
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ i
 #pragma unroll
     for (uint32_t s = 0; s < SPT; ++s) {
         const uint32_t b = blockIdx.x * (256u * SPT) + s * 256u + threadIdx.x;
-        live[s] = b < B && pair_rows<D>(inputs, b, g, level, row[s], w[s]);
+        live[s] = b < B && pair_rows<D, FAST>(inputs, b, g, level, row[s], w[s]);
         if (live[s]) {
 #pragma unroll
             for (uint32_t i = 0; i < NC; ++i) rank[s][i] = atomicAdd(&hist[row[s][i] >> shift], 1u);
@@ -603,8 +618,10 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bin_zero, dim3(div_up(lay.total_bins, 256u)), dim3(256), 0, st, counts, lay.total_bins);   // (a kernel, not hipMemsetAsync: one node type in a captured graph)
     const dim3 gs(div_up(B, 256u * SPT), max_level), blk(256);
-    if (D == 3) hipLaunchKernelGGL((k_bin_count<3>), gs, blk, 0, st, inputs, B, g, bg, counts);
-    else hipLaunchKernelGGL((k_bin_count<2>), gs, blk, 0, st, inputs, B, g, bg, counts);
+    const bool fast = D == 3 && levels_fast(g);          // branch-free row addressing (pair_rows)
+    if (D == 3 && fast) hipLaunchKernelGGL((k_bin_count<3, true>), gs, blk, 0, st, inputs, B, g, bg, counts);
+    else if (D == 3) hipLaunchKernelGGL((k_bin_count<3, false>), gs, blk, 0, st, inputs, B, g, bg, counts);
+    else hipLaunchKernelGGL((k_bin_count<2, false>), gs, blk, 0, st, inputs, B, g, bg, counts);
     SN_LAUNCH_CHECK("k_bin_count");
     uint32_t *block_sums = reinterpret_cast<uint32_t *>(w + lay.block_sums);
     const dim3 gp(div_up(lay.total_bins, PLAN_BLOCK_BINS));
@@ -615,7 +632,8 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     const dim3 ga(lay.max_items), gm(lay.max_shared_bins < 2048u ? lay.max_shared_bins : 2048u);
 #define SN_BIN_C(DD, CC)                                                                                                         \
     do {                                                                                                                         \
-        hipLaunchKernelGGL((k_bin_scatter<DD, CC>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, ekey, econtrib);     \
+        if (DD == 3 && fast) hipLaunchKernelGGL((k_bin_scatter<DD, CC, DD == 3>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, ekey, econtrib); \
+        else hipLaunchKernelGGL((k_bin_scatter<DD, CC, false>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, ekey, econtrib);     \
         SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accum<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_bin_accum<CC>), ga, blk, lds, st, hdr, items, shared_bins, g, bg, ekey, econtrib, slabs, grad_embeddings);      \
         hipLaunchKernelGGL((k_bin_merge<CC>), gm, blk, 0, st, hdr, shared_bins, g, bg, slabs, grad_embeddings);                  \
