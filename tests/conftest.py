@@ -30,6 +30,14 @@ def gpu():
     # the product path must be the native library: fail loudly if it is not there
     assert os.path.exists(_lib.LIB_PATH), f"{_lib.LIB_PATH} missing on the GPU box"
     assert _lib.lib().sn_device_count() >= 1, _lib.lib().sn_last_error()
+    # SN_TEST_TUNING="band_streams=2,...": run the whole GPU suite under a non-default kernel selection (bit-neutral fields only make sense:
+    # e.g. every image-mode render with proposal stages as two row bands on two HIP streams)
+    if os.environ.get("SN_TEST_TUNING"):
+        from sanerf_hq_amd import raymarching as rm
+        for item in os.environ["SN_TEST_TUNING"].split(","):
+            k, v = item.split("=")
+            assert k.strip() in rm.Tuning.FIELDS, k
+            setattr(rm.tuning, k.strip(), int(v))
     return torch.device("cuda:0")
 
 

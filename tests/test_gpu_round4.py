@@ -284,3 +284,25 @@ def test_row_bands_on_two_streams_are_bit_identical(gpu, H, W, steps, f16, feat)
     torch.cuda.synchronize()
     for k in plain:
         assert torch.equal(out[k], plain[k]), k
+
+
+def test_row_bands_automatic_at_800x800_reference_schedule(gpu):
+    """At 800x800 (2500 workgroups) a schedule with proposal stages takes the two-stream band split by itself: image, depth and weights
+    equal the single-stream render bit for bit (fp16 tables, the bench's `also.ref_f16` configuration), and the single-stage schedule of
+    the bench line is left alone (one launch of 2500 workgroups)."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    H = W = 800
+    steps = [128, 64, 32]
+    model = product_model(synthetic_params(steps, seed=1), steps, False, gpu)
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    plan = rm.RenderPlan(model, steps, torch.float16)
+    auto = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, tuning=rm.Tuning()).items()}
+    info = rm.last_launch_info()
+    assert info["launches"] == 2 and info["workgroups"] == 1250, info            # two bands of 400 rows
+    one = rm.render_rays(plan, ro, rd, tile_w=W, tuning=rm.Tuning(band_streams=1), out={})
+    assert rm.last_launch_info()["launches"] == 1
+    for k in auto:
+        assert torch.equal(auto[k], one[k]), k
+    flat = rm.RenderPlan(product_model(synthetic_params([128], seed=1), [128], False, gpu), [128], torch.float16)
+    rm.render_rays(flat, ro, rd, tile_w=W, tuning=rm.Tuning())
+    assert rm.last_launch_info()["launches"] == 1 and rm.last_launch_info()["workgroups"] == 2500
