@@ -377,6 +377,44 @@ LINEAR_WGRAD_MIN_ROWS = 16384      # below this the BLAS call is as fast
 LINEAR_WGRAD_MAX_OUT = 256         # sn_linear_wgrad's output rows (any fan-in)
 
 _wgrad_ws: dict = {}
+_wgrad_ws_wide: dict = {}
+
+# Weight gradients beside the rest of the backward pass (round 4).  A layer's weight gradient is a leaf of the backward graph: nothing
+# downstream of it runs before the optimiser.  sn_linear_wgrad is matrix-core work, the gradient scatter of the grid encoder that follows it
+# in a mask-field / RGB step is memory and LDS work -- on ONE stream they run one after the other.  With WGRAD_SIDE_STREAM the weight
+# gradients of a backward call go to a second stream (forked after everything they read exists) and the backward pass joins it in an engine
+# callback at its very end (torch.autograd queue_callback), so the two kinds of kernel overlap.  Only when no gradient tensor can be touched
+# before that join: every parameter's .grad is None (AccumulateGrad then stores the tensor, no kernel) -- otherwise the launch stays inline.
+# Tensors the side stream reads or writes are recorded with the caching allocator (record_stream).  Capturable (fork and join are events).
+WGRAD_SIDE_STREAM = True
+_side_streams: dict = {}
+
+
+def _wgrad_side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _beside_ok(params) -> bool:
+    return not any(p.grad is not None or p._backward_hooks for p in params)
+
+
+def _run_beside_backward(params, tensors, launch) -> bool:
+    """launch() on the side stream if that is safe (see above); returns whether it did."""
+    if not WGRAD_SIDE_STREAM or not _beside_ok(params):
+        return False
+    dev = tensors[0].device
+    main, side = torch.cuda.current_stream(dev), _wgrad_side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        launch()
+    for t in tensors:
+        t.record_stream(side)
+    ev = side.record_event()
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_event(ev))
+    return True
 
 
 class _small_linear(Function):
@@ -408,6 +446,7 @@ class _small_linear(Function):
                 ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x2.device)
                 _wgrad_ws[x2.device] = ws
             gw = torch.empty(N, K, device=x2.device, dtype=torch.float32)
+            # (inline: on the side stream the ~10 small launches of an RGB step cost more in forks than they hide -- step as a graph 2.24 -> 2.45 ms)
             _lib.check(lib.sn_linear_wgrad(_lib.dev(x2, "x"), _lib.dev(gy2, "grad_output"), M, K, N, _lib.dev(gw, "grad_weight"),
                                            ws.data_ptr(), ws.numel(), _lib.stream()), "sn_linear_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -474,20 +513,22 @@ class _wide_mlp_train(Function):
         grads_w = []
         inputs = [x2.contiguous()] + [h.reshape(N, 256) for h in hs]
         outs = gh + [gy2]
-        for i in range(nl):
-            if not ctx.needs_input_grad[2 + i]:
-                grads_w.append(None)
-                continue
-            K, Nn = inputs[i].shape[1], outs[i].shape[1]
-            wneed = int(lib.sn_linear_wgrad_workspace_bytes(N, K, Nn))
-            wsb = _wgrad_ws.get(x.device)
-            if wsb is None or wsb.numel() < wneed:
-                wsb = torch.empty(max(wneed, 1 << 20), dtype=torch.uint8, device=x.device)
-                _wgrad_ws[x.device] = wsb
-            gw = torch.empty(Nn, K, device=x.device, dtype=torch.float32)
-            _lib.check(lib.sn_linear_wgrad(_lib.dev(inputs[i], "x"), _lib.dev(outs[i], "grad_output"), N, K, Nn, _lib.dev(gw, "grad_weight"),
-                                           wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_linear_wgrad")
-            grads_w.append(gw)
+        todo = [i for i in range(nl) if ctx.needs_input_grad[2 + i]]
+        gws = {i: torch.empty(outs[i].shape[1], inputs[i].shape[1], device=x.device, dtype=torch.float32) for i in todo}
+        wneed = max([int(lib.sn_linear_wgrad_workspace_bytes(N, inputs[i].shape[1], outs[i].shape[1])) for i in todo], default=0)
+        wsb = _wgrad_ws_wide.get(x.device)                       # (its own workspace: these launches may run beside _linear's on the main stream)
+        if todo and (wsb is None or wsb.numel() < wneed):
+            wsb = torch.empty(max(wneed, 1 << 20), dtype=torch.uint8, device=x.device)
+            _wgrad_ws_wide[x.device] = wsb
+
+        def launch_wgrads():
+            for i in todo:
+                K, Nn = inputs[i].shape[1], outs[i].shape[1]
+                _lib.check(lib.sn_linear_wgrad(_lib.dev(inputs[i], "x"), _lib.dev(outs[i], "grad_output"), N, K, Nn, _lib.dev(gws[i], "grad_weight"),
+                                               wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_linear_wgrad")
+        if todo and not _run_beside_backward([ws[i] for i in todo], [inputs[i] for i in todo] + [outs[i] for i in todo] + list(gws.values()) + [wsb], launch_wgrads):
+            launch_wgrads()
+        grads_w = [gws.get(i) for i in range(nl)]
         return (gx.reshape(x.shape) if ctx.needs_input_grad[0] else None), None, *grads_w
 
 

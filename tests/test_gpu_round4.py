@@ -306,3 +306,35 @@ def test_row_bands_automatic_at_800x800_reference_schedule(gpu):
     flat = rm.RenderPlan(product_model(synthetic_params([128], seed=1), [128], False, gpu), [128], torch.float16)
     rm.render_rays(flat, ro, rd, tile_w=W, tuning=rm.Tuning())
     assert rm.last_launch_info()["launches"] == 1 and rm.last_launch_info()["workgroups"] == 2500
+
+
+def test_wide_mlp_weight_gradients_beside_the_backward_pass(gpu):
+    """ops.WGRAD_SIDE_STREAM: the wide training MLP's weight gradients run on a second stream and the backward pass joins it in an engine callback
+    at its end.  Same gradients as the inline launch (bit for bit: same kernels, same inputs); with a gradient already present on a parameter
+    (accumulation: AccumulateGrad launches an add) the launch stays inline; allocator traffic right after backward() must not disturb them."""
+    from sanerf_hq_amd import ops
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(7)
+    mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+    x = torch.randn(32768, 143, device=gpu, requires_grad=True)
+
+    def grads(side, keep=False):
+        ops.WGRAD_SIDE_STREAM = side
+        if not keep:
+            for p in mlp.parameters():
+                p.grad = None
+        x.grad = None
+        (mlp(x) ** 2).sum().backward()
+        junk = torch.full((1 << 22,), float("nan"), device=gpu)          # (would land in freed blocks of the backward pass)
+        del junk
+        return [p.grad.clone() for p in mlp.parameters()] + [x.grad.clone()]
+    try:
+        assert ops.wide_mlp_fusable(x, list(mlp.net), [])
+        a, b = grads(True), grads(False)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        c = grads(True, keep=True)                                        # accumulation on top of b's gradients: inline path
+        for u, v in zip(c[:-1], b[:-1]):
+            assert torch.allclose(u, 2 * v, rtol=1e-6, atol=0)
+    finally:
+        ops.WGRAD_SIDE_STREAM = True
