@@ -24,9 +24,13 @@ def spec_of(g) -> list:
     return json.loads(str(g["param_spec"]))
 
 
-def params_from_spec(spec) -> Dict[str, np.ndarray]:
+def params_from_spec(spec, tables_f16: bool = False) -> Dict[str, np.ndarray]:
+    """tables_f16: the fixture was generated with every hash table rounded to fp16 VALUES (tools/gen_golden.py fx_render(tables_f16=True))."""
     from sanerf_hq_amd import synth
-    return {s["name"]: synth.make_param(s) for s in spec}
+    out = {s["name"]: synth.make_param(s) for s in spec}
+    if tables_f16:
+        out = {k: (v.astype(np.float16).astype(np.float32) if k.endswith("embeddings") else v) for k, v in out.items()}
+    return out
 
 
 def oracle_cfg(orc, params: Dict[str, np.ndarray], num_steps, heads: bool = False, table_f16: bool = False, aabb=None):

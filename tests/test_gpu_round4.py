@@ -338,3 +338,26 @@ def test_wide_mlp_weight_gradients_beside_the_backward_pass(gpu):
             assert torch.allclose(u, 2 * v, rtol=1e-6, atol=0)
     finally:
         ops.WGRAD_SIDE_STREAM = True
+
+
+@pytest.mark.parametrize("name,steps", [("render_flat128_h", [128]), ("render_sref_h", [128, 64, 32])])
+def test_bench_route_vs_reference_fixture_with_fp16_tables(gpu, name, steps, monkeypatch):
+    """The route the bench line takes -- fp16 table STORAGE, the linear-tail last stage, densified levels 5-6 (forced: the automatic rule wants
+    64 M samples) -- against the reference's own outputs on tables of fp16 values (tests/golden/render_*_h.npz, generated by importing the
+    reference's Python): RGB within the north-star tolerance 1e-4, depth / weights_sum within 1e-4; and the same without densified levels."""
+    from helpers import golden, params_from_spec, spec_of
+    from sanerf_hq_amd import raymarching as rm
+    monkeypatch.setattr(rm.tuning, "final_sp_max_rays", -1)
+    monkeypatch.setattr(rm.tuning, "prop_sp_max_rays", -1)
+    g = golden(name)
+    model = product_model(params_from_spec(spec_of(g), tables_f16=True), steps, False, gpu)
+    u_tables = {k: T(g[f"u{k}"], gpu) for k in range(1, len(steps))} if len(steps) > 1 else None
+    plan = rm.RenderPlan(model, steps, torch.float16)
+    for densify in (2, 1):
+        monkeypatch.setattr(rm.tuning, "densify", densify)
+        out = rm.render_rays(plan, T(g["rays_o"], gpu), T(g["rays_d"], gpu), u_tables=u_tables, out={})
+        info = rm.last_launch_info()
+        assert info["final_kernel"] == ("k_final_stage<lt,K=7>" if densify == 2 else "k_final_stage<lt,K=5>"), info
+        np.testing.assert_allclose(out["image"].cpu().numpy(), g["image"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out["depth"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), g["weights_sum"], rtol=0, atol=1e-4)

@@ -98,6 +98,25 @@ def test_render_sref(orc):
     np.testing.assert_allclose(got["weights_sum"], g["weights_sum"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["render_flat128_h", "render_sref_h"])
+def test_render_with_fp16_valued_tables(orc, name):
+    """The reference's own render (imported Python, fp32 arithmetic) on tables whose values are fp16-representable -- what a half-precision
+    table copy holds, the storage BASELINE configs[1] names -- against the oracle in BOTH table modes: fp32 storage of the rounded values and
+    fp16 storage (the oracle widens rows on the fly): same numbers."""
+    g = golden(name)
+    assert int(g["tables_f16"]) == 1
+    params = params_from_spec(spec_of(g), tables_f16=True)
+    steps = [int(t) for t in g["num_steps"]]
+    u_tables = {k: g[f"u{k}"] for k in range(1, len(steps))}
+    for f16 in (False, True):
+        got = orc.render(oracle_cfg(orc, params, steps, table_f16=f16), g["rays_o"], g["rays_d"], debug=True, u_tables=u_tables)
+        for k in range(1, len(steps)):
+            assert np.array_equal(got[f"inds{k}"], g[f"inds{k}"]), f"sample indices of stage {k}"
+        np.testing.assert_allclose(got["image"], g["image"], rtol=0, atol=1e-4)          # north_star tolerance
+        np.testing.assert_allclose(got["depth"], g["depth"], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(got["weights_sum"], g["weights_sum"], rtol=0, atol=1e-6)
+
+
 def test_render_flat128(orc):
     g, got, _ = _render_case(orc, "render_flat128")
     np.testing.assert_allclose(got["sigmas0"], g["sigmas0"], rtol=2e-6, atol=1e-6)

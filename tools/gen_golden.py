@@ -384,13 +384,18 @@ def build_cfg_from_model(model, opt, keep):
 
 
 def fx_render(rr, nn_, ru, tag, num_steps, with_heads, n_side, H, W, base_seed, table_amp, mlp_gain,
-              pose=None, time_it=False):
+              pose=None, time_it=False, tables_f16=False):
     print(f"[render:{tag}] num_steps={num_steps} heads={with_heads} rays={n_side * n_side}")
     opt = make_opt(num_steps=num_steps, with_sam=with_heads, with_mask=with_heads)
     torch.manual_seed(0)
     model = nn_.NeRFNetwork(opt)
     spec = param_spec_for(model, base_seed, table_amp, mlp_gain)
     load_params(model, spec)
+    if tables_f16:     # the reference computes in fp32 on tables whose VALUES are fp16-representable: what a half-precision table copy holds
+        with torch.no_grad():
+            for name, p_ in model.named_parameters():
+                if name.endswith("embeddings"):
+                    p_.copy_(p_.half().float())
     pose = synth.orbit_pose(1.0, 20.0, 30.0) if pose is None else pose
     ro, rd, idx = subset_rays(ru, H, W, n_side, pose)
     N = ro.shape[0]
@@ -428,7 +433,8 @@ def fx_render(rr, nn_, ru, tag, num_steps, with_heads, n_side, H, W, base_seed, 
     out = dict(rays_o=np_(ro), rays_d=np_(rd), pixel_index=idx.astype(np.int64),
                image=np_(res["image"]), depth=np_(res["depth"]), weights_sum=np_(res["weights_sum"]),
                param_spec=np.array(json.dumps(spec)), num_steps=np.array(num_steps, dtype=np.int64),
-               with_heads=np.array(int(with_heads)), HW=np.array([H, W, n_side], dtype=np.int64), pose=pose)
+               with_heads=np.array(int(with_heads)), HW=np.array([H, W, n_side], dtype=np.int64), pose=pose,
+               tables_f16=np.array(int(tables_f16)))
     for k, c in enumerate(cap.pdf_calls):
         out[f"bins{k}"] = np_(c["bins"]); out[f"weights{k}"] = np_(c["weights"])
         out[f"inds{k + 1}"] = np_(c["inds"]).astype(np.int32); out[f"u{k + 1}"] = np_(c["u"])
@@ -693,6 +699,10 @@ def main():
         fx_render(rr, nn_, ru, "sref", [128, 64, 32], False, 16, 64, 64, 1234, 1.0, 4.0, time_it=True)
     if on("flat128"):
         fx_render(rr, nn_, ru, "flat128", [128], False, 12, 64, 64, 555, 1.0, 4.0)
+    if on("flat128_h"):     # the bench configuration's storage: tables rounded to fp16 values (BASELINE configs[1])
+        fx_render(rr, nn_, ru, "flat128_h", [128], False, 12, 64, 64, 777, 1.0, 4.0, tables_f16=True)
+    if on("sref_h"):
+        fx_render(rr, nn_, ru, "sref_h", [128, 64, 32], False, 12, 64, 64, 4321, 1.0, 4.0, tables_f16=True)
     if on("heads"):
         fx_render(rr, nn_, ru, "heads", [128, 64, 32], True, 8, 64, 64, 999, 1.0, 4.0)
     if on("c1"):
