@@ -1269,8 +1269,20 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     float out_acc[16];                     // XMODE 3: sum over this wave's samples of weight x logit, per ray (neurons as tile 0's registers)
 #pragma unroll
     for (int r = 0; r < 16; ++r) out_acc[r] = 0.0f;
+    float wt = 0.0f;                       // XMODE 3: this lane's compositing weight in the current tile
+    if constexpr (XMODE == 3) ok = blockIdx.x * 32u + (lane & 31u) < a.N / a.T;     // (a workgroup whose tiles are all skipped never runs load_sample)
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
-    if constexpr (XMODE == 3) load_sample(tile);
+    if constexpr (XMODE == 3) {
+        // A tile whose 128 samples all carry weight exactly 0 (behind an opaque surface the transmittance has underflowed, in empty space
+        // alpha = 1 - exp(-0) = 0) adds w * logit = 0 to every ray: it is skipped whole -- no gathers, no MLP.  Bit-identical as long as
+        // the skipped logits would have been finite (0 * inf = NaN in the reference's sum).  The weight stream needs no adjustment: every
+        // tile consumes the same chunk sequence, so the chunks prefetched for "the next tile" serve the tile after it just as well.
+        const uint32_t ray_ = blockIdx.x * 32u + (lane & 31u), t_ = 4u * tile + wave;
+        const bool ok_ = ray_ < a.N / a.T;
+        wt = ok_ ? a.wts[(size_t)ray_ * a.T + t_] : 0.0f;
+        if (__syncthreads_or(wt != 0.0f) == 0) continue;
+        load_sample(tile);
+    }
     // ---- layer 0: input k-steps only; accumulators start from the bias the plain way (once per tile) ----
     {
         const WideLayer L = a.layer[0];
@@ -1435,9 +1447,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         if (ok && chk != chk) g_wide_overflow = 1;
     }
     if constexpr (XMODE == 3) {            // renderer.py:384: out[ray, m] = sum_t w[ray, t] * logits[ray, t, m]: this wave's t of this tile
-        const float w = ok ? a.wts[n] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float t = w * acc[0][r]; out_acc[r] = out_acc[r] + t; }
+        for (int r = 0; r < 16; ++r) { const float t = wt * acc[0][r]; out_acc[r] = out_acc[r] + t; }
     }
     }                                      // tiles
     const WideLayer LL = a.layer[a.nl - 1u];
@@ -1446,6 +1457,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         // the four waves hold different samples of the same 32 rays: fixed-order sum through LDS (the weight ring is dead), wave 0 stores
         float *part = reinterpret_cast<float *>(lds_w);                  // [4 waves][32 rays][32 neurons]
         const uint32_t j = lane & 31u;
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");             // (skipped tiles leave prefetched weight chunks in flight: they must land before the ring is reused)
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wave * 32u + j) * 32u + (r & 3) + 8u * (r >> 2) + 4u * half] = out_acc[r];

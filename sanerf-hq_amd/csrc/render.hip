@@ -2767,12 +2767,15 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
         const float rb_next = real_bin(rs, bin_at(j + 1u));
         const float tmid = (rb_next + rb_prev) / 2.0f;
         rb_prev = rb_next;
+        const float w = a.w_in[(size_t)j * Npad + r];
+        // a sample index at which all 64 rays of the wave carry weight exactly 0 (behind an opaque surface, in empty space) adds
+        // fmaf(0, feature, acc) = acc: no position, no gathers.  Bit-identical (table values are finite).
+        if (__all(w == 0.0f)) continue;
         float p[3], x01[3];
         sample_x01(a.rc, rs, tmid, p, x01);
         bool oob = false;
 #pragma unroll
         for (int d = 0; d < 3; ++d) if (x01[d] < 0.0f || x01[d] > 1.0f) oob = true;     // gridencoder.cu:105-130
-        const float w = a.w_in[(size_t)j * Npad + r];
         const float wz = oob ? 0.0f : w;
         float pos[LG][3];
         float cv[LG][8][C];

@@ -361,3 +361,31 @@ def test_bench_route_vs_reference_fixture_with_fp16_tables(gpu, name, steps, mon
         np.testing.assert_allclose(out["image"].cpu().numpy(), g["image"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(out["depth"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), g["weights_sum"], rtol=0, atol=1e-4)
+
+
+def test_heads_skip_exactly_zero_weights(gpu):
+    """An opaque field (synthetic MLPs with gain 40: sigma is ~0 or huge) leaves most last-stage samples with weight EXACTLY 0 -- behind the
+    surface the transmittance has underflowed, in front of it alpha = 0.  The fused mask head skips a 128-sample tile whose weights are all
+    zero, the in-render feature stage a sample index at which a whole wave's weights are zero: both results must equal what the kernels that
+    evaluate every sample produce (stand-alone grid_composite: bit for bit; three-kernel mask route: summation order apart)."""
+    from helpers import make_opt
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    H = W = 128
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    params = synthetic_params([128, 64, 32], heads=True, seed=3, gain=40.0)
+    model = NeRFNetwork(make_opt(with_sam=True, with_mask=True))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    model = model.to(gpu).eval()
+    with torch.no_grad():
+        o = rm.render_rays(model._get_plan(with_feat=True), ro, rd, tile_w=W, want=("weights_last", "xyzs_last"))
+        wl = o["weights_last"]
+        assert float((wl == 0).float().mean()) > 0.5, "the scene is meant to have mostly exact-zero weights"
+        ref = rm.grid_composite(wl, o["xyzs_last"], model.s_grid, model.bound, tile_w=W)
+        assert torch.equal(o["f_feat"], ref)
+        model.fused_mask_head = True
+        a = model.render(ro, rd, staged=False, perturb=False, return_mask=1, H=H, W=W, tile_w=W)["instance_mask_logits"].clone()
+        model.fused_mask_head = False
+        b = model.render(ro, rd, staged=False, perturb=False, return_mask=1, H=H, W=W, tile_w=W)["instance_mask_logits"]
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))

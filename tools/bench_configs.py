@@ -219,6 +219,22 @@ def main():
             "rays_missing_the_aabb": round(float((o1["weights_sum"] == 0).float().mean()), 4),
             "image_max_abs_diff": float((o0["image"] - o1["image"]).abs().max())}   # (per-sample third layer vs linear tail: fp32 round-off)
         del soft
+    # ---- heads on an opaque field (MLP gain 40): most last-stage samples carry weight exactly 0, which the fused mask head (whole 128-sample
+    #      tiles) and the in-render feature stage (wave-wide sample indices) skip -- bit-identical, see test_heads_skip_exactly_zero_weights ----
+    for tag, kw, key in (("mask_head", dict(with_sam=False, with_mask=True), dict(return_mask=1)), ("sam_head", dict(with_sam=True, with_mask=False), dict(return_feats=1))):
+        pm = synthetic_params([128, 64, 32], heads=True, seed=3, gain=40.0)
+        mo = NeRFNetwork(make_opt(**kw))
+        mo.load_state_dict({k: torch.from_numpy(v) for k, v in pm.items()}, strict=False)
+        mo = mo.to(dev).eval()
+        ro4, rd4 = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(400, 400), 400, 400, device=dev)
+
+        def hr():
+            with torch.no_grad():
+                return mo.render(ro4, rd4, staged=False, perturb=False, H=400, W=400, tile_w=400, **key)
+        with torch.no_grad():
+            wl = rm.render_rays(mo._get_plan(), ro4, rd4, tile_w=400, want=("weights_last",))["weights_last"]
+        out[f"opaque_field_{tag}_400x400"] = {"ms": round(timeit(hr) * 1e3, 3), "exact_zero_weights": round(float((wl == 0).float().mean()), 4)}
+        del mo
     # ---- C5 ----
     out["C5_mask_training_step_4096_rays"] = c5_entry(dev)
     _, ro, rd, _, N = c5_setup(dev)
