@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 8
+#define SN_ABI_VERSION 9
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -238,6 +238,9 @@ typedef struct sn_render_tuning {
                                   * (bit-neutral): 0 automatic (>= 2048 workgroups: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 fp16;
                                   * >= 512 with the feature stage: 400x400 + SAM head 3.00 -> 2.82 ms), 1 never, 2 whenever the image has two bands
                                   * of whole tile rows */
+    int32_t exact_early_out;     /* the last stage leaves the march once the transmittance of all 64 rays of a wave has underflowed to EXACTLY 0 (every later
+                                  * weight is alpha * 0: bit-neutral; opaque scenes only): 0 automatic (schedules with proposal stages), 1 never, 2 always.
+                                  * The proposal stages always do (their remaining weights are written as 0 without evaluating the density). */
     int32_t experiment;          /* SN_EXP_*: variants that were built, verified bit-identical and measured SLOWER; honoured only by
                                   * a library built with -DSN_EXPERIMENTS (sn_build_flags), SN_ERR_UNSUPPORTED otherwise */
 } sn_render_tuning;

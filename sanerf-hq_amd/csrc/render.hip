@@ -919,6 +919,16 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
             if (a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
         }
         rb_prev = rb_next;
+        // EXACT early-out (round 4): once the transmittance of all 64 rays of the wave has underflowed to exactly 0 it stays 0 (the optical
+        // depth never decreases), so every later weight is alpha * 0 = 0 whatever the density: the remaining samples are not evaluated, their
+        // weights are written as 0 and the pdf normaliser keeps taking its (0 + 0.01) terms in the same order.  Opaque scenes only; bit-identical.
+        if (!a.dbg_bins && !a.dbg_sigma && !a.dbg_w && __all(tr == 0.0f)) {
+            for (uint32_t jj = j + 1u; jj < T; ++jj) {
+                a.w_scr[(size_t)jj * Npad + r] = 0.0f;
+                wacc += (double)(0.0f + 0.01f);
+            }
+            break;
+        }
     }
 
     // ---- pass 2: sample_pdf (renderer.py:84-119) as one merge of cdf against u ----
@@ -1673,7 +1683,7 @@ enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 
 // AUX: the instantiation that also serves the feature stage (weights -> scratch) and the opt-in early termination;
 // the plain one carries neither (one spilled register less in the march of the headline configuration)
-template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false, bool LT = false, bool L0L = false>
+template <typename TT, int L, int C, int H1, int H2, int NOUT, int VH, int MODE, int K, bool AUX = false, bool LT = false, bool L0L = false, bool EO = false>
 __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_final_stage(FinalArgs a) {
     SN_POISON_ALL();
     static_assert(!LT || (MODE == MLP_F16X3 && K >= 4 && K <= 8), "linear tail: split-fp16 MLP on the FinalLv path");
@@ -1763,6 +1773,9 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     for (int c = 0; c < NCOL; ++c) fimg[c] = 0.0f;
     float dep = 0.0f;
     double cum = 0.0, wsum = 0.0;
+    float tr_seen = 1.0f;                                  // this lane's ray: transmittance in front of the sample just evaluated
+    uint32_t j_stop = a.T;                                 // first sample index NOT evaluated (exact early-out below)
+    const bool per_sample_export = a.dbg_bins || a.dbg_w || a.dbg_sigma || a.dbg_xyz || a.dbg_geo;
     const TT *table = reinterpret_cast<const TT *>(a.table);
     // linear tail: sum_j w_j relu(h2_j) of the lane's 32 hidden rows, for the tile-0 and the tile-1 sample it shares
     float hacc[LT ? 2 : 1][LT ? 32 : 1];
@@ -1916,6 +1929,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
                     if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
                     const float alpha = 1.0f - expf_det(-ds);
                     const float tr = expf_det(-(float)cum);
+                    tr_seen = tr;
                     float w = alpha * tr;
                     if (w != w) w = 0.0f;
                     cum += (double)ds;
@@ -1935,6 +1949,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (AUX) { if (a.stop_cum > 0.0f && __all((float)cum > a.stop_cum)) break; }
+            if constexpr (EO) { if (!per_sample_export && __all(tr_seen == 0.0f)) { j_stop = j + 1u; break; } }      // exact early-out (see below)
             rb_prev = rb_next;
             continue;
         }
@@ -1958,6 +1973,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
         const float alpha = 1.0f - expf_det(-ds);
         const float tr = expf_det(-(float)cum);
+        tr_seen = tr;
         float w = alpha * tr;
         if (w != w) w = 0.0f;
         cum += (double)ds;
@@ -1990,6 +2006,12 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         // opt-in early termination (not reference behaviour): all 64 rays of the wave are opaque to
         // within eps -> the remaining samples could add at most eps to any weight sum
         if constexpr (AUX) { if (a.stop_cum > 0.0f && __all((float)cum > a.stop_cum)) break; }
+        // EXACT early-out (round 4, always on when no per-sample tensor is exported): once the transmittance exp(-optical depth) of all 64
+        // rays of the wave has underflowed to exactly 0 it stays 0 (the optical depth never decreases), every later weight is alpha * 0 = 0
+        // and adds nothing to image, depth or weights_sum: the march ends.  Opaque scenes only (optical depth > 103); bit-identical.  A template
+        // switch (EO instantiations, chosen by sn_render_tuning.exact_early_out): in the kernel of the single-stage bench line the test --
+        // a compare and a branch per sample -- perturbs the schedule by 0.5-1 % (same-box A/B), so that launch keeps the plain instantiation.
+        if constexpr (EO) { if (!per_sample_export && __all(tr_seen == 0.0f)) { j_stop = j + 1u; break; } }
         rb_prev = rb_next;
         if constexpr (MODE != MLP_F16X3) {   // un-pipelined modes: geometry of the next sample
             const uint32_t jn = j + 2u <= T ? j + 2u : T;
@@ -2001,6 +2023,9 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     }
 
     clock_probe(1);
+    if constexpr (AUX) {            // the feature stage reads every weight: the samples behind the exact early-out carry weight 0 (and are skipped there too)
+        if (a.w_out) for (uint32_t jj = j_stop; jj < T; ++jj) a.w_out[(size_t)jj * Npad + r] = 0.0f;
+    }
     if constexpr (LT) {
         // geometry channels, once per ray: W3[1 + c] . (sum_j w_j relu(h2_j)); both tiles' shares, then the half-wave exchange
 #pragma unroll 1
@@ -3507,6 +3532,10 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             else SN_LAUNCH_FINAL_T(float, MODE_, KK, false, LDS_FLOATS);                                                       \
         } while (0)
         const bool aux = fa.w_out != nullptr || fa.stop_cum > 0.0f;
+        // exact early-out of the last stage (linear-tail instantiations): automatic = with proposal stages (the reference's schedules; the test
+        // costs a semi-transparent scene 0.1-0.3 %, an opaque one renders 40 % faster), not for a single-stage schedule (the bench line's
+        // kernel stays as it is); tuning.exact_early_out 1 = never, 2 = always.  The proposal stages always have theirs.
+        const bool eo = cfg->tuning.exact_early_out == 2 || (cfg->tuning.exact_early_out == 0 && S >= 2u);
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = (SN_FINAL_LV && !lv_ok) ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
@@ -3557,13 +3586,14 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
 #endif
         } else if (mlp_mode == MLP_F16X3 && Kmain == 5 && !(fa.dbg_bins || fa.dbg_w || fa.dbg_sigma || fa.dbg_xyz || fa.dbg_geo) && lt_enabled(cfg)) {
             // linear tail: layer 3 off the matrix cores (per-sample geometry features are not available in this form)
-#define SN_LAUNCH_FINAL_LT(TT_, AUX_)                                                                                          \
+#define SN_LAUNCH_FINAL_LT_E(TT_, AUX_, EO_)                                                                                  \
             do {                                                                                                             \
                 const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);                   \
-                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true>), \
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, false, EO_>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
-                hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
+                hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, false, EO_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \
             } while (0)
+#define SN_LAUNCH_FINAL_LT(TT_, AUX_) do { if (eo) SN_LAUNCH_FINAL_LT_E(TT_, AUX_, true); else SN_LAUNCH_FINAL_LT_E(TT_, AUX_, false); } while (0)
             // SN_RENDER_L0=1 (opt-in): fp16 tables whose level 0 fits 16 KiB keep that level LDS-resident.  Bit-identical and measured
             // SLOWER than the texture path (800x800 [128]: 6.44 -> 6.58 ms, profiles/r03/ab_round3_experiments.txt): with fp16 tables the
             // kernel is not bound by the texture addressers, and the 8 ds_read_b32 + swizzled slab addressing cost more than 2 gathers save
@@ -3590,13 +3620,14 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                           (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float), dens ? 7 : 5, lv_gathers(dens ? 7 : 5));
             if (dens) {     // levels 5 and 6 densified for this call (densify_levels)
                 const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);
-                if (f16) {
-                    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                    hipLaunchKernelGGL((k_final_stage<__half, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), dim3(nblk), dim3(256), lds_bytes, st, fa7);
-                } else {
-                    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                    hipLaunchKernelGGL((k_final_stage<float, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true>), dim3(nblk), dim3(256), lds_bytes, st, fa7);
-                }
+#define SN_LAUNCH_FINAL_K7(TT_, EO_)                                                                                           \
+                do {                                                                                                         \
+                    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true, false, EO_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+                    hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 7, false, true, false, EO_>), dim3(nblk), dim3(256), lds_bytes, st, fa7); \
+                } while (0)
+                if (f16) { if (eo) SN_LAUNCH_FINAL_K7(__half, true); else SN_LAUNCH_FINAL_K7(__half, false); }
+                else { if (eo) SN_LAUNCH_FINAL_K7(float, true); else SN_LAUNCH_FINAL_K7(float, false); }
+#undef SN_LAUNCH_FINAL_K7
             }
 #ifdef SN_EXPERIMENTS
             else if (l0) { note("k_final_stage<lt,K=5,lds-level0>", nblk, (size_t)(PACK_FLOATS + 4 * 2 * 64 * 16 + L0_MAX_ROWS) * sizeof(float), 5, lv_gathers(5) - 2u);
@@ -3608,6 +3639,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
 #undef SN_LAUNCH_FINAL_LT_L0
 #endif
 #undef SN_LAUNCH_FINAL_LT
+#undef SN_LAUNCH_FINAL_LT_E
         } else if (mlp_mode == MLP_F16X3) {
             note(Kmain == 5 ? "k_final_stage<per-sample,K=5>" : "k_final_stage<per-sample,generic>", nblk, (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float),
                  Kmain, Kmain == 5 ? lv_gathers(5) : (uint32_t)dense_prefix(gl_main) * 4u + (16u - (uint32_t)dense_prefix(gl_main)) * 8u);

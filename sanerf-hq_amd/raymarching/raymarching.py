@@ -42,7 +42,7 @@ class Tuning:
         prop_sp_max_rays / final_sp_max_rays   ray-count thresholds of the several-lanes-per-ray kernels (0 default, < 0 never)
         feat_levels        levels per pass of the feature stage (0 default)
         experiment         _lib.EXP_*: measured-and-rejected variants, experiments builds only (SN_LIB=.../libsanerf_hip_exp.so)"""
-    FIELDS = ("mlp_mode", "per_sample_form", "densify", "linear_tile_order", "prop_sp_max_rays", "final_sp_max_rays", "feat_levels", "band_streams", "experiment")
+    FIELDS = ("mlp_mode", "per_sample_form", "densify", "linear_tile_order", "prop_sp_max_rays", "final_sp_max_rays", "feat_levels", "band_streams", "exact_early_out", "experiment")
 
     def __init__(self, **kw):
         for f in self.FIELDS:

@@ -389,3 +389,48 @@ def test_heads_skip_exactly_zero_weights(gpu):
         b = model.render(ro, rd, staged=False, perturb=False, return_mask=1, H=H, W=W, tile_w=W)["instance_mask_logits"]
     assert torch.isfinite(a).all()
     assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("steps,f16", [([128], True), ([128, 64, 32], False), ([64, 32], True)])
+def test_exact_early_out_is_bit_identical(gpu, steps, f16):
+    """tuning.exact_early_out: once the transmittance of all 64 rays of a wave has underflowed to exactly 0 the last stage stops marching and
+    the proposal stages stop evaluating densities (their remaining weights are 0 whatever the density).  On an opaque field (MLP gain 40:
+    most rays saturate within a few samples) image, depth and weights_sum of the early-out instantiations equal those of the plain ones bit
+    for bit -- also through the in-render feature stage, whose weights behind the early-out are written as zeros."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    H, W = 96, 104
+    model = product_model(synthetic_params(steps, heads=True, seed=3, gain=40.0), steps, True, gpu)
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.0, 20.0, 30.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    td = torch.float16 if f16 else torch.float32
+    for feat in (False, True):
+        plan = rm.RenderPlan(model, steps, td, feat_encoder=model.s_grid if feat else None)
+        off = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, tuning=rm.Tuning(exact_early_out=1)).items()}
+        on = rm.render_rays(plan, ro, rd, tile_w=W, tuning=rm.Tuning(exact_early_out=2), out={})
+        assert float((off["weights_sum"] > 0.999).float().mean()) > 0.3, "the scene is meant to be mostly opaque"
+        assert set(on) == set(off)
+        for k in off:
+            assert torch.equal(on[k], off[k]), (k, feat)
+
+
+def test_opaque_field_vs_oracle_with_early_outs(gpu, orc):
+    """The exact early-outs (proposal stages: always; last stage: automatic with proposal stages) against the oracle, which evaluates every
+    sample: on an opaque field the resampled indices are bit-exact and image / depth / weights_sum within the fp32 contract."""
+    from sanerf_hq_amd import raymarching as rm
+    steps = [128, 64, 32]
+    params = synthetic_params(steps, seed=3, gain=40.0)
+    model = product_model(params, steps, False, gpu)
+    H, W = 24, 40
+    _, _, ro, rd = camera_rays(orc, H, W, radius=1.0, elev=20.0, azim=30.0)
+    plan = rm.RenderPlan(model, steps)
+    out = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W)                       # no per-stage tensors: every early-out is active
+    dbg = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W, want=("inds",), out={})
+    want = orc.render(oracle_cfg(orc, params, steps), ro, rd, debug=True)
+    assert float((want["weights_sum"] > 0.999).mean()) > 0.3
+    for k in (1, 2):
+        assert np.array_equal(dbg[f"inds{k}"].cpu().numpy(), want[f"inds{k}"])
+    np.testing.assert_allclose(out["image"].cpu().numpy(), want["image"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["depth"].cpu().numpy(), want["depth"], rtol=1e-4, atol=1e-5)    # (gain-40 MLPs amplify the split-fp16 round-off: 3e-5 on 2 of 960 rays)
+    np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), want["weights_sum"], rtol=0, atol=1e-5)
+    # and the early-out render equals the per-stage-tensor render (whose proposal stages evaluate everything) in what both return
+    for k in ("depth", "weights_sum"):
+        assert torch.equal(out[k], dbg[k]), k

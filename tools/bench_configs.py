@@ -235,6 +235,14 @@ def main():
             wl = rm.render_rays(mo._get_plan(), ro4, rd4, tile_w=400, want=("weights_last",))["weights_last"]
         out[f"opaque_field_{tag}_400x400"] = {"ms": round(timeit(hr) * 1e3, 3), "exact_zero_weights": round(float((wl == 0).float().mean()), 4)}
         del mo
+    # ---- exact early-out of the march (sn_render_tuning.exact_early_out) on the opaque field: 800x800, both schedules ----
+    for sch in ([128, 64, 32], [128]):
+        mo = product_model(synthetic_params(sch, seed=3, gain=40.0), sch, False, dev)
+        pl = rm.RenderPlan(mo, sch, torch.float16)
+        ts = {nm: timeit(lambda tu=tu: rm.render_rays(pl, ro8, rd8, tile_w=W, tuning=tu)) for nm, tu in
+              (("ms_default", rm.Tuning()), ("ms_last_stage_early_out_off", rm.Tuning(exact_early_out=1)), ("ms_last_stage_early_out_on", rm.Tuning(exact_early_out=2)))}
+        out["exact_early_out_opaque_field_800x800_" + "_".join(map(str, sch))] = {k: round(v * 1e3, 3) for k, v in ts.items()}
+        del mo, pl
     # ---- C5 ----
     out["C5_mask_training_step_4096_rays"] = c5_entry(dev)
     _, ro, rd, _, N = c5_setup(dev)
