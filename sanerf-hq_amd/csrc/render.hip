@@ -3532,10 +3532,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             else SN_LAUNCH_FINAL_T(float, MODE_, KK, false, LDS_FLOATS);                                                       \
         } while (0)
         const bool aux = fa.w_out != nullptr || fa.stop_cum > 0.0f;
-        // exact early-out of the last stage (linear-tail instantiations): automatic = with proposal stages (the reference's schedules; the test
-        // costs a semi-transparent scene 0.1-0.3 %, an opaque one renders 40 % faster), not for a single-stage schedule (the bench line's
-        // kernel stays as it is); tuning.exact_early_out 1 = never, 2 = always.  The proposal stages always have theirs.
-        const bool eo = cfg->tuning.exact_early_out == 2 || (cfg->tuning.exact_early_out == 0 && S >= 2u);
+        // exact early-out of the LAST stage (linear-tail instantiations): opt-in (tuning.exact_early_out = 2).  Measured on the opaque field
+        // (profiles/r04/bench_configs.json): behind proposal stages the last stage's 32 samples sit around the surface and the test buys nothing
+        // (1.953 vs 1.952 ms -- the proposal stages' own early-out, always on, is what takes that render from 3.19 to 1.95 ms) while it costs a
+        // semi-transparent scene 0.2-0.3 %; a single-stage schedule gains (6.07 -> 4.43 ms) but its kernel is the bench line's (0.5-1 % cost).
+        const bool eo = cfg->tuning.exact_early_out == 2;
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = (SN_FINAL_LV && !lv_ok) ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv

@@ -413,7 +413,7 @@ def test_exact_early_out_is_bit_identical(gpu, steps, f16):
 
 
 def test_opaque_field_vs_oracle_with_early_outs(gpu, orc):
-    """The exact early-outs (proposal stages: always; last stage: automatic with proposal stages) against the oracle, which evaluates every
+    """The exact early-outs (proposal stages: always; last stage: forced on here) against the oracle, which evaluates every
     sample: on an opaque field the resampled indices are bit-exact and image / depth / weights_sum within the fp32 contract."""
     from sanerf_hq_amd import raymarching as rm
     steps = [128, 64, 32]
@@ -422,7 +422,7 @@ def test_opaque_field_vs_oracle_with_early_outs(gpu, orc):
     H, W = 24, 40
     _, _, ro, rd = camera_rays(orc, H, W, radius=1.0, elev=20.0, azim=30.0)
     plan = rm.RenderPlan(model, steps)
-    out = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W)                       # no per-stage tensors: every early-out is active
+    out = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W, tuning=rm.Tuning(exact_early_out=2))     # no per-stage tensors: every early-out is active
     dbg = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=W, want=("inds",), out={})
     want = orc.render(oracle_cfg(orc, params, steps), ro, rd, debug=True)
     assert float((want["weights_sum"] > 0.999).mean()) > 0.3
