@@ -413,7 +413,10 @@ def _run_beside_backward(params, tensors, launch) -> bool:
     for t in tensors:
         t.record_stream(side)
     ev = side.record_event()
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_event(ev))
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_event(ev))
+    except RuntimeError:            # not inside an engine-driven backward pass (backward() called by hand): join right away
+        main.wait_event(ev)
     return True
 
 
