@@ -196,16 +196,17 @@ def main():
     raygen_ms = ev[0].elapsed_time(ev[1]) / 10
     n_local = rays_o.shape[0]
 
-    def measure(schedule, tables, n_steps, n_warm, rays=None, gather=multi, compact=False, aabb=None):
+    def measure(schedule, tables, n_steps, n_warm, rays=None, gather=multi, compact=False, aabb=None, gain=None):
         """K timed whole-image renders (+ all-gather when `gather`) of one configuration.
         rays = (rays_o, rays_d, width, n_total): another image than the bench line's (no gather).
         compact / aabb: the opt-in live-sample compaction (cfg.compact_live) and a replacement aabb (`also` entries only)."""
         r_o, r_d, r_w, n_total = rays if rays is not None else (rays_o, rays_d, W, total_rays)
         steps = [128] if schedule == "flat128" else [128, 64, 32]
-        if schedule not in models:
-            params = synth.synthetic_params(steps, seed=0)
-            models[schedule] = (params, synth.product_model(params, steps, False, dev))
-        params, model = models[schedule]
+        mkey = schedule if gain is None else (schedule, gain)
+        if mkey not in models:
+            params = synth.synthetic_params(steps, seed=0) if gain is None else synth.synthetic_params(steps, seed=3, gain=gain)
+            models[mkey] = (params, synth.product_model(params, steps, False, dev))
+        params, model = models[mkey]
         plan = rm.RenderPlan(model, steps, torch.float16 if tables == "f16" else torch.float32, compact_live=compact)
         if aabb is not None:
             for i in range(6):
@@ -408,8 +409,23 @@ def main():
                 "ms_default_kernels": round(r0["ms_per_step"], 4), "ms_compact_live": round(r1["ms_per_step"], 4),
                 "rays_missing_the_aabb": round(float((r1["out"]["weights_sum"] == 0).float().mean()), 4),
                 # (the compacting kernel keeps the per-sample third layer, the default kernel applies its geometry rows once per ray:
-                #  equal up to fp32 round-off, bit-equal with SN_RENDER_LT=0 -- tests/test_gpu_render.py)
+                #  equal up to fp32 round-off, bit-equal with tuning.per_sample_form = 1 -- tests/test_gpu_render.py)
                 "image_max_abs_diff": float((img0 - r1["out"]["image"]).abs().max()), "num_steps": r1["steps"]}
+        # an OPAQUE field (MLP gain 40: what a trained scene looks like to the march): the exact early-out of the proposal stages (always on,
+        # bit-identical) -- and, for the single-stage schedule, the last stage's (opt-in, tuning.exact_early_out = 2)
+        try:
+            r = measure("ref", args.tables, 5, 2, gain=40.0)
+            also["opaque_field_ref_" + args.tables] = {"ms_per_step": round(r["ms_per_step"], 4), "rays_per_s": round(r["value"], 1), "num_steps": r["steps"],
+                                                      "rays_with_weights_sum_above_0.999": round(float((r["out"]["weights_sum"] > 0.999).float().mean()), 4),
+                                                      "note": "same 800x800 camera, synthetic field with MLP gain 40 (opaque); semi-transparent bench field: also.ref_" + args.tables}
+            r0 = measure("flat128", args.tables, 5, 2, gain=40.0)
+            rm.tuning.exact_early_out = 2
+            r1 = measure("flat128", args.tables, 5, 2, gain=40.0)
+            rm.tuning.exact_early_out = 0
+            also["opaque_field_flat128_" + args.tables] = {"ms_per_step": round(r0["ms_per_step"], 4), "ms_per_step_exact_early_out": round(r1["ms_per_step"], 4),
+                                                          "image_bit_equal": bool(torch.equal(r0["out"]["image"], r1["out"]["image"]))}
+        except Exception as e:   # noqa: BLE001
+            also["opaque_field_error"] = f"{type(e).__name__}: {e}"
         # the other BASELINE configurations, driver-timed (short runs; tools/bench_configs.py holds the long forms and more variants)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         sys.path.insert(0, os.path.join(ROOT, "tests"))
