@@ -211,7 +211,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_sums(const uint32_t *
 
 __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_emit(const uint32_t *__restrict__ counts, uint32_t *__restrict__ cursor, uint32_t total_bins,
                                                                 const uint32_t *__restrict__ block_sums, BinHdr *__restrict__ hdr, BinItem *__restrict__ items,
-                                                                BinShared *__restrict__ shared_bins, BinGeom bg) {
+                                                                BinShared *__restrict__ shared_bins, BinGeom bg, uint32_t slab_cap,
+                                                                float *__restrict__ grad_table) {
     SN_POISON_ALL();
     __shared__ PlanTables tb;
     plan_tables(tb, bg);
@@ -224,6 +225,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_emit(const uint32_t *
     for (uint32_t bq = 0; bq < gridDim.x; ++bq) {              // (at most 128 workgroups' totals: uniform loads)
 #pragma unroll
         for (int q = 0; q < 5; ++q) { const uint32_t x = block_sums[bq * 5u + q]; all[q] += x; if (bq < blockIdx.x) base[q] += x; }
+    }
+    // The slab region is sized from a proven worst case (slab_floats_bound), so this cannot trigger; if it ever did, no item is emitted (nothing
+    // is written past the workspace) and the gradient's first element is poisoned so that the step fails loudly instead of silently.
+    if (all[4] > slab_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0u) { *hdr = BinHdr{0u, 0u, 0u, 0u}; grad_table[0] = __builtin_nanf(""); }
+        return;
     }
     uint32_t off = base[0] + excl[0], ish = base[1] + excl[1], iex = all[1] + base[2] + excl[2], isb = base[3] + excl[3], isl = base[4] + excl[4];
 #pragma unroll
@@ -514,10 +521,14 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // rows per bin of every level: about half of an item's capacity in expected entries (density = pairs per row of the level), so that
 // uneven occupancy rarely splits a bin; power of two; at most BIN_ROWS_MAX rows and BIN_MAX_PER_LEVEL bins
-static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t max_level, uint64_t *bins_used, uint64_t *rows_total) {
+// *slab_floats: worst case of the slab region.  A split bin holds c > E_CAP entries and becomes ceil(c / E_CAP) <= c / E_CAP + 1 items with one
+// slab of (C << shift) floats each; a level holds P = B 2^D entries, so its split bins' items number <= P / E_CAP + min(bins, P / E_CAP).  (The
+// round-4 bound, 2 x the table, assumed rows per bin <= E_CAP / (2 density); the 4096-bins-per-level cap raises the shift beyond that for large B.)
+static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t max_level, uint64_t *bins_used, uint64_t *slab_floats) {
     bg->ecap = e_cap(C); bg->C = C;
     for (uint32_t l = 0; l <= SN_MAX_LEVELS; ++l) bg->boff[l] = 0;
-    *bins_used = 0; *rows_total = 0;
+    *bins_used = 0; *slab_floats = 0;
+    const uint64_t pairs = (uint64_t)B << D;
     for (uint32_t l = 0; l < SN_MAX_LEVELS; ++l) { bg->shift[l] = 0; bg->nb[l] = 0; }
     const uint32_t rmax = bg->ecap < BIN_ROWS_MAX ? bg->ecap : BIN_ROWS_MAX;
     for (uint32_t l = 0; l < max_level; ++l) {
@@ -532,7 +543,8 @@ static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, u
         bg->nb[l] = (uint32_t)((size + (1ull << s) - 1) >> s);
         bg->boff[l + 1] = bg->boff[l] + bg->nb[l];
         *bins_used += bg->nb[l];
-        *rows_total += size;
+        const uint64_t slab = (uint64_t)C << s, by_entries = pairs / bg->ecap;
+        if (slab > SMALL_BIN_FLOATS) *slab_floats += (by_entries + (by_entries < bg->nb[l] ? by_entries : bg->nb[l])) * slab;
     }
     for (uint32_t l = max_level; l < SN_MAX_LEVELS; ++l) bg->boff[l + 1] = bg->boff[max_level];
     return bg->boff[max_level] > 0;
@@ -543,9 +555,8 @@ struct BinLayout {
     uint32_t max_items, max_shared_bins, total_bins;
 };
 
-// worst-case sizes: items <= n / E_CAP + bins; split bins <= n / E_CAP; slab floats <= 2 x the table's floats (a split
-// bin's items hold >= E_CAP entries each, and rows per bin <= E_CAP / (2 density))
-static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t rows_total) {
+// worst-case sizes: items <= n / E_CAP + bins; split bins <= n / E_CAP; slab floats: bin_geometry's bound
+static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t slab_floats) {
     BinLayout l;
     const uint32_t cap = e_cap(C);
     l.total_bins = (uint32_t)bins_used;
@@ -560,7 +571,7 @@ static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t
     l.shared_bins = o; o += align256((size_t)l.max_shared_bins * sizeof(BinShared));
     l.ekey = o; o += align256((size_t)n * 2);
     l.econtrib = o; o += align256((size_t)n * C * 4);
-    l.slabs = o; o += align256((size_t)(2 * rows_total * C + 2 * (uint64_t)BIN_FLOATS) * 4);
+    l.slabs = o; o += align256((size_t)(slab_floats + 64) * 4);
     l.total = o + 256;
     return l;
 }
@@ -577,10 +588,10 @@ size_t sn_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t 
     const uint64_t n = (uint64_t)B * max_level * (1u << D);
     if (n == 0 || n >= (1ull << 31)) return 0;
     BinGeom bg;
-    uint64_t bins_used = 0, rows_total = 0;
-    if (!bin_geometry(&bg, offsets_host, B, D, C, max_level, &bins_used, &rows_total)) return 0;   // a level beyond 4096 bins of 4096 rows: use the atomic path
-    if (2 * rows_total * C + 2 * (uint64_t)BIN_FLOATS >= (1ull << 32)) return 0;                      // slab offsets are 32-bit
-    return bin_layout(n, C, bins_used, rows_total).total;
+    uint64_t bins_used = 0, slab_floats = 0;
+    if (!bin_geometry(&bg, offsets_host, B, D, C, max_level, &bins_used, &slab_floats)) return 0;   // a level beyond 4096 bins of 4096 rows: use the atomic path
+    if (slab_floats >= 0xffffff00ull) return 0;                                                       // slab offsets are 32-bit: use the atomic path
+    return bin_layout(n, C, bins_used, slab_floats).total;
 }
 
 int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
@@ -599,13 +610,13 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     const uint64_t n64 = (uint64_t)B * max_level * (1u << D);
     SN_REQUIRE(n64 < (1ull << 31), "grid_encode_backward_binned: %llu contributions exceed 2^31", (unsigned long long)n64);
     BinGeom bg;
-    uint64_t bins_used = 0, rows_total = 0;
-    if (!bin_geometry(&bg, offsets_host, B, D, C, max_level, &bins_used, &rows_total) || 2 * rows_total * C + 2 * (uint64_t)BIN_FLOATS >= (1ull << 32)) {
-        set_error("grid_encode_backward_binned: a level needs more than %u bins of %u rows (or the table exceeds 2^31 floats); use sn_grid_encode_backward",
+    uint64_t bins_used = 0, slab_floats = 0;
+    if (!bin_geometry(&bg, offsets_host, B, D, C, max_level, &bins_used, &slab_floats) || slab_floats >= 0xffffff00ull) {
+        set_error("grid_encode_backward_binned: a level needs more than %u bins of %u rows (or the split bins' slabs exceed 2^32 floats); use sn_grid_encode_backward",
                   BIN_MAX_PER_LEVEL, BIN_ROWS_MAX);
         return SN_ERR_UNSUPPORTED;
     }
-    const BinLayout lay = bin_layout(n64, C, bins_used, rows_total);
+    const BinLayout lay = bin_layout(n64, C, bins_used, slab_floats);
     SN_REQUIRE(table_aligned(grad) && table_aligned(workspace), "grid_encode_backward_binned: grad / workspace must be 16-byte aligned");
     if (workspace_bytes < lay.total) { set_error("grid_encode_backward_binned: workspace too small (%zu bytes, need %zu)", workspace_bytes, lay.total); return SN_ERR_WORKSPACE; }
     char *w = reinterpret_cast<char *>(workspace);
@@ -626,7 +637,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     uint32_t *block_sums = reinterpret_cast<uint32_t *>(w + lay.block_sums);
     const dim3 gp(div_up(lay.total_bins, PLAN_BLOCK_BINS));
     hipLaunchKernelGGL(k_bin_plan_sums, gp, dim3(PLAN_THREADS), 0, st, counts, lay.total_bins, bg, block_sums);
-    hipLaunchKernelGGL(k_bin_plan_emit, gp, dim3(PLAN_THREADS), 0, st, counts, cursor, lay.total_bins, block_sums, hdr, items, shared_bins, bg);
+    hipLaunchKernelGGL(k_bin_plan_emit, gp, dim3(PLAN_THREADS), 0, st, counts, cursor, lay.total_bins, block_sums, hdr, items, shared_bins, bg, (uint32_t)slab_floats, grad_embeddings);
     SN_LAUNCH_CHECK("k_bin_plan");
     const size_t lds = (size_t)(BIN_ROWS_MAX + BIN_FLOATS) * sizeof(float);      // 80 KiB: two workgroups per CU
     const dim3 ga(lay.max_items), gm(lay.max_shared_bins < 2048u ? lay.max_shared_bins : 2048u);

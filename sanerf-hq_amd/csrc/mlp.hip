@@ -907,6 +907,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #ifndef SN_WIDE_JV
 #define SN_WIDE_JV 8         // vector instructions the scheduler may place behind each MFMA of a tile
 #endif
+#ifndef SN_WIDE_PAIRS
+#define SN_WIDE_PAIRS 1      // chunk8 walks the output tiles in interleaved pairs (1) or one at a time (0: rounds 3-4)
+#endif
 
 template <bool B> struct bool_tag { static constexpr bool value = B; };
 template <int N> struct int_tag { static constexpr int value = N; };
@@ -1102,6 +1105,74 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         constexpr int t = decltype(tc)::value;
         static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; float v = acc[t][r]; asm("" : "+v"(v)); prev[16 * t + r] = v; });
     };
+#if SN_WIDE_PAIRS
+    // Tiles in PAIRS (round 5): the two tiles of a pair alternate on the matrix pipe -- c0 c1 c0 c1 c0 c1 -- so that an MFMA never follows, across
+    // filler instructions, the MFMA that produced its accumulator.  A dependent MFMA issues back to back behind its producer for free, but ONE
+    // instruction between the two costs ~43 cycles (MI355X_MICROARCH.md, constants table), and the just-in-time operands are exactly such
+    // instructions: the one-tile-at-a-time form above paid that twice per tile (k-steps of 1.2-1.4 k cycles against 768 of matrix time).
+    // Same products in the same order per accumulator: bit-identical.
+    auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
+        constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
+        if (g < 128u) wide_trace(g);
+        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
+        const half8_t Bh = __builtin_bit_cast(half8_t, make_uint4(ob_h[0], ob_h[1], ob_h[2], ob_h[3]));
+        const half8_t Bl = __builtin_bit_cast(half8_t, make_uint4(ob_l[0], ob_l[1], ob_l[2], ob_l[3]));
+        uint4 ah[2][2], al[2][2];                      // [register set][tile of the pair]
+        ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
+        floatx16 bias[2];
+        if constexpr (FIRST) { bias_tile(l, 0, bias[0]); bias_tile(l, 1, bias[1]); }
+        static_for<WIDE_MT / 2>([&](auto ppc) {
+            constexpr int pp = decltype(ppc)::value, t0 = 2 * pp, t1 = t0 + 1, cs = pp & 1, ns = cs ^ 1;
+            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cs][0]), A0l = __builtin_bit_cast(half8_t, al[cs][0]);
+            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cs][1]), A1l = __builtin_bit_cast(half8_t, al[cs][1]);
+            floatx16 c0, c1;
+            if constexpr (FIRST) { c0 = bias[0]; c1 = bias[1]; } else { c0 = acc[t0]; c1 = acc[t1]; }
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
+            if constexpr (pp + 1 == WIDE_MT / 2) {
+                // the last pair: every operand read of this chunk has been issued -- synchronise on chunk g+1 behind the pair's first two MFMAs,
+                // its first operands ride on the remaining four
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u, extra_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch_first_pair(g + 1u);
+            }
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
+            acc[t0] = c0; acc[t1] = c1;
+            if constexpr (pp + 1 < WIDE_MT / 2) {
+                if (!(SN_WIDE_ABLATE & 4)) {
+                    ah[ns][0] = buf[(t0 + 2) * 128]; al[ns][0] = buf[(t0 + 2) * 128 + 64];
+                    ah[ns][1] = buf[(t1 + 2) * 128]; al[ns][1] = buf[(t1 + 2) * 128 + 64];
+                }
+                if constexpr (FIRST) { bias_tile(l, t0 + 2, bias[0]); bias_tile(l, t1 + 2, bias[1]); }
+            }
+            if constexpr (FIRST && pp == 0) { escape_tile(int_tag<6>{}); escape_tile(int_tag<7>{}); }
+            if constexpr (ESC && pp >= 1) { escape_tile(int_tag<t0 - 2>{}); escape_tile(int_tag<t1 - 2>{}); }
+            prep(int_tag<t0>{});
+            prep(int_tag<t1>{});
+            if constexpr (pp + 1 == WIDE_MT / 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, FIRST ? 2 : 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (g + 1u < total_chunks) refill(g + 1u);
+        ++g;
+    };
+#else
     auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
         constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
         if (g < 128u) wide_trace(g);
@@ -1162,6 +1233,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         if (g + 1u < total_chunks) refill(g + 1u);
         ++g;
     };
+
+#endif
 
     // ---- operand makers ----
     auto h_piece = [&](auto kc, auto pc, uint32_t (&nbh)[4], uint32_t (&nbl)[4]) {      // pair p (0..3) of h k-step k

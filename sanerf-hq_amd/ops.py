@@ -21,6 +21,8 @@ import ctypes as C
 import os
 
 import numpy as np
+import weakref
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -386,7 +388,14 @@ _wgrad_ws_wide: dict = {}
 # callback at its very end (torch.autograd queue_callback), so the two kinds of kernel overlap.  Only when no gradient tensor can be touched
 # before that join: every parameter's .grad is None (AccumulateGrad then stores the tensor, no kernel) -- otherwise the launch stays inline.
 # Tensors the side stream reads or writes are recorded with the caching allocator (record_stream).  Capturable (fork and join are events).
-WGRAD_SIDE_STREAM = True
+#
+# OPT-IN (round 5, advisor): the caller states, by setting the flag, what this module cannot see from a parameter -- that nothing consumes
+# a weight gradient on the main stream before the backward pass ends.  That is false under DistributedDataParallel (the reducer's hooks sit
+# on the AccumulateGrad node in C++ and all-reduce the bucket while the side stream may still be writing it) and when one MLP is applied
+# twice inside one graph (the engine's input buffer adds the two gradients on the main stream).  What CAN be seen is checked per call
+# (_beside_ok): a leaf that requires grad, .grad is None, no tensor hooks, no post-accumulate-grad hooks; the shared-weight case is caught by
+# counting the live autograd nodes that hold the weight (_wide_uses).  bench.py / tools/train_*.py set the flag for their single-process steps.
+WGRAD_SIDE_STREAM = False
 _side_streams: dict = {}
 
 
@@ -397,8 +406,26 @@ def _wgrad_side_stream(device):
     return s
 
 
+class _UseToken:
+    __slots__ = ("__weakref__",)
+
+
+_wide_uses: dict = {}      # id(weight) -> WeakSet of tokens, one per live _wide_mlp_train node that holds the weight and has not been differentiated
+                           # (a weight used twice in one graph must not take the side stream; a node dropped without backward() frees its token)
+
+
+_shared_now: set = set()   # weights seen with two live nodes during the running backward pass (cleared by an engine callback at its end)
+
+
 def _beside_ok(params) -> bool:
-    return not any(p.grad is not None or p._backward_hooks for p in params)
+    for p in params:
+        if not (p.is_leaf and p.requires_grad) or p.grad is not None or p._backward_hooks:
+            return False
+        if getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+        if len(_wide_uses.get(id(p), ())) > 1 or id(p) in _shared_now:
+            return False
+    return True
 
 
 def _run_beside_backward(params, tensors, launch) -> bool:
@@ -480,6 +507,10 @@ class _wide_mlp_train(Function):
                 hs.append(h)
         ctx.save_for_backward(x, *hs, *weights)
         ctx.nl, ctx.leaky = len(weights), bool(leaky)
+        if WGRAD_SIDE_STREAM:
+            ctx.use_token = _UseToken()
+            for w in weights:
+                _wide_uses.setdefault(id(w), weakref.WeakSet()).add(ctx.use_token)
         return h
 
     @staticmethod
@@ -529,8 +560,15 @@ class _wide_mlp_train(Function):
                 K, Nn = inputs[i].shape[1], outs[i].shape[1]
                 _lib.check(lib.sn_linear_wgrad(_lib.dev(inputs[i], "x"), _lib.dev(outs[i], "grad_output"), N, K, Nn, _lib.dev(gws[i], "grad_weight"),
                                                wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_linear_wgrad")
+        if any(len(_wide_uses.get(id(w), ())) > 1 for w in ws):          # a weight shared by two nodes of this graph: both stay inline
+            _shared_now.update(id(w) for w in ws)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_shared_now.clear)
+            except RuntimeError:
+                pass
         if todo and not _run_beside_backward([ws[i] for i in todo], [inputs[i] for i in todo] + [outs[i] for i in todo] + list(gws.values()) + [wsb], launch_wgrads):
             launch_wgrads()
+        ctx.use_token = None
         grads_w = [gws.get(i) for i in range(nl)]
         return (gx.reshape(x.shape) if ctx.needs_input_grad[0] else None), None, *grads_w
 

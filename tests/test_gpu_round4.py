@@ -337,7 +337,7 @@ def test_wide_mlp_weight_gradients_beside_the_backward_pass(gpu):
         for u, v in zip(c[:-1], b[:-1]):
             assert torch.allclose(u, 2 * v, rtol=1e-6, atol=0)
     finally:
-        ops.WGRAD_SIDE_STREAM = True
+        ops.WGRAD_SIDE_STREAM = False
 
 
 @pytest.mark.parametrize("name,steps", [("render_flat128_h", [128]), ("render_sref_h", [128, 64, 32])])

@@ -1,0 +1,113 @@
+"""GPU tests added in round 5: the binned grid backward beyond the round-4 slab bound (advisor, high), the opt-in weight-gradient side
+stream with a weight shared by two nodes of one graph (advisor, medium), the pair-interleaved wide-MLP chunks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import camera_rays, oracle_cfg, product_model, synthetic_params  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("C,B,concentrate", [(8, 1 << 21, 0.0), (8, 1 << 21, 0.5), (2, 3 << 20, 0.0)])
+def test_binned_grid_backward_large_batches(gpu, orc, C, B, concentrate):
+    """grid_binned.hip at B >= 2 M samples of the heads' grid (L = 16, T = 2^19, desired 512: network.py:104).  The 4096-bins-per-level
+    cap raises the rows per bin there, split bins outnumber the round-4 bound (2 x the table) and k_bin_accum wrote past the slab region
+    (advisor, round 4).  The region is now sized from the proven worst case (bin_geometry: entries / E_CAP + min(bins, entries / E_CAP)
+    slabs per level); binned == atomic within the summation-order tolerance, same set of touched rows, first element not poisoned."""
+    from sanerf_hq_amd import ops
+    from sanerf_hq_amd.gridencoder import grid_encode
+    L = 16
+    offs, pls = orc.grid_layout(3, L, C, 2, 16, 19, 512)
+    gen = torch.Generator(device=gpu).manual_seed(11 + C)
+    emb = (torch.rand(int(offs[-1]), C, device=gpu, generator=gen) * 2 - 1)
+    x = torch.rand(B, 3, device=gpu, generator=gen)
+    k = int(B * concentrate)
+    if k:
+        x[:k] = (torch.tensor([[0.41, 0.57, 0.33]], device=gpu) + 2e-3 * torch.randn(k, 3, device=gpu, generator=gen)).clamp_(0, 1)
+    g = torch.randn(B, L * C, device=gpu, generator=gen)
+    res = {}
+    old = ops.GRID_BACKWARD_MODE
+    try:
+        for mode in ("binned", "atomic"):
+            ops.GRID_BACKWARD_MODE = mode
+            et = emb.clone().requires_grad_(True)
+            grid_encode(x, et, T(offs, gpu), pls, 16, False).backward(g)
+            res[mode] = et.grad
+            del et
+    finally:
+        ops.GRID_BACKWARD_MODE = old
+    assert bool(torch.isfinite(res["binned"]).all())
+    ref = res["atomic"].double()
+    rel = float((res["binned"].double() - ref).norm() / ref.norm())
+    assert rel < (2e-6 if concentrate == 0.0 else 5e-5), rel
+    assert torch.equal(res["binned"].abs().sum(-1) > 0, res["atomic"].abs().sum(-1) > 0)
+
+
+def test_wgrad_side_stream_is_opt_in_and_safe_for_a_shared_weight(gpu):
+    """ops.WGRAD_SIDE_STREAM (advisor, round 4): off by default; when on, an MLP applied TWICE inside one graph (the engine adds the two
+    weight gradients on the main stream before AccumulateGrad) keeps both launches inline -- gradients equal those of the flag off, bit for
+    bit -- and a parameter with a post-accumulate-grad hook never takes the side stream."""
+    from sanerf_hq_amd import ops
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    assert ops.WGRAD_SIDE_STREAM is False
+    torch.manual_seed(3)
+    mlp = SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu)
+    xa = torch.randn(32768, 143, device=gpu)
+    xb = torch.randn(32768, 143, device=gpu)
+
+    def grads(side):
+        ops.WGRAD_SIDE_STREAM = side
+        for p in mlp.parameters():
+            p.grad = None
+        ((mlp(xa) ** 2).sum() + (mlp(xb) * 3.0).sum()).backward()
+        junk = torch.full((1 << 22,), float("nan"), device=gpu)
+        del junk
+        return [p.grad.clone() for p in mlp.parameters()]
+    try:
+        assert ops.wide_mlp_fusable(xa, list(mlp.net), [])
+        a, b = grads(False), grads(True)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        assert not ops._shared_now                       # cleared by the engine callback at the end of the pass
+        seen = []
+        h = mlp.net[0].weight.register_post_accumulate_grad_hook(lambda p: seen.append(float(p.grad.abs().sum())))
+        ops.WGRAD_SIDE_STREAM = True
+        assert not ops._beside_ok([mlp.net[0].weight])
+        for p in mlp.parameters():
+            p.grad = None
+        (mlp(xa) ** 2).sum().backward()
+        torch.cuda.synchronize()
+        assert seen and abs(seen[0] - float(mlp.net[0].weight.grad.abs().sum())) <= 1e-3 * seen[0]
+        h.remove()
+    finally:
+        ops.WGRAD_SIDE_STREAM = False
+
+
+@pytest.mark.parametrize("N", [128, 1000, 160000])
+def test_wide_mlp_pair_interleaved_chunks_match_torch(gpu, N):
+    """k_mlp_wide_j walks a k-step's eight output tiles in interleaved pairs (round 5: no filler instruction between an MFMA and the MFMA
+    that consumes its accumulator).  Same products in the same order per accumulator as rounds 3-4: the SAM head MLP (skip layer, biases,
+    LayerNorm: network.py:107-116) and the mask MLP (network.py:118-123) against torch fp32 at the split-fp16 contract (2^-21 per product)."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(N)
+    for mlp, ln in ((SkipConnMLP(163, 256, 256, 5, skip_layers=[2], bias=True), torch.nn.LayerNorm(256)),
+                    (SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False), None)):
+        mlp = mlp.to(gpu)
+        ln = ln.to(gpu) if ln is not None else None
+        x = torch.randn(N, mlp.dim_in, device=gpu)
+        with torch.no_grad():
+            want = mlp(x.double().float())
+            want = ln(want) if ln is not None else want
+            got = rm.mlp_forward(x, mlp, ln)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0)

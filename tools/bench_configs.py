@@ -137,7 +137,9 @@ def c5_setup(dev):
 def c5_entry(dev, warm=3, iters=10, optimisers=True):
     """BASELINE configs[4]: mask-field training step, 4096 rays (fwd + bwd of m_grid + mask_mlp under the mask NLL, field frozen)."""
     from sanerf_hq_amd.optim import Adam as HipAdam   # (csrc/optim.hip: the same dense update, one pass per tensor)
+    from sanerf_hq_amd import ops
     model, ro, rd, labels, N = c5_setup(dev)
+    ops.WGRAD_SIDE_STREAM = True     # opt-in: one process, no DistributedDataParallel, every MLP applied once per graph (ops.py states the contract)
     optim = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-15)
 
     def fwd_bwd():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-k-step shader cycles of the fused mask head inside a real 400x400 mask render (samples in [ray][t] order along the rays):
-usage (GPU box): SN_LIB=tmp_ab/wtrace.so python tools/mask_trace.py      (-DSN_WIDE_TRACE=1 -DSN_WIDE_TRACE_MID=1 build)"""
+usage (GPU box): SN_LIB=ab/wtrace.so python tools/mask_trace.py      (-DSN_WIDE_TRACE=1 -DSN_WIDE_TRACE_MID=1 build)"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

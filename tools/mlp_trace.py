@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-chunk shader cycles of k_mlp_wide (workgroup 0, wave 0) from a -DSN_WIDE_TRACE=1 build of mlp.hip:
-usage (GPU box): SN_LIB=tmp_ab/wtrace.so python tools/mlp_trace.py"""
+usage (GPU box): SN_LIB=ab/wtrace.so python tools/mlp_trace.py"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
