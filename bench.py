@@ -64,6 +64,12 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="world size 1 only: still go through RCCL (init, all-gather pipeline, barriers)")
     ap.add_argument("--primary-only", action="store_true", help="skip the extra configurations reported under `also`")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: nccl (= RCCL over xGMI, the product) or gloo (device tensors staged through the host: lets the N > 1 branch run where "
+                         "RCCL cannot, e.g. several ranks on one GPU)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="N > 1: every rank uses cuda:0 (a one-GPU box exercising the N-rank code path; the ranks time-share the GPU, so `value` "
+                         "measures nothing about scaling -- the line says so)")
     ap.add_argument("--tuning", default="", help="kernel-selection fields of raymarching.Tuning for A/B runs, e.g. densify=1,per_sample_form=1 "
                                                   "(mlp_mode also takes f16x3 / mfma32 / valu); default: the shipped kernels")
     return ap.parse_args()
@@ -149,8 +155,12 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if args.shared_device:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
+    if args.shared_device and world > 1 and args.dist_backend == "nccl":
+        sys.exit("bench.py: --shared-device needs --dist-backend gloo (RCCL refuses two ranks on one device)")
     force_dist = args.force_dist and world == 1      # exercise the RCCL code path on a one-GPU box
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -160,7 +170,10 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     rccl_ranks = None
     if multi:
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                        # every rank really joined the RCCL communicator
         rccl_ranks = int(ones.item())
@@ -217,9 +230,13 @@ def main():
         pipe = PipelinedGather(H, W, 5, dev, depth=2, align=align) if gather else None
 
         def step():
-            rm.render_rays(plan, r_o, r_d, tile_w=r_w, out=out)
-            if pipe is not None:
-                band = torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
+            if pipe is None:
+                rm.render_rays(plan, r_o, r_d, tile_w=r_w, out=out)
+            else:
+                # the kernels write rgb | depth | weights_sum into this rank's slice of the image buffer (sn_render_io.out_stride) and the
+                # all-gather runs in place: no concatenation, no staging copy of the band
+                band = pipe.band_buffer()
+                rm.render_rays(plan, r_o, r_d, tile_w=r_w, out=out, packed=band)
                 pipe.submit(band)
 
         for _ in range(n_warm):
@@ -259,7 +276,7 @@ def main():
         # kernel class and step; the ceilings below are priced per band, so the launches of one step are summed
         per = lambda i: (ms[i] / n_steps) if cnt[i] else None     # noqa: E731
         return dict(steps=steps, params=params, out=out, elapsed=elapsed, value=n_total / (elapsed / n_steps),
-                    ms_per_step=elapsed / n_steps * 1e3, median_ms=per_step[len(per_step) // 2], tables=tables,
+                    ms_per_step=elapsed / n_steps * 1e3, median_ms=per_step[len(per_step) // 2], max_ms=per_step[-1], tables=tables,
                     s_bytes=2 if tables == "f16" else 4, final_ms=per(4), final_launches=int(cnt[4]), pack_ms=per(0),
                     prop_ms=[per(1), per(2)], shader_mhz=float(mhz.value), probe_ms=float(probe_ms.value), launch=launch,
                     image=pipe.drain() if pipe is not None else None)
@@ -278,6 +295,7 @@ def main():
                       "note": "rank 0 alone renders the whole image right after the timed region (other ranks idle at a barrier)"}
             full = torch.cat([r1["out"]["image"], r1["out"]["depth"].unsqueeze(-1), r1["out"]["weights_sum"].unsqueeze(-1)], dim=-1)
             gathered_check = {"max_abs_diff_vs_single_gpu_image": float((m["image"] - full).abs().max().item()),
+                              "max_abs_diff": float((m["image"] - full).abs().max().item()),
                               "rows_per_rank": [list(shard_rows(H, world, r, align)) for r in range(world)]}
         dist.barrier()
         del ro_f, rd_f
@@ -385,18 +403,26 @@ def main():
         from sanerf_hq_amd.dist import all_shards
         bands8 = all_shards(H4, 8, band_align(H4, 8))
         proj = {}
+        PROJ_FRAMES = 10
         for sch in ("flat128", "ref"):
-            t_full = also[f"c4_1600x1600_{sch}_{args.tables}"]["ms_per_step"]
-            t_band = []
+            # per-frame GPU-timeline durations (HIP events between frames), MEDIAN per band: one hiccup frame cannot poison a band (round 4's
+            # driver-run line read 13.1 ms for one 2 ms band: 3 frames, wall-clock mean); the slowest frame of every band is reported beside it
+            rf = measure(sch, args.tables, PROJ_FRAMES, 2, rays=(ro4, rd4, H4, H4 * H4))
+            t_full, t_band, t_band_max = rf["median_ms"], [], []
             for b0, e0 in bands8:
-                r = measure(sch, args.tables, 3, 1, rays=(ro4[b0 * H4:e0 * H4], rd4[b0 * H4:e0 * H4], H4, (e0 - b0) * H4))
-                t_band.append(round(r["ms_per_step"], 4))
-            proj[sch] = {"whole_image_ms": t_full, "band_ms": t_band, "rows_per_band": [e0 - b0 for b0, e0 in bands8],
+                r = measure(sch, args.tables, PROJ_FRAMES, 2, rays=(ro4[b0 * H4:e0 * H4], rd4[b0 * H4:e0 * H4], H4, (e0 - b0) * H4))
+                t_band.append(round(r["median_ms"], 4)); t_band_max.append(round(r["max_ms"], 4))
+            med = sorted(t_band)[len(t_band) // 2]
+            proj[sch] = {"whole_image_ms": round(t_full, 4), "whole_image_max_frame_ms": round(rf["max_ms"], 4),
+                         "band_ms": t_band, "band_max_frame_ms": t_band_max, "rows_per_band": [e0 - b0 for b0, e0 in bands8],
                          "workgroups_per_band": [-(-(((H4 + 7) // 8) * ((e0 - b0 + 7) // 8)) // 4) for b0, e0 in bands8],
+                         "outlier_bands": [i for i, t in enumerate(t_band) if t > 1.5 * med],
+                         "outlier_frames_in_bands": [i for i, (t, tm) in enumerate(zip(t_band, t_band_max)) if tm > 1.5 * t],
                          "projected_speedup_8": round(t_full / max(t_band), 3)}
-        also["c4_eight_band_projection"] = dict(proj, note="one GPU renders each of the 8 row bands of the 1600x1600 image separately (3 timed frames each, "
-                                                "wall clock incl. launches); a workgroup is four 8x8-pixel wave tiles, so a 200-row band is 1250 workgroups "
-                                                "(2.44 rounds of 512 resident workgroups; the stages' time steps at multiples of 256: profiles/r04/staircase_1600.txt)")
+        also["c4_eight_band_projection"] = dict(proj, note=f"one GPU renders each of the 8 row bands of the 1600x1600 image separately ({PROJ_FRAMES} timed frames "
+                                                "each after 2 warm-ups; per-frame HIP-event durations, median per band, slowest frame beside it; projected_speedup_8 = "
+                                                "whole-image median / slowest band median); a workgroup is four 8x8-pixel wave tiles, so a 200-row band is 1250 "
+                                                "workgroups (the stages' time steps at multiples of 256: profiles/r04/staircase_1600.txt)")
         del ro4, rd4
         # opt-in live-sample compaction (not reference behaviour, off in every line above): a scene whose aabb
         # two thirds of the rays miss (renderer.py:133-135), default kernels vs k_final_stage_cmp; images are bit-equal
@@ -481,7 +507,8 @@ def main():
                              "a frozen field is rendered; a training loop would re-convert 3 tables per step, 0.05 ms)" if args.tables == "f16" else "")
                           + (" -- BASELINE configs[1] is the fp16 configuration: tables in half like the reference's fp16 mode (grid.py:43-49), "
                              "results equal the fp32 oracle run on the same rounded tables to 1e-5 (also.flat128_f32: fp32 tables)" if args.tables == "f16" else ""),
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks if args.dist_backend == "nccl" else None, "ranks_joined": rccl_ranks,
+            "dist_backend": (args.dist_backend if multi else None), "shared_device": bool(args.shared_device and world > 1),
             "config": {"workload": f"{cfg_name}: {W}x{H} image, {n_local} rays on this GPU, hashgrid L=16 T=2^19 F=2, "
                                    f"32-64-64-16 + 31-32-32-3 MLPs, num_steps={steps} ({args.schedule}), tables {args.tables}, "
                                    "arithmetic fp32, random-init weights, orbit camera",
@@ -489,6 +516,8 @@ def main():
                        "parallelism": f"ray-tile row bands x{world}" + (" + one RCCL all-gather of rgb|depth|wsum per frame" if multi else "")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "also": also,
         }
+        if args.shared_device and world > 1:
+            line["value_note"] = "all ranks time-share ONE GPU (--shared-device): this line proves the N-rank code path, its value says nothing about scaling"
         if single is not None:
             line["single_gpu_same_image"] = single
             line["n1_same_image_rays_per_s"] = single["rays_per_s"]      # the base a scaling curve of THIS image must use (not the 800x800 N=1 line)

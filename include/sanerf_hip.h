@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 9
+#define SN_ABI_VERSION 10
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -312,6 +312,9 @@ typedef struct sn_render_io {
     float       *image;                     /* [N,3] */
     float       *depth;                     /* [N] */
     float       *weights_sum;               /* [N] */
+    uint32_t     out_stride;                /* 0: the three outputs above are dense arrays.  s >= 5: each is a COLUMN RANGE of a row-major buffer whose
+                                             * rays are s floats apart (image[n*s + 0..2], depth[n*s], weights_sum[n*s]): a band that feeds the
+                                             * image all-gather is written straight into its [N,5] payload (image = p, depth = p+3, weights_sum = p+4) */
     /* optional per-stage outputs, [N, ...] row-major like the reference tensors; NULL = not wanted */
     float       *bins[SN_MAX_STAGES];       /* [N,T_k+1] */
     float       *weights[SN_MAX_STAGES];    /* [N,T_k]   */

@@ -65,7 +65,7 @@ class RenderIO(C.Structure):
                 ("N", C.c_uint32), ("tile_w", C.c_uint32),
                 ("bins0_table", C.c_void_p), ("u_table", C.c_void_p * MAX_STAGES),
                 ("bins0_ray_stride", C.c_uint32), ("u_ray_stride", C.c_uint32 * MAX_STAGES), ("skip_final", C.c_int32),
-                ("image", C.c_void_p), ("depth", C.c_void_p), ("weights_sum", C.c_void_p),
+                ("image", C.c_void_p), ("depth", C.c_void_p), ("weights_sum", C.c_void_p), ("out_stride", C.c_uint32),
                 ("bins", C.c_void_p * MAX_STAGES), ("weights", C.c_void_p * MAX_STAGES),
                 ("sigmas", C.c_void_p * MAX_STAGES), ("inds", C.c_void_p * MAX_STAGES),
                 ("xyzs_last", C.c_void_p), ("geo_feat_last", C.c_void_p), ("f_image", C.c_void_p), ("f_feat", C.c_void_p),
@@ -73,7 +73,7 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 9   # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 10  # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),

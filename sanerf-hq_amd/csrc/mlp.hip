@@ -93,6 +93,7 @@ struct PackArgs {
     uint32_t transposed;                  // 1: w[l] is read as its transpose (backward pass): element [m][k] = w[l][k * in_dim[l] + m]
     uint32_t pair_ks;                     // k_mlp_wide_j<3>: the first pair_ks input k-steps of layer 0 hold (half-wave h, slot i) = level 2 kx + (i >> 2),
                                           // channel 4 h + (i & 3) of the C = 8 grid instead of input column 16 kx + 8 h + i (see issue_pair)
+    uint32_t pair_levels;                 // k_pack_mlp16: levels of that grid (its k-steps carry four levels each; mlp16.inc)
 };
 
 __device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo) {
@@ -907,9 +908,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 #ifndef SN_WIDE_JV
 #define SN_WIDE_JV 8         // vector instructions the scheduler may place behind each MFMA of a tile
 #endif
-#ifndef SN_WIDE_PAIRS
-#define SN_WIDE_PAIRS 1      // chunk8 walks the output tiles in interleaved pairs (1) or one at a time (0: rounds 3-4)
-#endif
 
 template <bool B> struct bool_tag { static constexpr bool value = B; };
 template <int N> struct int_tag { static constexpr int value = N; };
@@ -1105,74 +1103,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         constexpr int t = decltype(tc)::value;
         static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; float v = acc[t][r]; asm("" : "+v"(v)); prev[16 * t + r] = v; });
     };
-#if SN_WIDE_PAIRS
-    // Tiles in PAIRS (round 5): the two tiles of a pair alternate on the matrix pipe -- c0 c1 c0 c1 c0 c1 -- so that an MFMA never follows, across
-    // filler instructions, the MFMA that produced its accumulator.  A dependent MFMA issues back to back behind its producer for free, but ONE
-    // instruction between the two costs ~43 cycles (MI355X_MICROARCH.md, constants table), and the just-in-time operands are exactly such
-    // instructions: the one-tile-at-a-time form above paid that twice per tile (k-steps of 1.2-1.4 k cycles against 768 of matrix time).
-    // Same products in the same order per accumulator: bit-identical.
-    auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
-        constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
-        if (g < 128u) wide_trace(g);
-        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
-        const half8_t Bh = __builtin_bit_cast(half8_t, make_uint4(ob_h[0], ob_h[1], ob_h[2], ob_h[3]));
-        const half8_t Bl = __builtin_bit_cast(half8_t, make_uint4(ob_l[0], ob_l[1], ob_l[2], ob_l[3]));
-        uint4 ah[2][2], al[2][2];                      // [register set][tile of the pair]
-        ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
-        floatx16 bias[2];
-        if constexpr (FIRST) { bias_tile(l, 0, bias[0]); bias_tile(l, 1, bias[1]); }
-        static_for<WIDE_MT / 2>([&](auto ppc) {
-            constexpr int pp = decltype(ppc)::value, t0 = 2 * pp, t1 = t0 + 1, cs = pp & 1, ns = cs ^ 1;
-            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cs][0]), A0l = __builtin_bit_cast(half8_t, al[cs][0]);
-            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cs][1]), A1l = __builtin_bit_cast(half8_t, al[cs][1]);
-            floatx16 c0, c1;
-            if constexpr (FIRST) { c0 = bias[0]; c1 = bias[1]; } else { c0 = acc[t0]; c1 = acc[t1]; }
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
-            if constexpr (pp + 1 == WIDE_MT / 2) {
-                // the last pair: every operand read of this chunk has been issued -- synchronise on chunk g+1 behind the pair's first two MFMAs,
-                // its first operands ride on the remaining four
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u, extra_tag);
-                __builtin_amdgcn_sched_barrier(0);
-                prefetch_first_pair(g + 1u);
-            }
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
-            acc[t0] = c0; acc[t1] = c1;
-            if constexpr (pp + 1 < WIDE_MT / 2) {
-                if (!(SN_WIDE_ABLATE & 4)) {
-                    ah[ns][0] = buf[(t0 + 2) * 128]; al[ns][0] = buf[(t0 + 2) * 128 + 64];
-                    ah[ns][1] = buf[(t1 + 2) * 128]; al[ns][1] = buf[(t1 + 2) * 128 + 64];
-                }
-                if constexpr (FIRST) { bias_tile(l, t0 + 2, bias[0]); bias_tile(l, t1 + 2, bias[1]); }
-            }
-            if constexpr (FIRST && pp == 0) { escape_tile(int_tag<6>{}); escape_tile(int_tag<7>{}); }
-            if constexpr (ESC && pp >= 1) { escape_tile(int_tag<t0 - 2>{}); escape_tile(int_tag<t1 - 2>{}); }
-            prep(int_tag<t0>{});
-            prep(int_tag<t1>{});
-            if constexpr (pp + 1 == WIDE_MT / 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, FIRST ? 2 : 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, SN_WIDE_JV, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if (g + 1u < total_chunks) refill(g + 1u);
-        ++g;
-    };
-#else
     auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
         constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
         if (g < 128u) wide_trace(g);
@@ -1233,8 +1163,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         if (g + 1u < total_chunks) refill(g + 1u);
         ++g;
     };
-
-#endif
 
     // ---- operand makers ----
     auto h_piece = [&](auto kc, auto pc, uint32_t (&nbh)[4], uint32_t (&nbl)[4]) {      // pair p (0..3) of h k-step k
@@ -1627,6 +1555,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     }
 }
 
+#include "mlp16.inc"
+
 // Which forward kernel: k_mlp_wide_j (operands just in time; SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms, 400x400 mask render
 // 7.49 -> 7.13 ms; bit-identical).  The superseded k_mlp_wide forward modes are compiled only into experiments builds (-DSN_EXPERIMENTS),
 // where sn_debug_set("wide_jit", 0) selects them for an A/B.  (With fewer than 4 samples per ray the fused mask head keeps k_mlp_wide<3>;
@@ -1634,10 +1564,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #ifdef SN_EXPERIMENTS
 static int g_wide_jit = 1;
 static int g_wide_narrow1 = 1;       // sn_debug_set("wide_narrow1", 0): the fused mask head's last layer as a padded tile PAIR as before (A/B)
+static int g_mask_head16 = 1;        // sn_debug_set("mask_head16", 8): k_mlp16 as ONE 512-thread workgroup per CU; 0: the fused mask head on k_mlp_wide_j<3> (one wave per SIMD) as in rounds 3-4 (A/B)
+static int g_mlp16 = 0;              // sn_debug_set("mlp16", 1): sn_mlp_wide_forward on k_mlp16<0> (A/B)
 static bool wide_jit(int xmode) { (void)xmode; return g_wide_jit != 0; }
 #else
 static constexpr bool wide_jit(int) { return true; }
 static constexpr int g_wide_narrow1 = 1;
+static constexpr int g_mask_head16 = 1;
+static constexpr int g_mlp16 = 0;
 #endif
 
 extern "C" int sn_debug_set(const char *key, int value) {
@@ -1645,6 +1579,8 @@ extern "C" int sn_debug_set(const char *key, int value) {
 #ifdef SN_EXPERIMENTS
     if (strcmp(key, "wide_jit") == 0) { g_wide_jit = value; return SN_OK; }
     if (strcmp(key, "wide_narrow1") == 0) { g_wide_narrow1 = value; return SN_OK; }
+    if (strcmp(key, "mask_head16") == 0) { g_mask_head16 = value; return SN_OK; }
+    if (strcmp(key, "mlp16") == 0) { g_mlp16 = value; return SN_OK; }
     set_error("debug_set: unknown key '%s'", key);
     return SN_ERR_INVALID;
 #else
@@ -1677,6 +1613,36 @@ static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) 
         off += L.narrow ? (size_t)(WIDE_HKS / 4) * WIDE_CHUNK_U4 : (size_t)((L.uses_h ? WIDE_HKS : 0) + L.x_ks) * WIDE_CHUNK_U4;
     }
     SN_REQUIRE(off < (1ull << 31), "mlp_wide: packed weights too large");
+    *total_u4 = off;
+    return SN_OK;
+}
+
+// chunk stream of k_mlp16 (mlp16.inc): k-steps of 32 inputs, one 32 KiB chunk each; grid_levels > 0: layer 0's input is grid_levels x 8 grid
+// features (four levels per k-step) followed by `appended` channels in k-steps of their own (fused mask head)
+static int wide16_plan(const sn_mlp_desc *m, uint32_t grid_levels, uint32_t appended, WideLayer *layers, size_t *total_u4) {
+    SN_REQUIRE(m->num_layers >= 1 && m->num_layers <= SN_MAX_LAYERS, "mlp16: num_layers=%u outside 1..%d", m->num_layers, SN_MAX_LAYERS);
+    SN_REQUIRE(m->activation <= 1u, "mlp16: activation must be 0 (relu) or 1 (leaky_relu 0.01)");
+    const uint32_t din = m->dims[0], nl = m->num_layers;
+    SN_REQUIRE(din >= 1 && din <= 1024, "mlp16: input width %u outside 1..1024", din);
+    SN_REQUIRE((m->skip_mask & 1u) == 0u, "mlp16: a skip connection into layer 0 is not meaningful");
+    const uint32_t x_ks = grid_levels ? div_up(grid_levels, 4) + div_up(appended, 32) : div_up(din, 32);
+    size_t off = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        SN_REQUIRE(m->weight[l], "mlp16: layer %u has no weight", l);
+        if (l + 1 < nl) SN_REQUIRE(m->dims[l + 1] == (uint32_t)WIDE, "mlp16: hidden width must be %d (layer %u has %u)", WIDE, l, m->dims[l + 1]);
+        else SN_REQUIRE(m->dims[l + 1] >= 1 && m->dims[l + 1] <= (uint32_t)WIDE, "mlp16: output width %u outside 1..%d", m->dims[l + 1], WIDE);
+        WideLayer &L = layers[l];
+        const bool skip = ((m->skip_mask >> l) & 1u) != 0u;
+        L.uses_h = l > 0 ? 1u : 0u;
+        L.x_ks = (l == 0 || skip) ? x_ks : 0u;
+        L.out = m->dims[l + 1];
+        L.mt = div_up(L.out, 16);
+        L.has_bias = m->bias[l] ? 1u : 0u;
+        L.w_off = (uint32_t)off;
+        L.narrow = (l + 1 == nl && L.uses_h && L.x_ks == 0u && L.out <= 16u) ? 1u : 0u;
+        off += L.narrow ? (size_t)W16_CHUNK_U4 : (size_t)((L.uses_h ? W16_HKS : 0) + L.x_ks) * W16_CHUNK_U4;
+    }
+    SN_REQUIRE(off < (1ull << 31), "mlp16: packed weights too large");
     *total_u4 = off;
     return SN_OK;
 }
@@ -1851,7 +1817,15 @@ extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_ou
 // levels of its position and the appended geometry channels -- in registers, straight into the B operands of the first
 // layer, and composites the per-sample logits with the ray's weights in its epilogue.  Neither the [N*T, 143] input nor
 // the [N*T, n_inst] logits exist in memory.
-extern "C" size_t sn_rm_mask_head_workspace_bytes(const sn_mlp_desc *mlp) { return sn_mlp_wide_workspace_bytes(mlp); }
+extern "C" size_t sn_rm_mask_head_workspace_bytes(const sn_mlp_desc *mlp) {
+    // whichever skeleton takes the call: k_mlp16's stream pads the input k-steps to 32 columns (at most one more k-step per 4 levels + the appended ones)
+    const size_t a = sn_mlp_wide_workspace_bytes(mlp);
+    WideLayer layers[SN_MAX_LAYERS];
+    size_t u4 = 0;
+    if (!mlp || a == 0 || wide16_plan(mlp, 0u, 0u, layers, &u4) != SN_OK) return a;
+    const size_t b = (u4 + 2u * (size_t)W16_CHUNK_U4) * sizeof(uint4);
+    return a > b ? a : b;
+}
 
 extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights, uint32_t N, uint32_t T, uint32_t E,
                                float bound, const sn_grid_desc *grid, const sn_mlp_desc *mlp, float *out,
@@ -1878,6 +1852,61 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     size_t u4 = 0;
     int rc = wide_plan(mlp, pa.layer, &u4);
     if (rc) return rc;
+    {
+        // Two waves per SIMD on 16-row tiles (mlp16.inc) whenever the shape allows: the reference's mask_mlp does (n_inst <= 16 outputs behind
+        // hidden layers, no skip layers, T >= 4 samples per ray, a grid of the fast-path shape)
+        GridLevels gl16;
+        rc = build_grid_levels(&gl16, grid->offsets, grid->D, grid->C, grid->L, grid->S, grid->H, grid->gridtype, (int)grid->align_corners, grid->interp);
+        if (rc) return rc;
+        const bool fit16 = g_mask_head16 != 0 && nl >= 2u && mlp->dims[nl] <= 16u && mlp->skip_mask == 0u && T >= 4u && E <= 32u && levels_fast(gl16) &&
+                           (uint64_t)grid->offsets[grid->L] * 32u < (1ull << 32);
+        if (fit16) {
+            PackArgs p16;
+            size_t n16 = 0;
+            rc = wide16_plan(mlp, grid->L, E, p16.layer, &n16);
+            if (rc) return rc;
+            SN_REQUIRE(workspace_bytes >= n16 * sizeof(uint4), "mask_head: workspace too small (%zu bytes, need %zu)", workspace_bytes, n16 * sizeof(uint4));
+            SN_REQUIRE((uint64_t)N * T < (1ull << 32), "mask_head: N*T does not fit 32 bits");
+            hipStream_t st = (hipStream_t)stream;
+            p16.din = mlp->dims[0]; p16.nl = nl; p16.pack = reinterpret_cast<uint4 *>(workspace); p16.transposed = 0;
+            p16.pair_ks = div_up(grid->L, 4); p16.pair_levels = grid->L;
+            uint32_t max_threads = 0;
+            for (uint32_t l = 0; l < nl; ++l) {
+                p16.w[l] = mlp->weight[l];
+                p16.in_dim[l] = l == 0 ? mlp->dims[0] : (uint32_t)WIDE;
+                const uint32_t th = ((p16.layer[l].uses_h ? W16_HKS : 0) + p16.layer[l].x_ks) * (uint32_t)W16_MT * 64u;
+                if (th > max_threads) max_threads = th;
+            }
+            hipLaunchKernelGGL(k_pack_mlp16, dim3(div_up(max_threads, 256), nl), dim3(256), 0, st, p16);
+            SN_LAUNCH_CHECK("k_pack_mlp16");
+            WideArgs wa;
+            memset(&wa, 0, sizeof(wa));
+            wa.out = out; wa.pack = p16.pack;
+            wa.N = N * T; wa.din = mlp->dims[0]; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(n16 / W16_CHUNK_U4);
+            for (uint32_t l = 0; l < nl; ++l) { wa.bias[l] = mlp->bias[l]; wa.layer[l] = p16.layer[l]; }
+            wa.xyz = xyzs; wa.extra = extra; wa.wts = weights; wa.table = reinterpret_cast<const float *>(grid->embeddings);
+            wa.T = T; wa.E = E; wa.bound = bound;
+            int e = 0;
+            const float mant = frexpf(2.0f * bound, &e);
+            wa.inv_den = (mant == 0.5f && e > -100 && e < 100) ? 1.0f / (2.0f * bound) : 0.0f;
+            wa.g = gl16;
+            const size_t lds_fixed16 = (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 4u * SN_MAX_LEVELS * sizeof(uint32_t);
+#ifdef SN_EXPERIMENTS
+            if (g_mask_head16 == 8) {      // one 512-thread workgroup per CU (A/B)
+                const size_t lds16 = (size_t)W16Cfg<8>::NBUF * W16_CHUNK_U4 * sizeof(uint4) + lds_fixed16;
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp16<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+                hipLaunchKernelGGL((k_mlp16<3, 8>), dim3(div_up(N, 32u)), dim3(512), lds16, st, wa);
+            } else
+#endif
+            {
+                const size_t lds16 = (size_t)W16Cfg<4>::NBUF * W16_CHUNK_U4 * sizeof(uint4) + lds_fixed16;
+                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp16<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+                hipLaunchKernelGGL((k_mlp16<3, 4>), dim3(div_up(N, 16u)), dim3(256), lds16, st, wa);
+            }
+            SN_LAUNCH_CHECK("k_mlp16<3>");
+            return SN_OK;
+        }
+    }
     if (mlp->dims[nl] > 32u || mlp->skip_mask != 0u) {
         set_error("mask_head: fused path composites at most 32 outputs and no skip layers (got %u outputs, skip mask %u)", mlp->dims[nl], mlp->skip_mask);
         return SN_ERR_UNSUPPORTED;

@@ -1145,6 +1145,7 @@ struct FinalArgs {
     uint32_t bins0_stride;       // 0: bins0_tab is one shared table; else per ray [N][bins0_stride]
     uint32_t sh_degree;
     float *image, *depth, *wsum;
+    uint32_t istride, sstride;   // floats between consecutive rays of image / of depth and wsum (3 and 1, or sn_render_io.out_stride for both)
     float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
     float *w_out;                // scratch [T][Npad] for the feature stage, or NULL
     float stop_cum;              // > 0: a wave leaves the march once every lane's optical depth exceeds this (-ln eps)
@@ -2080,10 +2081,10 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         for (int c = 0; c < 3; ++c) {
             const float sg = 1.0f / (1.0f + expf_det(-rgb[c]));
             const float bgm = (1.0f - ws) * a.rc.bg;
-            a.image[(size_t)n * 3 + c] = sg + bgm;
+            a.image[(size_t)n * a.istride + c] = sg + bgm;
         }
-        a.depth[n] = dep;
-        a.wsum[n] = ws;
+        a.depth[(size_t)n * a.sstride] = dep;
+        a.wsum[(size_t)n * a.sstride] = ws;
         if (a.dbg_fimg) {
 #pragma unroll
             for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
@@ -2290,10 +2291,10 @@ __global__ __launch_bounds__(256) void k_final_stage_any(FinalArgs a, AnyShape s
         for (uint32_t c = 0; c < 3u; ++c) {
             const float sg = 1.0f / (1.0f + expf_det(-xin[c * 256u]));
             const float bgm = (1.0f - ws) * a.rc.bg;
-            a.image[(size_t)n * 3 + c] = sg + bgm;
+            a.image[(size_t)n * a.istride + c] = sg + bgm;
         }
-        a.depth[n] = dep;
-        a.wsum[n] = ws;
+        a.depth[(size_t)n * a.sstride] = dep;
+        a.wsum[(size_t)n * a.sstride] = ws;
     }
 }
 
@@ -2532,10 +2533,10 @@ __global__ __launch_bounds__(256, 2) void k_final_stage_cmp(FinalArgs a) {
         for (int c = 0; c < 3; ++c) {
             const float sg = 1.0f / (1.0f + expf_det(-rgb[c]));
             const float bgm = (1.0f - ws) * a.rc.bg;
-            a.image[(size_t)n * 3 + c] = sg + bgm;
+            a.image[(size_t)n * a.istride + c] = sg + bgm;
         }
-        a.depth[n] = dep;
-        a.wsum[n] = ws;
+        a.depth[(size_t)n * a.sstride] = dep;
+        a.wsum[(size_t)n * a.sstride] = ws;
         if (a.dbg_fimg) {
 #pragma unroll
             for (int c = 0; c < GEO; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
@@ -2738,10 +2739,10 @@ __global__ __launch_bounds__(256, 1) void k_final_stage_sp(FinalArgs a, uint32_t
         for (int k = 0; k < 3; ++k) {
             const float sg = 1.0f / (1.0f + expf_det(-rgb[k]));
             const float bgm = (1.0f - ws) * a.rc.bg;
-            a.image[(size_t)n * 3 + k] = sg + bgm;
+            a.image[(size_t)n * a.istride + k] = sg + bgm;
         }
-        a.depth[n] = dep;
-        a.wsum[n] = ws;
+        a.depth[(size_t)n * a.sstride] = dep;
+        a.wsum[(size_t)n * a.sstride] = ws;
     }
 }
 
@@ -3209,6 +3210,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     if (io->skip_final) SN_REQUIRE(cfg->num_stages >= 2 && io->bins[cfg->num_stages - 1] && !cfg->with_feat,
                                    "render_rays: skip_final needs >= 2 stages, io->bins[last] for the resampled bins, and no feature stage");
     else SN_REQUIRE(io->image && io->depth && io->weights_sum, "render_rays: outputs must be device pointers");
+    SN_REQUIRE(io->out_stride == 0u || io->out_stride >= 3u, "render_rays: out_stride %u must be 0 (dense outputs) or at least 3 floats", io->out_stride);
     const uint32_t S = cfg->num_stages;
     SN_REQUIRE(S >= 1 && S <= SN_MAX_STAGES, "render_rays: num_stages=%u outside 1..%d", S, SN_MAX_STAGES);
     for (uint32_t k = 0; k < S; ++k) SN_REQUIRE(cfg->num_steps[k] >= 1, "render_rays: num_steps[%u] must be >= 1", k);
@@ -3471,7 +3473,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.bins_in = b_scr[S - 1]; fa.bins0_stride = io->bins0_ray_stride;
         fa.bins0_tab = (S == 1 && io->bins0_table) ? io->bins0_table + (size_t)first * fa.bins0_stride : nullptr;
         fa.sh_degree = cfg->sh_degree;
-        fa.image = io->image + (size_t)first * 3; fa.depth = io->depth + first; fa.wsum = io->weights_sum + first;
+        fa.istride = io->out_stride ? io->out_stride : 3u; fa.sstride = io->out_stride ? io->out_stride : 1u;
+        fa.image = io->image + (size_t)first * fa.istride; fa.depth = io->depth + (size_t)first * fa.sstride; fa.wsum = io->weights_sum + (size_t)first * fa.sstride;
         fa.dbg_bins = io->bins[S - 1] ? io->bins[S - 1] + (size_t)first * (fa.T + 1) : nullptr;
         fa.dbg_w = io->weights[S - 1] ? io->weights[S - 1] + (size_t)first * fa.T : nullptr;
         fa.dbg_sigma = io->sigmas[S - 1] ? io->sigmas[S - 1] + (size_t)first * fa.T : nullptr;

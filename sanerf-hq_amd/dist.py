@@ -102,8 +102,15 @@ def render_model_sharded(model, pose, intrinsics, H: int, W: int, group: Optiona
 
     def rows(b, e):
         rays_o, rays_d = ray_fn(pose, intrinsics, H, W, device, b, e)
-        out = model.render(rays_o, rays_d, staged=False, perturb=False, tile_w=W)
-        return torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)
+        if device.type == "cuda":
+            # the fused render writes rgb | depth | weights_sum straight into the all-gather payload (sn_render_io.out_stride): no concatenation
+            band = torch.empty((e - b) * W, 5, device=device, dtype=torch.float32)
+            out = model.render(rays_o, rays_d, staged=False, perturb=False, tile_w=W, packed=band)
+            if out["image"].data_ptr() == band.data_ptr():
+                return band
+        else:
+            out = model.render(rays_o, rays_d, staged=False, perturb=False, tile_w=W)
+        return torch.cat([out["image"], out["depth"].unsqueeze(-1), out["weights_sum"].unsqueeze(-1)], dim=-1)   # (operator-chain routes, CPU twins of the tests)
 
     return render_image_sharded(rows, H, W, group, gather, force_collective)
 
@@ -131,6 +138,16 @@ class PipelinedGather:
         self.k = 0
         self.last = None
 
+    def band_buffer(self, rank: Optional[int] = None) -> torch.Tensor:
+        """This rank's [rows * W, K] slice of the image buffer the NEXT submit() gathers into: render into it (render_rays(packed=...)) and
+        hand it back to submit() -- the all-gather then runs in place, without a staging copy of the band."""
+        slot = self.k % len(self.images)
+        if self.works[slot] is not None:
+            self.works[slot].wait()                 # the buffer's previous frame is complete
+            self.works[slot] = None
+        r = (dist.get_rank(self.group) if dist.is_initialized() else 0) if rank is None else rank
+        return self.images[slot][r * self.local_numel:(r + 1) * self.local_numel]
+
     def submit(self, local: torch.Tensor) -> None:
         assert local.shape[0] == self.local_numel, f"expected a band of {self.local_numel} rays, got {local.shape[0]}"
         slot = self.k % len(self.images)
@@ -139,7 +156,11 @@ class PipelinedGather:
         if not dist.is_initialized():
             self.images[slot].copy_(local)
         else:
-            self.works[slot] = dist.all_gather_into_tensor(self.images[slot], local.contiguous(), group=self.group, async_op=True)
+            src = local.contiguous()
+            if src.data_ptr() >= self.images[slot].data_ptr() and src.data_ptr() < self.images[slot].data_ptr() + self.images[slot].numel() * self.images[slot].element_size() \
+                    and dist.get_backend(self.group) != "nccl":
+                src = src.clone()                   # band_buffer(): RCCL gathers in place (send = receive + rank * count); gloo stages through a copy
+            self.works[slot] = dist.all_gather_into_tensor(self.images[slot], src, group=self.group, async_op=True)
         self.last = slot
         self.k += 1
 

@@ -251,7 +251,7 @@ class NeRFRenderer(nn.Module):
         if perturb or self._needs_field_grad(update_proposal) or kind is None:
             return self._run_autograd(rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
                                       return_feats, return_mask, H, W)
-        return self._run_fused(rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w)
+        return self._run_fused(rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w, packed=kwargs.get("packed"))
 
     # ---------------------------------------------------------------------------------------
     @staticmethod
@@ -304,7 +304,9 @@ class NeRFRenderer(nn.Module):
                                    "(renderer.py:381 feeds 63 features into a 35-input MLP, network.py:128)")
             results["instance_mask_logits"] = rm.composite(weights.detach(), point_masks)
 
-    def _run_fused(self, rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w):
+    def _run_fused(self, rays_o, rays_d, bg_color, cam_near_far, return_feats, return_mask, H, W, tile_w, packed=None):
+        """packed: optional [N, >=5] buffer that receives rgb | depth | weights_sum in place (rm.render_rays; the all-gather payload of dist.py);
+        only with a scalar background (a tensor background is added after the kernel, renderer.py:353)."""
         opt = self.opt
         need_heads = opt.with_sam or return_mask > 0
         fused_sam = self._sam_fusable()
@@ -319,7 +321,8 @@ class NeRFRenderer(nn.Module):
         plan = self._get_plan(with_feat=fused_sam)
         bg = float(bg_color) if not torch.is_tensor(bg_color) else 0.0
         with torch.no_grad():
-            out = rm.render_rays(plan, rays_o, rays_d, cam_near_far=cam_near_far, bg_color=bg, tile_w=tile_w, want=want)
+            out = rm.render_rays(plan, rays_o, rays_d, cam_near_far=cam_near_far, bg_color=bg, tile_w=tile_w, want=want,
+                                 packed=None if torch.is_tensor(bg_color) else packed)
             image = out["image"]
             if torch.is_tensor(bg_color):                   # per-ray / rgb background (renderer.py:353)
                 image = image + (1 - out["weights_sum"]).unsqueeze(-1) * bg_color

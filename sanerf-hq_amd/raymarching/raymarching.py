@@ -630,11 +630,13 @@ class RenderPlan:
 def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: float = 1.0, tile_w: int = 0,
                 want: Sequence[str] = (), u_tables: Optional[Dict[int, torch.Tensor]] = None,
                 bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None,
-                skip_final: bool = False, tuning: Optional["Tuning"] = None):
+                skip_final: bool = False, tuning: Optional["Tuning"] = None, packed: Optional[torch.Tensor] = None):
     """Fused render of N rays.  Returns dict(image [N,3], depth [N], weights_sum [N]) plus the
     per-stage tensors named in `want`: 'bins', 'weights', 'sigmas', 'inds' (all stages),
     'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'; a plan built with `feat_encoder` also
-    returns 'f_feat' [N, L*C] = composite(weights_last, feat_encoder(xyzs_last))."""
+    returns 'f_feat' [N, L*C] = composite(weights_last, feat_encoder(xyzs_last)).
+    packed: a contiguous fp32 [N, K >= 5] buffer -- the kernels write rgb | depth | weights_sum into its first five columns (sn_render_io.out_stride)
+    and the returned image / depth / weights_sum are views of it: the payload of the image all-gather without a concatenation (dist.py)."""
     rays_o, rays_d = _flat3(rays_o), _flat3(rays_d)
     N = rays_o.shape[0]
     device = rays_o.device
@@ -681,9 +683,17 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         io.bins[S - 1] = buf(f"bins{S - 1}", (N, plan.num_steps[S - 1] + 1)).data_ptr()
     else:
         plan.check_range()           # fp16 range guard of the final stage's MLP: a no-op unless a parameter version moved
-        io.image = _lib.dev(buf("image", (N, 3)), "image")
-        io.depth = _lib.dev(buf("depth", (N,)), "depth")
-        io.weights_sum = _lib.dev(buf("weights_sum", (N,)), "weights_sum")
+        if packed is not None:
+            if not (packed.is_cuda and packed.dtype == torch.float32 and packed.dim() == 2 and packed.shape[0] == N and packed.shape[1] >= 5
+                    and packed.is_contiguous() and packed.device == device):
+                raise RuntimeError(f"render_rays: packed must be a contiguous fp32 [{N}, >=5] tensor on {device}, got {tuple(packed.shape)} {packed.dtype}")
+            base = packed.data_ptr()
+            io.image, io.depth, io.weights_sum, io.out_stride = base, base + 12, base + 16, packed.shape[1]
+            res["image"], res["depth"], res["weights_sum"] = packed[:, :3], packed[:, 3], packed[:, 4]
+        else:
+            io.image = _lib.dev(buf("image", (N, 3)), "image")
+            io.depth = _lib.dev(buf("depth", (N,)), "depth")
+            io.weights_sum = _lib.dev(buf("weights_sum", (N,)), "weights_sum")
     for k in range(S):
         T = plan.num_steps[k]
         if "bins" in want:

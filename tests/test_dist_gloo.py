@@ -150,3 +150,39 @@ def test_band_alignment_of_the_config4_image():
         bands = all_shards(1600, world, a)
         assert bands[0][0] == 0 and bands[-1][1] == 1600 and all(e - b == 1600 // world for b, e in bands)
         assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+
+
+def _pipe8_worker(rank, world, port, H, W, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sanerf_hq_amd.dist import PipelinedGather, band_align, shard_rows
+    align = band_align(H, world)
+    b, e = shard_rows(H, world, rank, align)
+    pg = PipelinedGather(H, W, 5, "cpu", depth=2, align=align)
+    for k in range(3):                                   # bench.py's step(): render INTO this rank's slice of the image buffer, gather in place
+        band = pg.band_buffer()
+        assert band.shape == ((e - b) * W, 5) and band.data_ptr() == pg.images[k % 2][b * W:e * W].data_ptr()
+        band.copy_(_fake_render(H, W)(b, e) + float(k))
+        pg.submit(band)
+    img = pg.drain().clone()
+    torch.save({"img": img, "band": (b, e), "align": align}, os.path.join(out_dir, f"q{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_config4_split_gathers_in_place(tmp_path):
+    """World size 8 (the round-4 verdict: the gloo tests stopped at 2 ranks): band_align(1600, 8) = 8-row wave tiles, 200 rows per rank,
+    PipelinedGather through band_buffer() -- the band is written into the image buffer and gathered without a staging copy, as bench.py's
+    N > 1 branch does -- three frames through two rotating buffers; every rank ends with the whole last frame."""
+    world, H, W = 8, 1600, 4
+    mp.spawn(_pipe8_worker, args=(world, _free_port(), H, W, str(tmp_path)), nprocs=world, join=True)
+    full = _fake_render(H, W)(0, H) + 2.0
+    bands = []
+    for r in range(world):
+        d = torch.load(os.path.join(tmp_path, f"q{r}.pt"))
+        assert d["align"] == 8 and torch.equal(d["img"], full), f"rank {r}"
+        bands.append(d["band"])
+    assert bands == [(200 * r, 200 * (r + 1)) for r in range(world)]
