@@ -242,6 +242,8 @@ typedef struct sn_render_tuning {
                                   * weight is alpha * 0: bit-neutral; opaque scenes only): 2 = on, 0 / 1 = off (the default: behind proposal stages it buys nothing, in a
                                   * single-stage schedule 6.07 -> 4.43 ms on an opaque field at 0.5-1 % cost on a semi-transparent one).
                                   * The proposal stages always do (their remaining weights are written as 0 without evaluating the density). */
+    int32_t wave_tile;           /* image mode: the 64 lanes of a wave cover 2^w x 2^(6-w) pixels: 0 default (8x8), 1..5 = w (2x32 ... 32x2); bit-neutral
+                                  * (A/B of the lines a gather instruction touches: profiles/r05/tile_shape_ab.txt) */
     int32_t experiment;          /* SN_EXP_*: variants that were built, verified bit-identical and measured SLOWER; honoured only by
                                   * a library built with -DSN_EXPERIMENTS (sn_build_flags), SN_ERR_UNSUPPORTED otherwise */
 } sn_render_tuning;

@@ -46,6 +46,7 @@ struct RayCommon {
     int contract, last_opaque;
     float bg;
     int xcd_swizzle;
+    uint32_t tlw;      // log2 of the wave tile's width in pixels (3: 8x8; sn_render_tuning.wave_tile)
     float inv_den;     // 1 / (2*bound) when that is a power of two (exact scaling), else 0
 };
 
@@ -68,15 +69,17 @@ __device__ __forceinline__ uint32_t tile_id(const RayCommon &rc) { return tile_i
 __device__ __forceinline__ bool ray_of_lane(const RayCommon &rc, uint32_t wg, uint32_t &n) {
     const uint32_t tid = threadIdx.x;
     if (rc.W) {
-        const uint32_t tx8 = (rc.W + 7u) >> 3, ty8 = (rc.rows + 7u) >> 3;
+        // wave tile = 2^tlw x 2^(6 - tlw) pixels (8x8 unless sn_render_tuning.wave_tile says otherwise; tx8 / ty8 keep their round-1 names)
+        const uint32_t tlw = rc.tlw, tlh = 6u - tlw, tw = 1u << tlw, th = 1u << tlh;
+        const uint32_t tx8 = (rc.W + tw - 1u) >> tlw, ty8 = (rc.rows + th - 1u) >> tlh;
         const uint32_t wave = tid >> 6, lane = tid & 63u;
         const uint32_t g = wg * 4u + wave;                       // wave tile
         const uint32_t pair = 2u * tx8, paired = (ty8 >> 1) * pair;
         uint32_t wx, wy;
         if (g < paired) { const uint32_t p = g / pair, i = g - p * pair; wx = i >> 1; wy = 2u * p + (i & 1u); }
         else { wx = g - paired; wy = ty8 & ~1u; }                // the odd last row (wx >= tx8: padding of the last workgroup)
-        const uint32_t py = wy * 8u + (lane >> 3);
-        const uint32_t px = wx * 8u + (lane & 7u);
+        const uint32_t py = (wy << tlh) + (lane >> tlw);
+        const uint32_t px = (wx << tlw) + (lane & (tw - 1u));
         const bool ok = wx < tx8 && px < rc.W && py < rc.rows;
         n = ok ? py * rc.W + px : 0u;
         return ok;
@@ -2991,8 +2994,12 @@ static bool rs_enabled(const sn_render_cfg *cfg) {
 #endif
 }
 
-static uint32_t blocks_for(uint32_t n, uint32_t W) {
-    if (W) { const uint32_t rows = (n + W - 1) / W; return div_up(((W + 7u) >> 3) * ((rows + 7u) >> 3), 4u); }   // four 8x8 wave tiles each (ray_of_lane)
+static uint32_t tile_log2w(const sn_render_cfg *cfg) { return (cfg && cfg->tuning.wave_tile >= 1 && cfg->tuning.wave_tile <= 5) ? (uint32_t)cfg->tuning.wave_tile : 3u; }
+static uint32_t blocks_for(uint32_t n, uint32_t W, uint32_t tlw) {
+    if (W) {                                                      // four wave tiles of 2^tlw x 2^(6 - tlw) pixels each (ray_of_lane)
+        const uint32_t rows = (n + W - 1) / W, tw = 1u << tlw, th = 64u >> tlw;
+        return div_up(((W + tw - 1u) >> tlw) * ((rows + th - 1u) / th), 4u);
+    }
     return div_up(n, 256);
 }
 
@@ -3021,7 +3028,7 @@ static BandPlan band_plan(const sn_render_cfg *cfg, uint32_t N, uint32_t W) {
     if (mode == 1 || W == 0 || !cfg || cfg->num_stages < 2 || N % W != 0) return p;
     // automatic: from 2048 workgroups (800x800); with the in-render feature stage -- a fourth kernel, bound by the texture path alone -- from 512
     // (400x400 + SAM-feature head, BASELINE configs[2]: 3.00 -> 2.82 ms, 2.58 -> 2.41 with fp16 tables; without it 400x400 gains nothing)
-    if (mode == 0 && blocks_for(N, W) < (cfg->with_feat ? 512u : 2048u)) return p;
+    if (mode == 0 && blocks_for(N, W, tile_log2w(cfg)) < (cfg->with_feat ? 512u : 2048u)) return p;
     const uint32_t rows = N / W;
     const uint32_t half_rows = ((rows / 2u + 15u) / 16u) * 16u;          // whole 16-row tile rows; the first band takes the odd one
     if (half_rows == 0u || half_rows >= rows) return p;
@@ -3197,7 +3204,7 @@ size_t sn_rm_render_workspace_bytes(const sn_render_cfg *cfg, uint32_t N, uint32
     if (!cfg || N == 0) return (size_t)PACK_FLOATS * sizeof(float);
     const BandPlan bp = band_plan(cfg, N, tile_w);
     const uint32_t nc = bp.chunk < N ? bp.chunk : N;
-    const size_t npad = (size_t)blocks_for(nc, tile_w) * 256u;
+    const size_t npad = (size_t)blocks_for(nc, tile_w, tile_log2w(cfg)) * 256u;
     const uint64_t samples = (uint64_t)N * cfg->num_steps[cfg->num_stages ? cfg->num_stages - 1 : 0];
     return ((size_t)bp.slots * stage_scratch_floats(cfg, (uint32_t)npad) + (size_t)PACK_FLOATS + pair_region_floats(cfg, samples)) * sizeof(float);
 }
@@ -3390,11 +3397,11 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     uint32_t chunk_index = 0;
     for (uint32_t first = 0; first < io->N; first += chunk, ++chunk_index) {
         const uint32_t n = (io->N - first) < chunk ? (io->N - first) : chunk;
-        const uint32_t nblk = blocks_for(n, W);
+        const uint32_t nblk = blocks_for(n, W, tile_log2w(cfg));
         const uint32_t Npad = nblk * 256u;
         const uint32_t slot = fork.side ? (chunk_index & 1u) : 0u;
         hipStream_t st = slot ? fork.side : st_main;                        // shadows the function-level `st`: this chunk's kernels and profile spans
-        const size_t slot_floats = stage_scratch_floats(cfg, blocks_for(chunk < io->N ? chunk : io->N, W) * 256u);
+        const size_t slot_floats = stage_scratch_floats(cfg, blocks_for(chunk < io->N ? chunk : io->N, W, tile_log2w(cfg)) * 256u);
         if ((size_t)(fork.side ? 2u : 1u) * slot_floats > scratch_floats_avail || stage_scratch_floats(cfg, Npad) > slot_floats) {
             set_error("render_rays: workspace too small (%zu bytes, need %zu)", io->workspace_bytes,
                       ((size_t)bplan.slots * slot_floats + head_floats) * sizeof(float));
@@ -3414,6 +3421,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         }
         {   // tuning.linear_tile_order disables the XCD-aware tile order (A/B switch)
             rc.xcd_swizzle = cfg->tuning.linear_tile_order == 0;
+            rc.tlw = tile_log2w(cfg);
             // compaction: workgroups differ in cost by the number of live rays of their tile; a contiguous tile range per
             // XCD would leave the XCDs that own empty image bands idle (measured on the small-aabb scene: 4.4 instead of
             // 3.0 ms), so tiles go round-robin over the XCDs in dispatch order

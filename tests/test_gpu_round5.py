@@ -164,3 +164,32 @@ def test_render_writes_straight_into_a_packed_band(gpu, orc):
         assert bool((packed[:, 5:] == -7.0).all())
         lin = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, packed=torch.empty(H * W, 5, device=gpu), out={})
         assert torch.equal(lin["image"], dense["image"]) and torch.equal(lin["depth"], dense["depth"])
+
+
+@pytest.mark.parametrize("N,T_,n_inst,L,E", [(300, 32, 2, 16, 15), (37, 128, 3, 16, 15), (64, 16, 16, 16, 7), (100, 8, 2, 6, 15), (33, 4, 1, 3, 0)])
+def test_fused_mask_head_on_16_row_tiles_agrees(gpu, N, T_, n_inst, L, E, experiments_build):
+    """k_mlp16<3, 8> (mlp16.inc, experiments builds: the fused mask head on v_mfma_f32_16x16x32_f16 tiles of 16 rows, two waves per SIMD, four
+    grid levels per input k-step, appended channels parked in LDS one tile ahead) against the shipped k_mlp_wide_j<3>: same products, an MFMA sums
+    32 of them instead of 16 -- round-off agreement; partial ray groups, samples outside the box, level counts that are no multiple of four, no
+    appended channels; and reproducible run to run."""
+    from sanerf_hq_amd import _lib, raymarching as rm
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    from sanerf_hq_amd.nerf.network import SkipConnMLP
+    torch.manual_seed(N + L)
+    enc = GridEncoder(input_dim=3, num_levels=L, level_dim=8, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).to(gpu)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1.0, 1.0)
+    mlp = SkipConnMLP(L * 8 + E, n_inst, 256, 3, skip_layers=[], bias=False).to(gpu)
+    xyz = torch.rand(N, T_, 3, device=gpu) * 2.2 - 1.1
+    extra = torch.randn(N, T_, max(E, 1), device=gpu)[..., :E].contiguous()
+    w = torch.rand(N, T_, device=gpu)
+    w[::7] = 0.0                                                       # rays whose samples all carry weight 0
+    a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
+    try:
+        _lib.check(_lib.lib().sn_debug_set(b"mask_head16", 8), "debug_set")
+        b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0).clone()
+        c = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
+    finally:
+        _lib.check(_lib.lib().sn_debug_set(b"mask_head16", 0), "debug_set")
+    assert torch.equal(b, c)
+    assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
