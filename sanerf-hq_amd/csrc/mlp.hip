@@ -1555,9 +1555,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     }
 }
 
-#ifdef SN_EXPERIMENTS
-#include "mlp16.inc"     // the fused mask head on 16-row tiles, two waves per SIMD (round 5): correct, slower than k_mlp_wide_j<3> -- experiments builds only
-#endif
+#include "mlp16.inc"     // k_mask16: the fused mask head on 16-row tiles, two waves per SIMD, tile pipeline (round 5)
 
 // Which forward kernel: k_mlp_wide_j (operands just in time; SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms, 400x400 mask render
 // 7.49 -> 7.13 ms; bit-identical).  The superseded k_mlp_wide forward modes are compiled only into experiments builds (-DSN_EXPERIMENTS),
@@ -1566,11 +1564,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #ifdef SN_EXPERIMENTS
 static int g_wide_jit = 1;
 static int g_wide_narrow1 = 1;       // sn_debug_set("wide_narrow1", 0): the fused mask head's last layer as a padded tile PAIR as before (A/B)
-static int g_mask_head16 = 0;        // sn_debug_set("mask_head16", 8): the fused mask head on k_mlp16<3, 8> (16-row tiles, two waves per SIMD: mlp16.inc) instead of k_mlp_wide_j<3>
+static int g_mask_head16 = 8;        // sn_debug_set("mask_head16", 0): the fused mask head on k_mlp_wide_j<3> (rounds 3-4) also where k_mask16 (mlp16.inc) takes it (A/B)
 static bool wide_jit(int xmode) { (void)xmode; return g_wide_jit != 0; }
 #else
 static constexpr bool wide_jit(int) { return true; }
 static constexpr int g_wide_narrow1 = 1;
+static constexpr int g_mask_head16 = 8;
 
 #endif
 
@@ -1616,8 +1615,7 @@ static int wide_plan(const sn_mlp_desc *m, WideLayer *layers, size_t *total_u4) 
     return SN_OK;
 }
 
-#ifdef SN_EXPERIMENTS
-// chunk stream of k_mlp16 (mlp16.inc): k-steps of 32 inputs, one 32 KiB chunk each; grid_levels > 0: layer 0's input is grid_levels x 8 grid
+// chunk stream of k_mask16 (mlp16.inc): k-steps of 32 inputs, one 32 KiB chunk each; grid_levels > 0: layer 0's input is grid_levels x 8 grid
 // features (four levels per k-step) followed by `appended` channels in k-steps of their own (fused mask head)
 static int wide16_plan(const sn_mlp_desc *m, uint32_t grid_levels, uint32_t appended, WideLayer *layers, size_t *total_u4) {
     SN_REQUIRE(m->num_layers >= 1 && m->num_layers <= SN_MAX_LAYERS, "mlp16: num_layers=%u outside 1..%d", m->num_layers, SN_MAX_LAYERS);
@@ -1646,8 +1644,6 @@ static int wide16_plan(const sn_mlp_desc *m, uint32_t grid_levels, uint32_t appe
     *total_u4 = off;
     return SN_OK;
 }
-
-#endif
 
 }  // namespace sn
 
@@ -1822,15 +1818,11 @@ extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_ou
 extern "C" size_t sn_rm_mask_head_workspace_bytes(const sn_mlp_desc *mlp) {
     // whichever skeleton takes the call: k_mlp16's stream pads the input k-steps to 32 columns (at most one more k-step per 4 levels + the appended ones)
     const size_t a = sn_mlp_wide_workspace_bytes(mlp);
-#ifdef SN_EXPERIMENTS
     WideLayer layers[SN_MAX_LAYERS];
     size_t u4 = 0;
     if (!mlp || a == 0 || wide16_plan(mlp, 0u, 0u, layers, &u4) != SN_OK) return a;
     const size_t b = (u4 + 2u * (size_t)W16_CHUNK_U4) * sizeof(uint4);
     return a > b ? a : b;
-#else
-    return a;
-#endif
 }
 
 extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights, uint32_t N, uint32_t T, uint32_t E,
@@ -1858,14 +1850,16 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
     size_t u4 = 0;
     int rc = wide_plan(mlp, pa.layer, &u4);
     if (rc) return rc;
-#ifdef SN_EXPERIMENTS
     if (g_mask_head16 != 0) {
-        // sn_debug_set("mask_head16", 8): two waves per SIMD on 16-row tiles (mlp16.inc) where the shape allows (n_inst <= 16 outputs behind hidden
-        // layers, no skip layers, T >= 4 samples per ray, a grid of the fast-path shape)
+        // k_mask16 (mlp16.inc: 16-row tiles, two waves per SIMD, the tile ahead's first-layer operands made under the hidden layer) takes the
+        // reference's mask head -- network.py:118-123: three bias-free layers, n_inst <= 16 outputs, <= 16 appended channels behind <= 16 levels,
+        // T >= 4 samples per ray, a grid of the fast-path shape; every other stack keeps k_mlp_wide_j<3> / k_mlp_wide<3> below
         GridLevels gl16;
         rc = build_grid_levels(&gl16, grid->offsets, grid->D, grid->C, grid->L, grid->S, grid->H, grid->gridtype, (int)grid->align_corners, grid->interp);
         if (rc) return rc;
-        const bool fit16 = g_mask_head16 != 0 && nl >= 2u && mlp->dims[nl] <= 16u && mlp->skip_mask == 0u && T >= 4u && E <= 32u && levels_fast(gl16) &&
+        bool any_bias = false;
+        for (uint32_t l = 0; l < nl; ++l) any_bias = any_bias || mlp->bias[l] != nullptr;
+        const bool fit16 = g_mask_head16 != 0 && nl == 3u && !any_bias && E <= 16u && mlp->dims[nl] <= 16u && mlp->skip_mask == 0u && T >= 4u && E <= 32u && grid->L <= 16u && levels_fast(gl16) &&
                            (uint64_t)grid->offsets[grid->L] * 32u < (1ull << 32);
         if (fit16) {
             PackArgs p16;
@@ -1897,18 +1891,16 @@ extern "C" int sn_rm_mask_head(const float *xyzs, const float *extra, const floa
             const float mant = frexpf(2.0f * bound, &e);
             wa.inv_den = (mant == 0.5f && e > -100 && e < 100) ? 1.0f / (2.0f * bound) : 0.0f;
             wa.g = gl16;
-            // biases [nl][256], level table, the appended channels of the tile ahead [8][threads]
-            const size_t lds_fixed16 = (size_t)nl * WIDE * sizeof(float) + 4u * SN_MAX_LEVELS * sizeof(uint32_t);
-            {
-                const size_t lds16 = (size_t)W16Cfg<8>::NBUF * W16_CHUNK_U4 * sizeof(uint4) + lds_fixed16 + 8u * 512u * sizeof(float);
-                SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp16<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-                hipLaunchKernelGGL((k_mlp16<3, 8>), dim3(div_up(N, 32u)), dim3(512), lds16, st, wa);
-            }
-            SN_LAUNCH_CHECK("k_mlp16<3>");
+            // weight ring (2 chunks), staged grid operands of the tile ahead [4][hi | lo][512] uint4, the narrow layer's resident weights, biases, level table
+            // ... the appended channels' operand [hi | lo][256] uint4, the level table + the live-tile word
+            const size_t lds16 = (size_t)W16Cfg<8>::NBUF * W16_CHUNK_U4 * sizeof(uint4) + 4u * 2u * 512u * sizeof(uint4) + (size_t)W16_HKS * 128u * sizeof(uint4) +
+                                 512u * sizeof(uint4) + 4u * SN_MAX_LEVELS * sizeof(uint32_t) + 16u;
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mask16<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            hipLaunchKernelGGL((k_mask16<8>), dim3(div_up(N, 32u)), dim3(512), lds16, st, wa);
+            SN_LAUNCH_CHECK("k_mask16");
             return SN_OK;
         }
     }
-#endif
     if (mlp->dims[nl] > 32u || mlp->skip_mask != 0u) {
         set_error("mask_head: fused path composites at most 32 outputs and no skip layers (got %u outputs, skip mask %u)", mlp->dims[nl], mlp->skip_mask);
         return SN_ERR_UNSUPPORTED;

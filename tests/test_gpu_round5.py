@@ -162,17 +162,12 @@ def test_render_writes_straight_into_a_packed_band(gpu, orc):
         assert got["image"].data_ptr() == packed.data_ptr()
         assert torch.equal(packed[:, :3], dense["image"]) and torch.equal(packed[:, 3], dense["depth"]) and torch.equal(packed[:, 4], dense["weights_sum"])
         assert bool((packed[:, 5:] == -7.0).all())
+        lin_dense = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, out={}).items()}      # linear ray order: the several-lanes-per-ray kernels
         lin = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=0, packed=torch.empty(H * W, 5, device=gpu), out={})
-        assert torch.equal(lin["image"], dense["image"]) and torch.equal(lin["depth"], dense["depth"])
+        assert torch.equal(lin["image"], lin_dense["image"]) and torch.equal(lin["depth"], lin_dense["depth"]) and torch.equal(lin["weights_sum"], lin_dense["weights_sum"])
 
 
-@pytest.mark.parametrize("N,T_,n_inst,L,E", [(300, 32, 2, 16, 15), (37, 128, 3, 16, 15), (64, 16, 16, 16, 7), (100, 8, 2, 6, 15), (33, 4, 1, 3, 0)])
-def test_fused_mask_head_on_16_row_tiles_agrees(gpu, N, T_, n_inst, L, E, experiments_build):
-    """k_mlp16<3, 8> (mlp16.inc, experiments builds: the fused mask head on v_mfma_f32_16x16x32_f16 tiles of 16 rows, two waves per SIMD, four
-    grid levels per input k-step, appended channels parked in LDS one tile ahead) against the shipped k_mlp_wide_j<3>: same products, an MFMA sums
-    32 of them instead of 16 -- round-off agreement; partial ray groups, samples outside the box, level counts that are no multiple of four, no
-    appended channels; and reproducible run to run."""
-    from sanerf_hq_amd import _lib, raymarching as rm
+def _mask_head_case(gpu, N, T_, n_inst, L, E):
     from sanerf_hq_amd.gridencoder import GridEncoder
     from sanerf_hq_amd.nerf.network import SkipConnMLP
     torch.manual_seed(N + L)
@@ -180,16 +175,43 @@ def test_fused_mask_head_on_16_row_tiles_agrees(gpu, N, T_, n_inst, L, E, experi
     with torch.no_grad():
         enc.embeddings.uniform_(-1.0, 1.0)
     mlp = SkipConnMLP(L * 8 + E, n_inst, 256, 3, skip_layers=[], bias=False).to(gpu)
-    xyz = torch.rand(N, T_, 3, device=gpu) * 2.2 - 1.1
+    xyz = torch.rand(N, T_, 3, device=gpu) * 2.2 - 1.1             # some samples outside the grid's box
     extra = torch.randn(N, T_, max(E, 1), device=gpu)[..., :E].contiguous()
     w = torch.rand(N, T_, device=gpu)
-    w[::7] = 0.0                                                       # rays whose samples all carry weight 0
-    a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
+    w[::7] = 0.0                                                   # rays whose samples all carry weight 0
+    return enc, mlp, xyz, extra, w
+
+
+@pytest.mark.parametrize("N,T_,n_inst,L,E", [(300, 32, 2, 16, 15), (37, 128, 3, 16, 15), (64, 16, 16, 16, 7), (100, 8, 2, 6, 15), (33, 4, 1, 3, 0), (4000, 32, 2, 16, 15)])
+def test_mask16_kernel_vs_unfused_composition_and_reproducible(gpu, N, T_, n_inst, L, E):
+    """k_mask16 (mlp16.inc, round 5: the fused mask head on v_mfma_f32_16x16x32_f16 tiles of 16 rows, two waves per SIMD, the tile ahead's
+    first-layer operands made by background units under the hidden layer and staged in LDS) takes the reference's mask-head shape
+    (network.py:118-123).  Against the unfused composition -- grid encoder -> cat -> wide MLP kernel -> composite (renderer.py:376-385) --
+    within the split-fp16 contract, and bit-equal run to run (a version whose units' gathers stayed in flight across a chunk boundary was not:
+    profiles/r05/mask16_units_ab.txt): partial ray groups, samples outside the box, level counts that are no multiple of four, few / no
+    appended channels, tiles whose weights are all zero, 4000 rays (every CU busy)."""
+    from sanerf_hq_amd import raymarching as rm
+    enc, mlp, xyz, extra, w = _mask_head_case(gpu, N, T_, n_inst, L, E)
+    outs = [rm.mask_head(w, xyz, extra, enc, mlp, 1.0).clone() for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    with torch.no_grad():
+        feats = enc(xyz.reshape(-1, 3), bound=1.0)
+        logits = rm.mlp_forward(torch.cat([feats, extra.reshape(N * T_, E)], dim=-1), mlp, None).reshape(N, T_, n_inst)
+        want = (w.unsqueeze(-1) * logits).sum(1)
+    assert torch.isfinite(outs[0]).all() and float((outs[0] - want).abs().max()) <= 5e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("N,T_,n_inst,L,E", [(300, 32, 2, 16, 15), (37, 128, 3, 16, 15), (64, 16, 16, 16, 7), (100, 8, 2, 6, 15)])
+def test_mask16_kernel_agrees_with_the_round4_kernel(gpu, N, T_, n_inst, L, E, experiments_build):
+    """Same-box A/B partner of k_mask16: k_mlp_wide_j<3> (rounds 3-4: 32-row tiles, one wave per SIMD), selected with sn_debug_set("mask_head16", 0)
+    in experiments builds: same products, an MFMA sums 32 of them instead of 16 -- round-off agreement."""
+    from sanerf_hq_amd import _lib, raymarching as rm
+    enc, mlp, xyz, extra, w = _mask_head_case(gpu, N, T_, n_inst, L, E)
+    b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0).clone()
     try:
-        _lib.check(_lib.lib().sn_debug_set(b"mask_head16", 8), "debug_set")
-        b = rm.mask_head(w, xyz, extra, enc, mlp, 1.0).clone()
-        c = rm.mask_head(w, xyz, extra, enc, mlp, 1.0)
-    finally:
         _lib.check(_lib.lib().sn_debug_set(b"mask_head16", 0), "debug_set")
-    assert torch.equal(b, c)
+        a = rm.mask_head(w, xyz, extra, enc, mlp, 1.0).clone()
+    finally:
+        _lib.check(_lib.lib().sn_debug_set(b"mask_head16", 8), "debug_set")
     assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))

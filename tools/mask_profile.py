@@ -10,6 +10,9 @@ from helpers import product_model, synthetic_params  # noqa: E402
 from sanerf_hq_amd import raymarching as rm, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("SN_MASK16"):      # experiments builds: SN_MASK16=0 keeps the fused mask head on k_mlp_wide_j<3> (A/B partner of k_mask16, mlp16.inc)
+    from sanerf_hq_amd import _lib
+    _lib.check(_lib.lib().sn_debug_set(b"mask_head16", int(os.environ["SN_MASK16"])), "debug_set")
 mode = sys.argv[1] if len(sys.argv) > 1 else "mask"
 if mode == "mask":
     model = build(False, True, dev).eval()
