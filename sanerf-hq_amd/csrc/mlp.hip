@@ -32,21 +32,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-#ifndef SN_WIDE_DMA_EARLY
-#define SN_WIDE_DMA_EARLY 1  // the 4 LDS-DMA pieces of chunk g+3 right after the barrier instead of one per tile pair: 0.465 -> 0.450 ms (SAM head MLP, 160 000 rows)
-#endif
-#ifndef SN_WIDE_INTERLEAVE
-#define SN_WIDE_INTERLEAVE 1 // MFMAs of the two tiles of a pair alternate (1) or run tile by tile (0): A/B switch
-#endif
-#ifndef SN_WIDE_TILESEQ
-#define SN_WIDE_TILESEQ 1    // a tile's three MFMAs back to back on one accumulator (1) or two tiles' MFMAs alternating (0)
-#endif
-#ifndef SN_WIDE_PIPE
-#define SN_WIDE_PIPE 1       // synchronisation + first operand reads of chunk g+1 issued under the last tile pair of chunk g (A/B switch)
-#endif
-#ifndef SN_WIDE_ABLATE
-#define SN_WIDE_ABLATE 0     // timing experiments only (wrong results): 1 = no per-chunk barrier, 2 = no weight DMA after the prologue, 3 = both
-#endif
 constexpr int WIDE = 256;                 // hidden width this build instantiates
 constexpr int WIDE_MT = WIDE / 32;        // output tiles of a hidden layer
 constexpr int WIDE_HKS = WIDE / 16;       // k-steps that consume a hidden layer
@@ -300,7 +285,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     // one chunk = one k-step x 8 output tiles; the B operand is supplied by the caller
     // npairs: output-tile pairs the layer really has (a narrow last layer -- the mask head's 256 -> n_inst -- skips the
     // padded tiles: wave-uniform)
-#if SN_WIDE_PIPE
     // Software pipeline ACROSS chunks (round 3; cycle trace of workgroup 0 in profiles/r03/ab_round3_experiments.txt: a chunk took 1150
     // shader cycles against 768 of matrix-pipe time -- every chunk began with "wait for the DMA, workgroup barrier, read the first tile
     // pair's operands from LDS" fully exposed).  Now the synchronisation for chunk g+1 and the LDS reads of its first tile pair are issued
@@ -314,10 +298,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         else if (later == 1u) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : : : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
         static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
-#if !(SN_WIDE_ABLATE & 1)
         __syncthreads();                   // every wave's pieces of chunk gn are in LDS; buffer (gn+3)%4 (chunk gn-1) has been read by all
-#endif
-        if (gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
+        if (gn + 3u < total_chunks) {
             const uint4 *nsrc = a.pack + (size_t)(gn + 3u) * WIDE_CHUNK_U4 + tid;
             const uint32_t ndst = lds_w_off + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
 #pragma unroll
@@ -330,7 +312,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     };
     sync_and_prefetch(0u);
     prefetch_first_pair(0u);
-#if SN_WIDE_TILESEQ
     // tile by tile: the three products of a tile issue back to back on ONE accumulator (the matrix pipe forwards it: no accumulator
     // read / write-back between them), the next tile's two operand reads ride between them
     auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t /*npairs*/) {
@@ -366,48 +347,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         }
         ++g;
     };
-#else
-    auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t /*npairs*/) {
-        wide_trace(g);
-        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
-        const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
-        uint4 ah[2][2], al[2][2];
-        ah[0][0] = pah[0]; al[0][0] = pal[0]; ah[0][1] = pah[1]; al[0][1] = pal[1];
-        // ONE wave per SIMD issues in order: whatever sits between two MFMAs longer than one MFMA's 32 cycles leaves the matrix pipe idle
-        // (cycle trace: 4 ds_read_b128 + waits + a branch between tile pairs cost ~55 cycles per pair, 1000 instead of 768 cycles per chunk
-        // even with no LDS traffic at all).  So: straight-line code -- all four tile pairs always run (tiles beyond a narrower layer are
-        // zero padding from the packer, their results are never read) -- and the next pair's four operand reads are dealt out one per MFMA.
-#pragma unroll
-        for (int pr = 0; pr < WIDE_MT / 2; ++pr) {
-            const int cur = pr & 1, nxt = cur ^ 1;
-            const bool sync_here = pr + 1 == WIDE_MT / 2;
-            if (sync_here) {
-                if (g + 1u < total_chunks) sync_and_prefetch(g + 1u);
-                __builtin_amdgcn_sched_barrier(0);
-                prefetch_first_pair(g + 1u);               // same basic block as this pair's MFMAs: dealt out between them like the others
-            } else {
-                ah[nxt][0] = buf[(2 * pr + 2) * 128]; al[nxt][0] = buf[(2 * pr + 2) * 128 + 64];
-                ah[nxt][1] = buf[(2 * pr + 3) * 128]; al[nxt][1] = buf[(2 * pr + 3) * 128 + 64];
-            }
-            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cur][0]), A0l = __builtin_bit_cast(half8_t, al[cur][0]);
-            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cur][1]), A1l = __builtin_bit_cast(half8_t, al[cur][1]);
-            floatx16 c0 = acc[2 * pr], c1 = acc[2 * pr + 1];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
-            acc[2 * pr] = c0; acc[2 * pr + 1] = c1;
-            // issue order inside the pair: MFMA, LDS read, MFMA, LDS read, MFMA, LDS read, MFMA, LDS read, MFMA, MFMA
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ++g;
-    };
-#endif
     auto run_chunk4 = [&](const uint4 (&bh)[4], const uint4 (&bl)[4]) {
         wide_trace(g);
         const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
@@ -439,65 +378,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         acc[0] = c0; acc[1] = c1;
         ++g;
     };
-#else
-    auto run_chunk = [&](const uint4 &bh, const uint4 &bl, uint32_t npairs) {
-        wide_trace(g);
-        // chunk g has landed when at most the pieces of the chunks issued after it are still in flight
-        const uint32_t later = total_chunks - 1u - g;
-        if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
-        else if (later == 1u) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
-#if !(SN_WIDE_ABLATE & 1)
-        __syncthreads();                   // every wave's pieces of chunk g are in LDS; buffer (g+3)%4 (chunk g-1) is free
-#endif
-        const bool more = g + 3u < total_chunks && !(SN_WIDE_ABLATE & 2);
-        const uint4 *nsrc = a.pack + (size_t)(g + 3u) * WIDE_CHUNK_U4 + tid;
-        const uint32_t ndst = lds_w_off + ((g + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
-        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
-        // Output tiles are processed in pairs with their MFMAs interleaved (a tile's three products depend on each
-        // other through the accumulator: back to back they leave the matrix pipe idle between issues); the A tiles
-        // of the next pair are read one pair ahead, and the scheduling barrier keeps the compiler from hoisting all
-        // the chunk's LDS reads (64 registers) to its top
-        const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
-#if SN_WIDE_DMA_EARLY
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
-        }
-#endif
-        uint4 ah[2][2], al[2][2];
-        ah[0][0] = buf[0]; al[0][0] = buf[64]; ah[0][1] = buf[128]; al[0][1] = buf[192];
-#pragma unroll
-        for (int pr = 0; pr < WIDE_MT / 2; ++pr) {
-            const int cur = pr & 1, nxt = cur ^ 1;
-            if ((uint32_t)pr < npairs) {
-            if (pr + 1 < WIDE_MT / 2) {
-                ah[nxt][0] = buf[(2 * pr + 2) * 128]; al[nxt][0] = buf[(2 * pr + 2) * 128 + 64];
-                ah[nxt][1] = buf[(2 * pr + 3) * 128]; al[nxt][1] = buf[(2 * pr + 3) * 128 + 64];
-            }
-            const half8_t A0h = __builtin_bit_cast(half8_t, ah[cur][0]), A0l = __builtin_bit_cast(half8_t, al[cur][0]);
-            const half8_t A1h = __builtin_bit_cast(half8_t, ah[cur][1]), A1l = __builtin_bit_cast(half8_t, al[cur][1]);
-            floatx16 c0 = acc[2 * pr], c1 = acc[2 * pr + 1];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
-            acc[2 * pr] = c0; acc[2 * pr + 1] = c1;
-            }
-            // the 4 DMA pieces of chunk g+3 go out one per pair (their issue overlaps the matrix pipe)
-#if !SN_WIDE_DMA_EARLY
-            if (more) dma16(nsrc + pr * 256, ndst + (uint32_t)pr * 4096u);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        static_assert(PIECES == WIDE_MT / 2, "one DMA piece per output-tile pair");
-        ++g;
-    };
-
-#endif
 
     // XMODE 4: the upstream gradient rows span many orders of magnitude (a sample's weight multiplies its row) and values
     // below 2^-14 would lose their lo half to fp16 subnormals, so every row is scaled by a power of two that brings its
@@ -522,42 +402,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
         }
     }
 
-#if !SN_WIDE_PIPE
-    // A narrow last layer (the mask head's 256 -> n_inst: one tile pair) would stream 16 chunks of which 7/8 are zero
-    // padding -- 39 % of the whole weight stream of that MLP.  Its packed form holds 4 k-steps x 1 pair per chunk instead.
-    auto run_chunk4 = [&](const uint4 (&bh)[4], const uint4 (&bl)[4]) {
-        wide_trace(g);
-        const uint32_t later = total_chunks - 1u - g;
-        if (later >= 2u) asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
-        else if (later == 1u) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        __syncthreads();
-        const bool more = g + 3u < total_chunks;
-        const uint4 *nsrc = a.pack + (size_t)(g + 3u) * WIDE_CHUNK_U4 + tid;
-        const uint32_t ndst = lds_w_off + ((g + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) dma16(nsrc + i * 256, ndst + (uint32_t)i * 4096u);
-        }
-        const uint4 *buf = lds_w + (g % (uint32_t)WIDE_NBUF) * WIDE_CHUNK_U4 + lane;
-        floatx16 c0 = acc[0], c1 = acc[1];
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            const half8_t A0h = __builtin_bit_cast(half8_t, buf[sl * 256]), A0l = __builtin_bit_cast(half8_t, buf[sl * 256 + 64]);
-            const half8_t A1h = __builtin_bit_cast(half8_t, buf[sl * 256 + 128]), A1l = __builtin_bit_cast(half8_t, buf[sl * 256 + 192]);
-            const half8_t Bh = __builtin_bit_cast(half8_t, bh[sl]), Bl = __builtin_bit_cast(half8_t, bl[sl]);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0l, Bh, c0, 0, 0, 0);   // small terms first, as in run_chunk
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1l, Bh, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bl, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bl, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0h, Bh, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1h, Bh, c1, 0, 0, 0);
-        }
-        acc[0] = c0; acc[1] = c1;
-        ++g;
-    };
-
-#endif
     auto x_operand = [&](uint32_t kx, uint4 &bh, uint4 &bl) {            // x[n][16 kx + 8 half + 0..7], zero padded
         float v[8];
         const uint32_t c0 = 16u * kx + 8u * half;
@@ -600,14 +444,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             uint32_t p[3];
 #pragma unroll
             for (uint32_t d = 0; d < 3u; ++d) p[d] = (idx & (1u << d)) ? umin(cell[d] + 1u, res - 1u) : cell[d];
-#if SN_WIDE_ABLATE & 8          // timing experiment (wrong results): every corner reads row 0 of its level (same loads, perfect locality)
-            load_row<float, 8>(tab, r.cv[idx]);
-#elif SN_WIDE_ABLATE & 16       // timing experiment (wrong results): no gathers at all
-#pragma unroll
-            for (int c = 0; c < 8; ++c) r.cv[idx][c] = r.pos[c % 3] + (float)p[c % 3];
-#else
             load_row<float, 8>(tab + (size_t)grid_row<3>(p, res, size, mode) * 8u, r.cv[idx]);
-#endif
         }
     };
     auto blend_level = [&](uint32_t kx, const LevelRegs &r, uint4 &bh, uint4 &bl) {
@@ -899,12 +736,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
 // (A first version kept two accumulator sets used by alternate layers; the register allocator answered the 256 live accumulators
 // with whole-set copies at every layer boundary: 9-10 thousand cycles per layer change, profiles/r03/ab_round3_experiments.txt.)
 // ------------------------------------------------------------------------------------------
-#ifndef SN_WIDE_JIT
-#define SN_WIDE_JIT 1        // host default: 1 = k_mlp_wide_j for the forward modes; env SN_WIDE_JIT=0/1 overrides at run time
-#endif
-#ifndef SN_WIDE_REFILL_LATE
-#define SN_WIDE_REFILL_LATE 0 // where the four DMA pieces of chunk g+4 are issued: 0 = right after the barrier (tile 6), 1 = behind the last tile's MFMAs,
-#endif                        // 2 = one between / two behind the three MFMAs of the last tile.  Measured per h k-step: 1110 / 1160 / 1260 cycles
 #ifndef SN_WIDE_JV
 #define SN_WIDE_JV 8         // vector instructions the scheduler may place behind each MFMA of a tile
 #endif
@@ -1053,24 +884,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" : : : "memory");
         }
         static_assert(PIECES == 4 && WIDE_NBUF == 4, "the vmcnt immediates above assume 4 pieces per chunk, 3 chunks ahead");
-#if !(SN_WIDE_ABLATE & 1)
         __syncthreads();
-#endif
-#if SN_WIDE_REFILL_LATE == 0
-        if (gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
-            dma16x4(a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane, lds_w_off4 + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES);
-        }
-#endif
-    };
-    // refill the buffer chunk gn-1 was read from (every wave passed the barrier above after its last read of it) with chunk gn+3.
-    // Issued BEHIND the last tile's MFMAs: the four pieces cost ~100 cycles of address / m0 set-up that used to sit between two tiles
-    auto refill_piece = [&](uint32_t gn, int i) {
-        const uint4 *nsrc = a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane;
-        const uint32_t ndst = lds_w_off4 + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES;
-        dma16(nsrc + i * 64, ndst + (uint32_t)i * 1024u);
-    };
-    auto refill = [&](uint32_t gn) {
-        if (SN_WIDE_REFILL_LATE == 1 && gn + 3u < total_chunks && !(SN_WIDE_ABLATE & 2)) {
+        if (gn + 3u < total_chunks) {
             dma16x4(a.pack + (size_t)((gn + 3u) % tile_chunks) * WIDE_CHUNK_U4 + wave * 256u + lane, lds_w_off4 + ((gn + 3u) % (uint32_t)WIDE_NBUF) * CHUNK_BYTES);
         }
     };
@@ -1079,8 +894,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
         pah[0] = buf[0]; pal[0] = buf[64]; pah[1] = buf[128]; pal[1] = buf[192];
     };
     sync_and_prefetch(0u, int_tag<0>{});
-    refill(0u);
-    if (SN_WIDE_REFILL_LATE == 2 && 3u < total_chunks) { refill_piece(0u, 0); refill_piece(0u, 1); refill_piece(0u, 2); refill_piece(0u, 3); }
     prefetch_first_pair(0u);
 
     const float act_slope = a.leaky ? 0.01f : 0.0f;
@@ -1118,27 +931,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             const half8_t Ah = __builtin_bit_cast(half8_t, ah[cur]), Al = __builtin_bit_cast(half8_t, al[cur]);
             floatx16 c;
             if constexpr (FIRST) c = bias[cur]; else c = acc[mt];
-            if constexpr (mt + 1 == WIDE_MT && SN_WIDE_REFILL_LATE == 2) {
-                const bool more = g + 4u < total_chunks && !(SN_WIDE_ABLATE & 2);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) refill_piece(g + 1u, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) refill_piece(g + 1u, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) { refill_piece(g + 1u, 2); refill_piece(g + 1u, 3); }
-            } else {
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);   // small terms first
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, c, 0, 0, 0);
-            }
             acc[mt] = c;
             if constexpr (mt + 2 < WIDE_MT) {
-                if (!(SN_WIDE_ABLATE & 4)) { ah[cur] = buf[(mt + 2) * 128]; al[cur] = buf[(mt + 2) * 128 + 64]; }   // ablation 4: no weight reads from LDS (wrong results)
+                ah[cur] = buf[(mt + 2) * 128]; al[cur] = buf[(mt + 2) * 128 + 64];
                 if constexpr (FIRST) bias_tile(l, mt + 2, bias[cur]);
             } else if constexpr (mt + 2 == WIDE_MT) {
                 if (g + 1u < total_chunks) sync_and_prefetch(g + 1u, extra_tag);
@@ -1160,7 +958,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (g + 1u < total_chunks) refill(g + 1u);
         ++g;
     };
 
@@ -1404,8 +1201,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p) { bh[p] = nbh[p]; bl[p] = nbl[p]; }
                 });
-                if (g + 1u < total_chunks) refill(g + 1u);
-                if (SN_WIDE_REFILL_LATE == 2 && g + 4u < total_chunks) { refill_piece(g + 1u, 0); refill_piece(g + 1u, 1); refill_piece(g + 1u, 2); refill_piece(g + 1u, 3); }
                 ++g;
             });
             acc[0] = c0; acc[1] = c1;

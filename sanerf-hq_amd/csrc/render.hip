@@ -151,18 +151,11 @@ struct Corner { float v[C]; };
 // fp16 tables, C = 2: a fetched row stays PACKED (its half2 bit pattern in v[0]) and the blend multiplies it with
 // v_fma_mix_f32, which widens an f16 operand on the fly -- the same fp32 fma on the same exactly-converted value as
 // v_cvt_f32_f16 + v_fma_f32, so results are bit-identical, but the 16 conversions per level (256 of ~1500 vector
-// instructions per sample of the final stage, 80 of ~700 in a proposal stage) disappear.  SN_HALF_MIX=0: A/B switch.
-#ifndef SN_HALF_MIX
-#define SN_HALF_MIX 1
-#endif
-#ifndef SN_HALF_MIX_PKW
-#define SN_HALF_MIX_PKW 1    // final stage, fp16 tables: packed corner-weight products in front of the widening fmas
-#endif
+// instructions per sample of the final stage, 80 of ~700 in a proposal stage) disappear.
 template <typename T, int C>
 __device__ __forceinline__ void corner_set_half2(Corner<T, C> &c, uint32_t bits) {
     static_assert(C == 2 && sizeof(T) == 2, "packed rows: fp16 tables with two features per level");
-    if constexpr (SN_HALF_MIX) { c.v[0] = __uint_as_float(bits); c.v[1] = 0.0f; }
-    else { const __half2 h = *reinterpret_cast<const __half2 *>(&bits); c.v[0] = __low2float(h); c.v[1] = __high2float(h); }
+    c.v[0] = __uint_as_float(bits); c.v[1] = 0.0f;
 }
 __device__ __forceinline__ float fma_mix_lo(float w, uint32_t packed, float acc) {      // fmaf(w, (float)packed.lo, acc)
     float d;
@@ -181,15 +174,6 @@ __device__ __forceinline__ float fma_mix_hi(float w, uint32_t packed, float acc)
 // The half-waves therefore trade addresses with one v_permlane32_swap per corner pair: the first load serves BOTH
 // x-corners of lanes 0-31, the second those of lanes 32-63 -- about half the distinct lines per instruction, same
 // instruction count -- and blend_level_x swaps the fetched values back.
-#ifndef SN_XSWAP_FROM
-#define SN_XSWAP_FROM 0      // every hashed level (same-box A/B: 8.41 -> 7.78 ms for [128]; from level 9: 7.96, from 11: 8.19)
-#endif
-#ifndef SN_PAIR_ALIGNED
-#define SN_PAIR_ALIGNED 1    // A/B switch: aligned x-pair rows for the dense levels of the final stage (PairTab)
-#endif
-#ifndef SN_BLEND_PKW
-#define SN_BLEND_PKW 1       // packed corner-weight products in the final stage's blends, fp32 tables (same-box: 7.25 -> 7.19 ms; fp16 tables 6.75 -> 6.90, so not there)
-#endif
 #ifndef SN_PROP_GROUP
 #define SN_PROP_GROUP 2      // proposal stage: levels gathered in groups of 2 + 2 + 1.  History: all 5 at once spilled at 128 VGPRs; 3 + 2 fitted
                              // (4.70 -> 4.55 ms); 2 + 2 + 1 fits 96 VGPRs = 5 waves per SIMD instead of 4 (SN_PROP_WAVES): [128,64,32] 4.53 -> 4.44 ms fp32
@@ -197,19 +181,9 @@ __device__ __forceinline__ float fma_mix_hi(float w, uint32_t packed, float acc)
 #ifndef SN_PROP_GROUP_H
 #define SN_PROP_GROUP_H 2    // the same for fp16 tables (78 VGPRs): 4.10 -> 3.98 ms
 #endif
-#ifndef SN_FINAL_LV
-#define SN_FINAL_LV 1        // final stage, K > 0: host-precomputed level constants + wave-uniform interior fast path (FinalLv); A/B switch
-#endif
-#ifndef SN_XSWAP_DENSE
-#define SN_XSWAP_DENSE 0
-#endif
-#ifndef SN_XSWAP_HALF
-#define SN_XSWAP_HALF 1      // fp16 tables too, since rows stay packed (one swap per corner pair): [128] 6.24 -> 6.21 ms, last stage of [128,64,32]
-                             // 1.86 -> 1.81 ms (round 2, unpacked rows: -2 %)
-#endif
 template <typename T, int KIND, int l>
 constexpr bool xswap_level() {
-    return (KIND == 1 || (KIND == 0 && SN_XSWAP_DENSE)) && l >= SN_XSWAP_FROM && (sizeof(T) == 4 || SN_XSWAP_HALF);
+    return KIND == 1 && l >= 0;
 }
 __device__ __forceinline__ void half_wave_swap(uint32_t &a, uint32_t &b) {
     // a' = [a.lanes0-31 | b.lanes0-31], b' = [a.lanes32-63 | b.lanes32-63]
@@ -302,9 +276,9 @@ template <typename T, int C, bool PKW = false>
 __device__ __forceinline__ void blend_level(const float (&pos)[3], const Corner<T, C> (&cv)[8], float (&acc)[C]) {
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
-    if constexpr (SN_HALF_MIX && C == 2 && sizeof(T) == 2) {   // packed fp16 rows (corner_set_half2): widening fma, same order
+    if constexpr (C == 2 && sizeof(T) == 2) {   // packed fp16 rows (corner_set_half2): widening fma, same order
         float w[8];
-        if constexpr (SN_HALF_MIX_PKW && PKW) {                // the 8 corner weights as 6 packed multiplies: every weight still (wx * wy) * wz
+        if constexpr (PKW) {                // the 8 corner weights as 6 packed multiplies: every weight still (wx * wy) * wz
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 wx = {1.0f - pos[0], pos[0]};
             const float wy0 = 1.0f - pos[1], wz0 = 1.0f - pos[2];
@@ -398,7 +372,7 @@ __device__ __forceinline__ bool encode_grouped(const T *__restrict__ table, cons
         static_for<0, GN>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int KIND = K < 0 ? -1 : ((l0 + k) < K ? 0 : 1);
-            issue_level<T, C, KIND, (PAIR && K > 0 && K <= 8 && SN_PAIR_ALIGNED)>(table, g, l0 + k, x01, pos[k], cv[k], pt);
+            issue_level<T, C, KIND, (PAIR && K > 0 && K <= 8)>(table, g, l0 + k, x01, pos[k], cv[k], pt);
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -431,7 +405,7 @@ __device__ __forceinline__ void issue_group(const T *__restrict__ table, const G
         constexpr int k = decltype(kk)::value;
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
-        issue_level<T, C, KIND, (K > 0 && K <= 8 && SN_PAIR_ALIGNED), xswap_level<T, KIND, l>()>(table, g, l, x01, r.pos[k], r.cv[k], &pt);
+        issue_level<T, C, KIND, (K > 0 && K <= 8), xswap_level<T, KIND, l>()>(table, g, l, x01, r.pos[k], r.cv[k], &pt);
     });
 }
 
@@ -442,8 +416,8 @@ __device__ __forceinline__ void blend_group(const GroupRegs<T, C, G> &r, Emit em
         constexpr int l = GRP * G + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
         float acc[C];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, C, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, C, true>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, C, true>(r.pos[k], r.cv[k], acc);
         emit(l, acc);
     });
 }
@@ -560,22 +534,13 @@ __device__ __forceinline__ void blend_span(const GroupRegs<T, 2, G> &r, Emit emi
         constexpr int l = L0 + k;
         constexpr int KIND = K < 0 ? -1 : (l < K ? 0 : 1);
         float acc[2];
-        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
-        else blend_level<T, 2, (SN_BLEND_PKW && (sizeof(T) == 4 || SN_HALF_MIX_PKW))>(r.pos[k], r.cv[k], acc);
+        if constexpr (xswap_level<T, KIND, l>()) blend_level_x<T, 2, true>(r.pos[k], r.cv[k], acc);
+        else blend_level<T, 2, true>(r.pos[k], r.cv[k], acc);
         emit(l, acc);
     });
 }
 // gather spans of the final stage (FinalLv path).  Span 0 is issued for sample j+1 before the matrix-core phase of sample j
 // (its registers are live across that phase), so it has to be short when the MLP needs many registers; it must be all dense.
-#ifndef SN_FINAL_SPANS
-#define SN_FINAL_SPANS 0
-#endif
-#ifndef SN_LT_TWO_PASS
-#define SN_LT_TWO_PASS 0     // linear tail, fp32 tables: 1 = composite tile by tile, 0 = one compositing pass (tile 0's activations held across tile 1's matrix phase)
-#endif
-#ifndef SN_LT_TWO_PASS_H
-#define SN_LT_TWO_PASS_H 0   // the same for fp16 tables (same-box: [128] 6.37 ms tile by tile, 6.31 ms in one pass; per-sample form 6.61 ms)
-#endif
 #ifndef SN_FINAL_SPANS_LT_H
 #define SN_FINAL_SPANS_LT_H 4  // the same for fp16 tables
 #endif
@@ -785,16 +750,6 @@ __device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &
 #ifndef SN_PROP_PB
 #define SN_PROP_PB 4         // cdf entries per block of the sample_pdf merge (pass 2 of the proposal stage); 8: same, 16: slower (select chains)
 #endif
-#ifndef SN_PROP_MFMA
-#define SN_PROP_MFMA 0       // proposal MLP layer 1 on v_mfma_f32_32x32x2_f32, B operands of both 32-sample tiles from one v_permlane32_swap per
-                             // k-step, no LDS (round 3): bit-identical (sigma / inds tests green), 150 fewer vector instructions per sample, and
-                             // SLOWER -- prop0 1.32 -> 1.60 ms, prop1 0.70 -> 0.83 ms (fp16 tables; 4 waves without spills: 1.62 / 0.86): five
-                             // dependent 64-cycle MFMAs + a 16-step fma chain hopping between the half-waves lengthen the per-wave dependent
-                             // chain that bounds this stage (as the LDS-transposed 16x16x4 attempt of round 2 did)
-#endif
-#ifndef SN_PROP_ABLATE_PASS2
-#define SN_PROP_ABLATE_PASS2 0
-#endif
 #ifndef SN_PROP_WAVES
 #define SN_PROP_WAVES 5      // waves per SIMD the proposal stage is compiled for (register budget 512 / N in steps of 8: 96 VGPRs); the
                              // stage is bound by each wave's dependent chain, so a fifth wave buys 3-4 % (profiles/r02/ab_round2_experiments.txt)
@@ -833,17 +788,6 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
     double cum = 0.0, wacc = 0.0;
     const TT *table = reinterpret_cast<const TT *>(a.table);
-#if SN_PROP_MFMA
-    // matrix-core operands of the 10-16-1 MLP: this lane's column of W0 per k-step, and W1 at the hidden rows its accumulator registers hold
-    float pa[5], pw1[8];
-    {
-        const uint32_t m = threadIdx.x & 31u, kh = (threadIdx.x >> 5) & 1u;
-#pragma unroll
-        for (int s5 = 0; s5 < 5; ++s5) pa[s5] = (IN == 10 && m < (uint32_t)HID) ? a.w0[m * (uint32_t)IN + 2u * (uint32_t)s5 + kh] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pw1[q] = a.w1[(uint32_t)(q & 3) + 8u * (uint32_t)(q >> 2) + 4u * kh];
-    }
-#endif
     for (uint32_t j = 0; j < T; ++j) {
         const float bnext = bin_at(j + 1);
         const float rb_next = real_bin(rs, bnext);
@@ -853,52 +797,6 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
         float feat[L * C];
         encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : SN_PROP_GROUP_H)>(table, a.g, x01, feat, &a.pairs);
         float raw[1];
-#if SN_PROP_MFMA
-        if constexpr (IN == 10 && HID == 16) {
-            // layer 1 (10 -> 16) on v_mfma_f32_32x32x2_f32: D[m][n] += A[m][k] B[k][n], five k-steps of 2.  Lane l supplies A[m = l&31][k = l>>5]
-            // (loop-invariant registers pa[]) and B[k = l>>5][n = l&31]: one v_permlane32_swap per k-step turns the lanes' own features
-            // (2s, 2s+1) into the B operands of BOTH 32-sample tiles.  fp32 MFMA accumulates c + a0*b0 + a1*b1 as an ascending fma chain, i.e.
-            // the oracle's order (asserted bit for bit by the sigma / inds tests).  The vector ALU, which bounds this stage, loses 176 fmas + 44
-            // LDS weight reads and keeps 16 relu + 32 fma + 12 swaps.
-            floatx16 h0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, h1 = h0;
-#pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                auto bb = __builtin_amdgcn_permlane32_swap(__float_as_uint(feat[2 * s5]), __float_as_uint(feat[2 * s5 + 1]), false, false);
-                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s5], __uint_as_float(bb[0]), h0, 0, 0, 0);
-                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s5], __uint_as_float(bb[1]), h1, 0, 0, 0);
-            }
-            // layer 2 (16 -> 1): ONE m-ascending fma chain per sample.  Accumulator register q of a lane is hidden row (q&3) + 8 (q>>2) + 4 (l>>5):
-            // rows 0-3 and 8-11 sit in the low half-wave, 4-7 and 12-15 in the high one, so the running sum hops between the halves three times.
-            float x0[8], x1[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { x0[q] = __builtin_fmaxf(h0[q], 0.0f); x1[q] = __builtin_fmaxf(h1[q], 0.0f); }
-            float t0 = 0.0f, t1 = 0.0f;
-            auto seg = [&](int q0) {
-#pragma unroll
-                for (int q = q0; q < q0 + 4; ++q) { t0 = __builtin_fmaf(pw1[q], x0[q], t0); t1 = __builtin_fmaf(pw1[q], x1[q], t1); }
-            };
-            auto up = [&]() {      // low half -> high half (the low half's copies become don't-care)
-                auto u0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t0), false, false);
-                auto u1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1), __float_as_uint(t1), false, false);
-                t0 = __uint_as_float(u0[0]); t1 = __uint_as_float(u1[0]);
-            };
-            auto down = [&]() {    // high half -> low half
-                auto u0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t0), false, false);
-                auto u1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1), __float_as_uint(t1), false, false);
-                t0 = __uint_as_float(u0[1]); t1 = __uint_as_float(u1[1]);
-            };
-            seg(0);                                       // rows 0-3   (valid in the low half)
-            up();
-            { const bool hi_half = (threadIdx.x & 32u) != 0u; t0 = hi_half ? t0 : 0.0f; t1 = hi_half ? t1 : 0.0f; }
-            seg(0);                                       // rows 4-7   (high half continues the chain; the low half restarts from 0: unused)
-            down();
-            seg(4);                                       // rows 8-11  (low half)
-            up();
-            seg(4);                                       // rows 12-15 (high half): the finished sums of BOTH tiles sit in the high half
-            auto fin = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t1), false, false);
-            raw[0] = __uint_as_float(fin[1]);             // lanes 0-31: tile 0 (their own samples), lanes 32-63: tile 1
-        } else
-#endif
         {
             float h[HID];
             const uint32_t oz = opaque_zero();
@@ -939,9 +837,6 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     // (the former one-entry-at-a-time merge chained T dependent global loads per ray and cost 19 % of the stage), its PB
     // prefix values are formed in the oracle's order (fp64 running sum of the pdf, rounded per prefix, clamped at 1), and
     // every lane then emits the outputs whose searchsorted(right=True) count falls inside the block.
-#if SN_PROP_ABLATE_PASS2
-    return;   // timing experiment only
-#endif
     const float wsum = (float)wacc;
     const uint32_t Tq = a.Tn + 1u;
     const float ustart = (float)(0.5 / Tq), uend = (float)(1 - 0.5 / Tq);
@@ -1329,23 +1224,9 @@ __global__ void k_pack_grid_mlp_f16(const float *__restrict__ w1, const float *_
     pack[(vec * 2u + 1u) * 64u + lane] = pl;
 }
 
-#ifndef SN_FINAL_ABLATE
-#define SN_FINAL_ABLATE 0    // timing / power experiments only (wrong results): 1 = no matrix-core MLP in k_final_stage, 2 = one weight read
-                             // per layer (no LDS weight stream), 4 = matrix instructions replaced by a vector op, 8 = two products of three
-#endif
 __device__ __forceinline__ floatx16 mfma3(const uint4 &ah, const uint4 &al, const uint4 &bh, const uint4 &bl, floatx16 acc) {
     const half8_t Ah = __builtin_bit_cast(half8_t, ah), Al = __builtin_bit_cast(half8_t, al);
     const half8_t Bh = __builtin_bit_cast(half8_t, bh), Bl = __builtin_bit_cast(half8_t, bl);
-#if SN_FINAL_ABLATE & 4
-    acc[0] += __uint_as_float((ah.x ^ bh.x) & 0x3fffffffu); acc[5] += __uint_as_float((al.y ^ bl.y) & 0x3fffffffu);
-    acc[9] += __uint_as_float((ah.z ^ bl.z) & 0x3fffffffu); acc[14] += __uint_as_float((al.w ^ bh.w) & 0x3fffffffu);
-    return acc;
-#endif
-#if SN_FINAL_ABLATE & 8
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
-    return acc;
-#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);   // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
@@ -1378,7 +1259,7 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
             for (int st = 0; st < 2; ++st) {
                 const uint4 bh = *reinterpret_cast<const uint4 *>(slab_hi + row + 8 * st);
                 const uint4 bl = *reinterpret_cast<const uint4 *>(slab_lo + row + 8 * st);
-                const int vec = (SN_FINAL_ABLATE & 2) ? 0 : mt * 2 + st;
+                const int vec = mt * 2 + st;
                 acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
             }
             h1[mt] = acc;
@@ -1391,33 +1272,20 @@ __device__ __forceinline__ void grid_mlp_mfma16(const uint4 *__restrict__ pk, co
             for (int q = 0; q < 4; ++q) {
                 uint4 bh, bl;
                 acc_to_b(h1[q >> 1], q & 1, bh, bl);
-                const int vec = (SN_FINAL_ABLATE & 2) ? 4 : 4 + mt * 4 + q;
+                const int vec = 4 + mt * 4 + q;
                 acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
             }
             h2[mt] = acc;
             __builtin_amdgcn_sched_barrier(0);
         }
         floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#if SN_FINAL_ABLATE & 16
-        // timing experiment: layer 3 off the matrix cores -- 64 relu + 64 fma (dot) + 64 fma (accumulate) of vector work instead
-        {
-            float d0 = 0.0f, d1 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float x0 = relu_bits(h2[0][i]), x1 = relu_bits(h2[1][i]);
-                d0 = __builtin_fmaf(x0, __uint_as_float(0x3c000000u + i), d0); d1 = __builtin_fmaf(x1, __uint_as_float(0x3c100000u + i), d1);
-                acc[i & 7] = __builtin_fmaf(d0, x0, acc[i & 7]); acc[(i + 3) & 7] = __builtin_fmaf(d1, x1, acc[(i + 3) & 7]);
-            }
-        }
-#else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 bh, bl;
             acc_to_b(h2[q >> 1], q & 1, bh, bl);
-            const int vec = (SN_FINAL_ABLATE & 2) ? 12 : 12 + q;
+            const int vec = 12 + q;
             acc = mfma3(pk[(vec * 2 + 0) * 64 + lane], pk[(vec * 2 + 1) * 64 + lane], bh, bl, acc);
         }
-#endif
 #pragma unroll
         for (int r = 0; r < 8; ++r) res[tile][r] = acc[r];
         __builtin_amdgcn_sched_barrier(0);
@@ -1601,13 +1469,8 @@ __device__ __forceinline__ void stage_w3p(float *__restrict__ dst, const float *
     }
 }
 // sum_i w[i] * x[i] over the lane's 32 hidden rows: four interleaved ascending fmaf chains, combined (s0 + s1) + (s2 + s3)
-#ifndef SN_LT_PK
-#define SN_LT_PK 1           // linear tail: the four partial chains of the dot products and the accumulator update as packed fp32 fmas (same
-                             // per-element arithmetic, half the issue slots)
-#endif
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot32_lds(const float *__restrict__ w, const float (&x)[32]) {
-#if SN_LT_PK
     f2v s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
 #pragma unroll
     for (int i4 = 0; i4 < 8; ++i4) {
@@ -1616,16 +1479,6 @@ __device__ __forceinline__ float dot32_lds(const float *__restrict__ w, const fl
         s23 = __builtin_elementwise_fma(f2v{ww.z, ww.w}, f2v{x[4 * i4 + 2], x[4 * i4 + 3]}, s23);
     }
     return (s01.x + s01.y) + (s23.x + s23.y);
-#else
-    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int i4 = 0; i4 < 8; ++i4) {
-        const float4 ww = *reinterpret_cast<const float4 *>(w + 4 * i4);
-        s[0] = __builtin_fmaf(ww.x, x[4 * i4 + 0], s[0]); s[1] = __builtin_fmaf(ww.y, x[4 * i4 + 1], s[1]);
-        s[2] = __builtin_fmaf(ww.z, x[4 * i4 + 2], s[2]); s[3] = __builtin_fmaf(ww.w, x[4 * i4 + 3], s[3]);
-    }
-    return (s[0] + s[1]) + (s[2] + s[3]);
-#endif
 }
 
 // hash-grid features of one position, split into f16 hi / lo and written to this lane's slab rows
@@ -1675,9 +1528,6 @@ __device__ __forceinline__ void encode_levels_lds(const T *__restrict__ table, c
 }
 
 enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
-#ifndef SN_FINAL_2T
-#define SN_FINAL_2T 0        // final stage (FinalLv path): both tiles of the wave share every weight read (grid_mlp_mfma16_2t)
-#endif
 #ifndef SN_RS_SPANS_H
 #define SN_RS_SPANS_H 6      // role-split producers, fp16 tables: 6 spans like fp32 tables, or 4 spans of 4 levels
 #endif
@@ -1796,8 +1646,8 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
     if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
     // software pipeline (MLP_F16X3): group 0 of sample j+1 is issued before the matrix-core phase of sample j
     constexpr int PG = 4;                                   // levels per gather group (generic instantiations)
-    constexpr bool LV = SN_FINAL_LV && MODE == MLP_F16X3 && K >= PG && K <= 8;   // FinalLv path; the prefetched span is all dense
-    using SP = FinalSpans<LV ? (LT ? (sizeof(TT) == 2 ? SN_FINAL_SPANS_LT_H : SN_FINAL_SPANS_LT) : SN_FINAL_SPANS) : 0>;   // FinalLv path: gather spans (span 0 crosses the matrix-core phase)
+    constexpr bool LV = MODE == MLP_F16X3 && K >= PG && K <= 8;   // FinalLv path; the prefetched span is all dense
+    using SP = FinalSpans<LV ? (LT ? (sizeof(TT) == 2 ? SN_FINAL_SPANS_LT_H : SN_FINAL_SPANS_LT) : 0) : 0>;   // FinalLv path: gather spans (span 0 crosses the matrix-core phase)
     constexpr int G0 = LV ? SP::B[1] : PG;
     static_assert(!LV || (L == 16 && SP::B[SP::N] == L && G0 <= K), "spans cover the 16 levels; span 0 is dense");
     GroupRegs<TT, 2, G0> g0;
@@ -1889,14 +1739,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_wave_barrier();
-#if SN_FINAL_ABLATE & 1
-            for (int k = 0; k < NOUT; ++k) h[k] = __uint_as_float(row_hi[k] ^ row_lo[k]);
-#elif SN_FINAL_2T
-            if constexpr (LV) grid_mlp_mfma16_2t(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
-            else grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
-#else
             if constexpr (!LT) grid_mlp_mfma16(reinterpret_cast<const uint4 *>(lds) + opaque_zero(), slab_hi, slab_lo, h);
-#endif
             __builtin_amdgcn_wave_barrier();
         } else if constexpr (MODE == MLP_F32) {
             encode_levels_lds<TT, L, C, 2, K>(table, a.g, x01, fe, fstride);
@@ -1912,7 +1755,7 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
 #pragma unroll
             for (int k = 0; k < NOUT; ++k) h[k] = actB[k * fstride];
         }
-        if constexpr (LT && (sizeof(TT) == 2 ? SN_LT_TWO_PASS_H : SN_LT_TWO_PASS)) {
+        if constexpr (LT && (sizeof(TT) == 2 ? 0 : 0)) {
             // tile by tile: layers 1-2, density dot, the compositing step of that tile's home lanes, the accumulator update -- the
             // 32 activations of tile 0 are dead before tile 1's matrix phase begins (one compositing pass over both tiles would hold
             // them across it: 32 registers the kernel does not have)
@@ -3038,17 +2881,21 @@ static BandPlan band_plan(const sn_render_cfg *cfg, uint32_t N, uint32_t W) {
     return p;
 }
 
-static hipStream_t band_side_stream() {
+// One library-owned side stream per (device, CALLER stream): two host threads that render on different streams of a device get different side
+// streams (a shared one would serialise them, and a thread that forks it while capturing a graph would pull the other thread's launches into its
+// capture -- advisor, round 4); callers that share a stream are ordered by that stream anyway.
+static hipStream_t band_side_stream(hipStream_t caller) {
     static std::mutex mu;
-    static std::map<int, hipStream_t> streams;
+    static std::map<std::pair<int, hipStream_t>, hipStream_t> streams;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = streams.find(dev);
+    const auto key = std::make_pair(dev, caller);
+    auto it = streams.find(key);
     if (it != streams.end()) return it->second;
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
-    streams[dev] = s;
+    streams[key] = s;
     return s;
 }
 
@@ -3059,7 +2906,7 @@ struct BandFork {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     BandFork(hipStream_t m, bool want) : main_st(m) {
         if (!want) return;
-        hipStream_t s = band_side_stream();
+        hipStream_t s = band_side_stream(m);
         if (!s) return;
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) { ev_fork = nullptr; return; }
         if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ev_fork); ev_fork = ev_join = nullptr; return; }
@@ -3550,7 +3397,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         const bool eo = cfg->tuning.exact_early_out == 2;
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
-        const int Kmain = (SN_FINAL_LV && !lv_ok) ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
+        const int Kmain = !lv_ok ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
         // few rays in linear order: lanes share rays (k_final_stage_sp); fewer samples per lane while CUs would idle
         const bool final_sp = W == 0 && mlp_mode == MLP_F16X3 && fa.stop_cum == 0.0f && !use_cmp && n <= final_sp_max_rays(cfg) &&
                               fa.T <= 64u * FSP_MAX_SPL;
