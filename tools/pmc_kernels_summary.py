@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""One line per kernel from the counter passes of tools/gpu_pmc_kernels.sh (profiles/<round>/pmc_kernels_*.txt): cycles per launch (GRBM_GUI_ACTIVE / 8 XCDs),
+MfmaUtil, VALUBusy, texture-address busy (TA_TA_BUSY_sum / 256 CUs / cycles), gather instructions, L1 accesses per gather instruction, L2 hit rate, FETCH / WRITE.
+usage: python tools/pmc_kernels_summary.py profiles/r05 > profiles/r05/pmc_kernels_summary.txt"""
+import os
+import re
+import sys
+
+d0 = sys.argv[1]
+sets = (("pmc_kernels_mask_head.txt", ("k_mask16",)), ("pmc_kernels_c3_sam_head.txt", ("k_feat_stage",)),
+        ("pmc_kernels_train_mask.txt", ("k_bin_scatter", "k_bin_accum", "k_linear_wgrad_mfma", "k_mlp_wide")),
+        ("pmc_kernels_ref_f16.txt", ("k_prop_stage", "k_final_stage")), ("pmc_kernels_flat128_f16.txt", ("k_final_stage",)))
+print("workload      kernel               cycles/launch  (ms at 2.3 GHz)  MfmaUtil VALUBusy TA-busy  gather-instr  L1-acc/instr  L2-hit  FETCH_SIZE  WRITE_SIZE")
+for f, ks in sets:
+    path = os.path.join(d0, f)
+    if not os.path.exists(path):
+        continue
+    d = {}
+    for ln in open(path):
+        m = re.match(r"(\S+)\s+(\S+)\s+dispatches=\s*(\d+) mean=(\S+)", ln)
+        if m:
+            d[(m.group(1), m.group(2))] = float(m.group(4))
+    for k in ks:
+        g = lambda c: d.get((k, c), float("nan"))   # noqa: E731
+        act = g("GRBM_GUI_ACTIVE") / 8
+        hit = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) * 100
+        print(f"{f[12:-4]:13s} {k:20s} {act:13.0f}  {act / 2.3e6:15.3f}  {g('MfmaUtil'):8.1f} {g('VALUBusy'):8.1f} {g('TA_TA_BUSY_sum') / 256 / act * 100:6.1f}%  {g('SQ_INSTS_VMEM_RD'):12.4g}  "
+              f"{g('TCP_TOTAL_CACHE_ACCESSES_sum') / max(g('SQ_INSTS_VMEM_RD'), 1):12.1f}  {hit:5.1f}%  {g('FETCH_SIZE'):10.4g}  {g('WRITE_SIZE'):10.4g}")
