@@ -37,14 +37,35 @@
 
 namespace sn {
 
-constexpr uint32_t BIN_FLOATS = 16128;          // contribution floats one work item holds in LDS (63 KiB; with the counters and the small static arrays just under 80 KiB): E_CAP = 16128 / C entries
-constexpr uint32_t BIN_ROWS_MAX = 4096;         // rows per bin (LDS counters of k_bin_accum: 16 KiB; with the 64 KiB above two workgroups per CU)
+#ifndef SN_BIN_FLOATS
+#define SN_BIN_FLOATS 12096
+#define SN_BIN_ROWS_MAX 1024
+#define SN_BIN_WGS 3
+#define SN_BIN_FILL 1.3
+#endif
+constexpr uint32_t BIN_FLOATS = SN_BIN_FLOATS;          // contribution floats one work item holds in LDS (63 KiB; with the counters and the small static arrays just under 80 KiB): E_CAP = 16128 / C entries
+constexpr uint32_t BIN_ROWS_MAX = SN_BIN_ROWS_MAX;         // rows per bin (LDS counters of k_bin_accum: 16 KiB; with the 64 KiB above two workgroups per CU)
 constexpr uint32_t BIN_MAX_PER_LEVEL = 4096;    // LDS histogram of the count / scatter kernels
 constexpr uint32_t SPT = 4;                     // samples per thread of the count / scatter kernels (1024 samples = 8192 pairs per block)
 constexpr uint32_t PLAN_THREADS = 256;
 constexpr uint32_t SMALL_BIN_FLOATS = 256;      // split bins up to this size flush with global atomics instead of slabs + merge
 
 __host__ __device__ constexpr uint32_t e_cap(uint32_t C) { return BIN_FLOATS / C; }
+
+#ifndef SN_BIN_TRACE
+#define SN_BIN_TRACE 0       // diagnostics build: a few workgroups of k_bin_scatter / k_bin_accum record the shader clock at every phase (sn_bin_debug_trace)
+#endif
+#if SN_BIN_TRACE
+__device__ unsigned long long g_bin_trace[2][16][16];     // [kernel][traced workgroup][phase]
+__device__ __forceinline__ void bin_trace(uint32_t kernel, uint32_t wg, uint32_t n_wg, uint32_t slot) {
+    if (threadIdx.x != 0 || slot >= 16u) return;
+    const uint32_t stride = n_wg / 16u ? n_wg / 16u : 1u;
+    if (wg % stride == 0u && wg / stride < 16u) g_bin_trace[kernel][wg / stride][slot] = __builtin_readcyclecounter();
+}
+#define BIN_TRACE(k, wg, n, slot) bin_trace(k, wg, n, slot)
+#else
+#define BIN_TRACE(k, wg, n, slot) ((void)0)
+#endif
 
 struct BinGeom {
     uint32_t shift[SN_MAX_LEVELS];   // log2(rows per bin) of each level
@@ -54,6 +75,8 @@ struct BinGeom {
     uint32_t C;
 };
 
+int g_bin_pull = -1;            // -1: by C (host code below); 0 / 1: sn_debug_set("bin_pull", v) in experiments builds (A/B)
+
 struct BinHdr { uint32_t n_items, n_shared_items, n_shared_bins, n_entries; };
 struct BinItem { uint32_t level_bin, begin, end, slab_off; };   // slab_off = first float of the item's partial-sum slab, or ~0u: the item owns its bin
 struct BinShared { uint32_t level_bin, slab_off, n_slabs, item0, begin, end, pad0, pad1; };   // a split bin: n_slabs items (first one = item item0 of the work list) of E_CAP
@@ -62,6 +85,9 @@ struct BinShared { uint32_t level_bin, slab_off, n_slabs, item0, begin, end, pad
 // FAST (D = 3, grids of the fused kernels' shape -- levels_fast(): hashed levels of power-of-two size, dense levels over all three dimensions,
 // align_corners = False, linear interpolation): the 8 rows come from 6 partial terms (corner_offsets: 2 full-rate 24-bit multiplies per
 // level) instead of 8 calls of the generic grid_row (7 quarter-rate v_mul_lo_u32 per corner: 56 per sample-level).  Same rows, same weights.
+template <uint32_t D, bool FAST>
+__device__ __forceinline__ void pair_rows_at(const float (&x01)[D], const GridLevels &g, uint32_t level, uint32_t (&row)[1u << D], float (&w)[1u << D]);
+
 template <uint32_t D, bool FAST>
 __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint32_t b, const GridLevels &g, uint32_t level,
                                           uint32_t (&row)[1u << D], float (&w)[1u << D]) {
@@ -73,6 +99,12 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
         oob |= (x01[d] < 0 || x01[d] > 1);
     }
     if (oob) return false;                                        // gridencoder.cu:290: no gradient outside [0,1]
+    pair_rows_at<D, FAST>(x01, g, level, row, w);
+    return true;
+}
+
+template <uint32_t D, bool FAST>
+__device__ __forceinline__ void pair_rows_at(const float (&x01)[D], const GridLevels &g, uint32_t level, uint32_t (&row)[1u << D], float (&w)[1u << D]) {
     const uint32_t res = g.res[level], size = g.size[level], mode = g.mode[level];
     if constexpr (FAST && D == 3) {
         float pos[3];
@@ -83,7 +115,7 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
         const float wx[2] = {1.0f - pos[0], pos[0]}, wy[2] = {1.0f - pos[1], pos[1]}, wz[2] = {1.0f - pos[2], pos[2]};
 #pragma unroll
         for (uint32_t idx = 0; idx < 8u; ++idx) w[idx] = (wx[idx & 1u] * wy[(idx >> 1) & 1u]) * wz[idx >> 2];     // gridencoder.cu:315-327: ((1 wx) wy) wz
-        return true;
+        return;
     } else {
     float pos[D], deriv[D];
     uint32_t cell[D];
@@ -101,7 +133,6 @@ __device__ __forceinline__ bool pair_rows(const float *__restrict__ inputs, uint
         row[idx] = grid_row<D>(p, res, size, mode);
         w[idx] = ww;
     }
-    return true;
     }
 }
 
@@ -112,7 +143,7 @@ __global__ __launch_bounds__(256) void k_bin_zero(uint32_t *__restrict__ p, uint
 
 template <uint32_t D, bool FAST>
 __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inputs, uint32_t B, GridLevels g, BinGeom bg,
-                                                   uint32_t *__restrict__ counts) {
+                                                   uint32_t *__restrict__ counts, uint32_t *__restrict__ blkcnt, uint32_t total_bins) {
     SN_POISON_ALL();
     __shared__ uint32_t hist[BIN_MAX_PER_LEVEL];
     const uint32_t level = blockIdx.y, nb = bg.nb[level], shift = bg.shift[level];
@@ -129,9 +160,38 @@ __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ inp
         }
     }
     __syncthreads();
+    if (blkcnt) {                 // the block's histogram row, zeros included (k_bin_colscan turns the column of a bin into the blocks' first slots)
+        for (uint32_t i = threadIdx.x; i < nb; i += 256u) blkcnt[(size_t)blockIdx.x * total_bins + bg.boff[level] + i] = hist[i];
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < nb; i += 256u) {
         const uint32_t c = hist[i];
         if (c) atomicAdd(&counts[bg.boff[level] + i], c);
+    }
+}
+
+// Per-(block, bin) counts -> the block's first slot inside the bin (exclusive running sum down the column of the bin) and the bin's total.
+// Why (round 5): handing out slots with one global atomic per non-empty (block, bin) -- 2 x 1 M atomics for the mask-field step, on 8 k
+// addresses -- cost ~50 us in k_bin_count + the scatter at the measured ceiling of device-scope atomics (2.1e10 lane-ops/s); the matrix is
+// 4 MB written, read, rewritten and read again.  A workgroup = 32 bins x 8 runs of blocks; coalesced over bins.
+__global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ blkcnt, uint32_t n_blk, uint32_t total_bins, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t part[8][32];
+    const uint32_t bx = threadIdx.x & 31u, ch = threadIdx.x >> 5, bin = blockIdx.x * 32u + bx;
+    const uint32_t per = (n_blk + 7u) >> 3, k0 = umin(ch * per, n_blk), k1 = umin(k0 + per, n_blk);
+    uint32_t sum = 0;
+    if (bin < total_bins) for (uint32_t k = k0; k < k1; ++k) sum += blkcnt[(size_t)k * total_bins + bin];
+    part[ch][bx] = sum;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; ++q) { const uint32_t v = part[q][bx]; if (q < ch) base += v; all += v; }
+    if (bin >= total_bins) return;
+    if (ch == 0u) counts[bin] = all;
+    for (uint32_t k = k0; k < k1; ++k) {
+        uint32_t *p = blkcnt + (size_t)k * total_bins + bin;
+        const uint32_t c = *p;
+        *p = base;
+        base += c;
     }
 }
 
@@ -256,11 +316,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_emit(const uint32_t *
 template <uint32_t D, uint32_t C, bool FAST>
 __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ inputs, const float *__restrict__ grad, uint32_t B,
                                                      GridLevels g, BinGeom bg, int layout, uint32_t *__restrict__ cursor,
+                                                     const uint32_t *__restrict__ blkbase, uint32_t total_bins,
                                                      uint16_t *__restrict__ ekey, float *__restrict__ econtrib) {
     SN_POISON_ALL();
     constexpr uint32_t NC = 1u << D;
     __shared__ uint32_t hist[BIN_MAX_PER_LEVEL];                 // phase 1: pairs of this block per bin; phase 2: the block's first slot per bin
     const uint32_t level = blockIdx.y, nb = bg.nb[level], shift = bg.shift[level];
+    const uint32_t t_wg = blockIdx.y * gridDim.x + blockIdx.x, t_n = gridDim.x * gridDim.y;
+    (void)t_wg; (void)t_n;
+    BIN_TRACE(0, t_wg, t_n, 0);
     for (uint32_t i = threadIdx.x; i < nb; i += 256u) hist[i] = 0u;
     __syncthreads();
     uint32_t row[SPT][NC], rank[SPT][NC];
@@ -275,12 +339,16 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ i
             for (uint32_t i = 0; i < NC; ++i) rank[s][i] = atomicAdd(&hist[row[s][i] >> shift], 1u);
         }
     }
+    BIN_TRACE(0, t_wg, t_n, 1);
     __syncthreads();
+    BIN_TRACE(0, t_wg, t_n, 2);
     for (uint32_t i = threadIdx.x; i < nb; i += 256u) {
         const uint32_t c = hist[i];
-        if (c) hist[i] = atomicAdd(&cursor[bg.boff[level] + i], c);
+        if (c) hist[i] = blkbase ? cursor[bg.boff[level] + i] + blkbase[(size_t)blockIdx.x * total_bins + bg.boff[level] + i]
+                                 : atomicAdd(&cursor[bg.boff[level] + i], c);
     }
     __syncthreads();
+    BIN_TRACE(0, t_wg, t_n, 3);
     const uint32_t mask = (1u << shift) - 1u;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
@@ -333,6 +401,110 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ i
             }
         }
     }
+#if SN_BIN_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    BIN_TRACE(0, t_wg, t_n, 4);
+}
+
+// PULL form of step 3 (round 5): the entry is a REFERENCE -- {sample | row-in-bin << 22, corner weight}, 8 bytes -- instead of the 2-byte row
+// and the C-float product.  k_bin_pull then fetches the sample's gradient row itself and multiplies.  Why: with C = 8 the products are 32
+// bytes per pair -- 537 MB written and read again for the 16.8 M pairs of the mask-field step -- and the 2-byte rows, scattered one by one,
+// each cost a 32-byte sector (counters: 921 MB written by k_bin_scatter against 570 MB of payload).  References are 134 MB each way.
+// Scattered 8-byte stores would be amplified just like the rows, so the block sorts its references by bin in LDS first (ranks and a
+// block-local scan of the histogram) and writes them out in runs: a (block, bin) run is consecutive in the bin's slot range, so a wave's
+// store covers a few whole runs.  512 threads x 2 samples = the 1024 samples per block of k_bin_count (same blockIdx.x -> same matrix row).
+constexpr uint32_t REF_THREADS = 512, REF_SPT = 256u * SPT / REF_THREADS;
+constexpr uint32_t REF_WINDOW = 4096;                           // positions of the block's sorted order staged in LDS at a time
+constexpr uint32_t REF_KEY_SHIFT = 22;                           // sample index below, row inside the bin above: B <= 2^22, rows per bin <= 2^10
+static_assert(BIN_ROWS_MAX <= (1u << (32u - REF_KEY_SHIFT)), "row-in-bin must fit above the sample index");
+
+template <uint32_t D, bool FAST>
+__global__ __launch_bounds__(REF_THREADS, 2) void k_bin_refs(const float *__restrict__ inputs, uint32_t B, GridLevels g, BinGeom bg,
+                                                  uint32_t *__restrict__ cursor, const uint32_t *__restrict__ blkbase, uint32_t total_bins,
+                                                  uint2 *__restrict__ eref) {
+    SN_POISON_ALL();
+    constexpr uint32_t NC = 1u << D, NPW = REF_WINDOW;
+    static_assert(256u * SPT <= 1024u && BIN_MAX_PER_LEVEL <= 4096u && BIN_ROWS_MAX <= 1024u, "the LDS record packs bin (12 bits), row in bin (10) and sample in block (10)");
+    __shared__ uint32_t hist[BIN_MAX_PER_LEVEL];                 // pairs of this block per bin -> the block's first slot of the bin
+    __shared__ uint32_t lbase[BIN_MAX_PER_LEVEL];                // first position of the bin in the block's sorted order
+    __shared__ uint32_t wsum[REF_THREADS / 64u];
+    extern __shared__ __attribute__((aligned(16))) uint32_t rec[];   // [NPW] records (bin << 20 | row in bin << 10 | sample in block) then [NPW] weights: a window of the block's pairs sorted by bin
+    float *wrec = reinterpret_cast<float *>(rec + NPW);
+    const uint32_t level = blockIdx.y, nb = bg.nb[level], shift = bg.shift[level], kmask = (1u << shift) - 1u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t t_wg = blockIdx.y * gridDim.x + blockIdx.x, t_n = gridDim.x * gridDim.y;
+    (void)t_wg; (void)t_n;
+    BIN_TRACE(0, t_wg, t_n, 0);
+    for (uint32_t i = tid; i < nb; i += REF_THREADS) hist[i] = 0u;
+    __syncthreads();
+    uint32_t row[REF_SPT][NC], rank[REF_SPT][NC];
+    float w[REF_SPT][NC];
+    bool live[REF_SPT];
+#pragma unroll
+    for (uint32_t s = 0; s < REF_SPT; ++s) {
+        const uint32_t b = blockIdx.x * (256u * SPT) + s * REF_THREADS + tid;
+        live[s] = b < B && pair_rows<D, FAST>(inputs, b, g, level, row[s], w[s]);
+        if (live[s]) {
+#pragma unroll
+            for (uint32_t i = 0; i < NC; ++i) rank[s][i] = atomicAdd(&hist[row[s][i] >> shift], 1u);
+        }
+    }
+    BIN_TRACE(0, t_wg, t_n, 1);
+    __syncthreads();
+    BIN_TRACE(0, t_wg, t_n, 2);
+    uint32_t total;
+    {   // block-local exclusive scan of the histogram (thread t owns a run of bins), and the block's slots from the bins' cursors
+        const uint32_t per = (nb + REF_THREADS - 1u) / REF_THREADS, lo = umin(tid * per, nb), hi = umin(lo + per, nb);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; ++i) sum += hist[i];
+        uint32_t inc = sum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+        if (lane == 63u) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = inc - sum;
+        total = 0;
+#pragma unroll
+        for (uint32_t w2 = 0; w2 < REF_THREADS / 64u; ++w2) { const uint32_t v = wsum[w2]; if (w2 < wave) base += v; total += v; }
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t c = hist[i];
+            lbase[i] = base;
+            base += c;
+            if (c) hist[i] = blkbase ? cursor[bg.boff[level] + i] + blkbase[(size_t)blockIdx.x * total_bins + bg.boff[level] + i]
+                                     : atomicAdd(&cursor[bg.boff[level] + i], c);
+        }
+    }
+    __syncthreads();
+    BIN_TRACE(0, t_wg, t_n, 3);
+    // the sorted order leaves through a WINDOW of NPW positions at a time (two rounds for a full block): 32 KiB of records instead of 64, so that
+    // two of these workgroups fit a CU (each is a chain of barrier-separated phases; alone on a CU nothing overlaps them)
+    const uint32_t b0 = blockIdx.x * (256u * SPT);
+    for (uint32_t p0 = 0; p0 < total; p0 += NPW) {
+#pragma unroll
+        for (uint32_t s = 0; s < REF_SPT; ++s) {
+            if (!live[s]) continue;
+#pragma unroll
+            for (uint32_t i = 0; i < NC; ++i) {
+                const uint32_t bn = row[s][i] >> shift, q = lbase[bn] + rank[s][i] - p0;
+                if (q < NPW) {
+                    rec[q] = (bn << 20) | ((row[s][i] & kmask) << 10) | (s * REF_THREADS + tid);
+                    wrec[q] = w[s][i];
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nq = umin(NPW, total - p0);
+        for (uint32_t q = tid; q < nq; q += REF_THREADS) {
+            const uint32_t v = rec[q], bn = v >> 20;
+            eref[hist[bn] + (p0 + q - lbase[bn])] = make_uint2((b0 + (v & 1023u)) | (((v >> 10) & 1023u) << REF_KEY_SHIFT), __float_as_uint(wrec[q]));
+        }
+        __syncthreads();
+    }
+#if SN_BIN_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    BIN_TRACE(0, t_wg, t_n, 4);
 }
 
 template <uint32_t C>
@@ -354,47 +526,34 @@ __device__ __forceinline__ void store_row(float *dst, const float (&v)[C]) {
 //   c. every entry takes slot end[row]++ and parks its contribution there   (ds_add_rtn_u32; afterwards end[r] = one past row r's last slot)
 //   d. rows are summed from LDS by the thread(s) that own them: one thread per row when the bin has >= 256 rows, else 256 / rows threads per
 //      row (coarse levels: a bin of 4 rows holds ~1000 entries) folded with wave shuffles and, beyond 64 threads per row, one LDS hop.
-template <uint32_t C>
-__global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__ hdr, const BinItem *__restrict__ items, const BinShared *__restrict__ shared_bins,
-                                                      GridLevels g, BinGeom bg,
-                                                      const uint16_t *__restrict__ ekey, const float *__restrict__ econtrib,
-                                                      float *__restrict__ slabs, float *__restrict__ grad_table) {
-    SN_POISON_ALL();
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
-    const BinHdr h = *hdr;
-    if (blockIdx.x >= h.n_items) return;
-    BinItem it;
-    if (blockIdx.x < h.n_shared_items) {         // an item of a split bin: bisect the records' first-item indices (ascending)
-        uint32_t lo = 0, hi = h.n_shared_bins;
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (shared_bins[mid].item0 <= blockIdx.x) lo = mid; else hi = mid; }
-        const BinShared sb = shared_bins[lo];
-        const uint32_t j = blockIdx.x - sb.item0, b0 = sb.begin + j * bg.ecap;
-        it = BinItem{sb.level_bin, b0, umin(b0 + bg.ecap, sb.end),
-                     sb.slab_off == 0xffffffffu ? 0xfffffffeu : sb.slab_off + j * (bg.C << bg.shift[sb.level_bin >> 16])};   // ...fe: small split bin, atomics
-    } else it = items[blockIdx.x];
-    const uint32_t level = it.level_bin >> 16, bin = it.level_bin & 0xffffu, shift = bg.shift[level], brows = 1u << shift;
-    uint32_t *end = lds_u;
-    float *sorted = reinterpret_cast<float *>(lds_u + BIN_ROWS_MAX);
-    __shared__ uint32_t wsum[4];
-    __shared__ float red[4][C];
+// The phases are device functions shared by the two kernels that feed them: k_bin_accum (entries = products, one item per workgroup) and
+// k_bin_pull (entries = references, persistent workgroups that fetch the next item's operands under the current item's phases).
+struct BinPull { const float *grad; const uint2 *eref; uint32_t B; int layout; };
+
+__device__ __forceinline__ BinItem bin_item_of(uint32_t i, const BinHdr &h, const BinItem *__restrict__ items, const BinShared *__restrict__ shared_bins, const BinGeom &bg) {
+    if (i >= h.n_shared_items) return items[i];
+    uint32_t lo = 0, hi = h.n_shared_bins;          // an item of a split bin: bisect the records' first-item indices (ascending)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (shared_bins[mid].item0 <= i) lo = mid; else hi = mid; }
+    const BinShared sb = shared_bins[lo];
+    const uint32_t j = i - sb.item0, b0 = sb.begin + j * bg.ecap;
+    return BinItem{sb.level_bin, b0, umin(b0 + bg.ecap, sb.end),
+                   sb.slab_off == 0xffffffffu ? 0xfffffffeu : sb.slab_off + j * (bg.C << bg.shift[sb.level_bin >> 16])};   // ...fe: small split bin, atomics
+}
+
+// a + b: afterwards end[r] = first sorted slot of row r.  Starts with a barrier (a persistent workgroup's previous item is still being summed).
+template <uint32_t EPT>
+__device__ __forceinline__ void bin_count_scan(uint32_t *end, uint32_t brows, const uint32_t (&key)[EPT], uint32_t *wsum, uint32_t t_wg, uint32_t t_n) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // all of this thread's entries (keys and contributions: EPT * C = 63 floats) are requested before anything waits on them:
-    // one exposed memory latency per item instead of one per phase
-    constexpr uint32_t EPT = (e_cap(C) + 255u) / 256u;
-    uint32_t key[EPT];
-    float val[EPT][C];
-#pragma unroll
-    for (uint32_t j = 0; j < EPT; ++j) {
-        const uint32_t e = it.begin + j * 256u + tid;
-        const bool in = e < it.end;
-        key[j] = in ? (uint32_t)ekey[e] : 0xffffffffu;
-        load_row<float, (int)C>(econtrib + (size_t)(in ? e : it.begin) * C, val[j]);
-    }
+    (void)t_wg; (void)t_n;
+    __syncthreads();
     for (uint32_t i = tid; i < brows; i += 256u) end[i] = 0u;
     __syncthreads();
+    BIN_TRACE(1, t_wg, t_n, 1);
 #pragma unroll
     for (uint32_t j = 0; j < EPT; ++j) if (key[j] != 0xffffffffu) atomicAdd(&end[key[j]], 1u);
+    BIN_TRACE(1, t_wg, t_n, 2);
     __syncthreads();
+    BIN_TRACE(1, t_wg, t_n, 3);
     {   // exclusive scan over brows counters: thread t owns the run [t * per, (t + 1) * per)
         const uint32_t per = (brows + 255u) >> 8, lo = umin(tid * per, brows), hi = umin(lo + per, brows);
         uint32_t sum = 0;
@@ -409,12 +568,15 @@ __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__
         for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = end[i]; end[i] = base; base += c; }
     }
     __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < EPT; ++j) {
-        if (key[j] == 0xffffffffu) continue;
-        const uint32_t slot = atomicAdd(&end[key[j]], 1u);
-        store_row<C>(sorted + (size_t)slot * C, val[j]);
-    }
+    BIN_TRACE(1, t_wg, t_n, 4);
+}
+
+// d (after a barrier): sums and stores.
+template <uint32_t C>
+__device__ __forceinline__ void bin_sum_store(const BinItem &it, const GridLevels &g, const BinGeom &bg, const uint32_t *end, const float *sorted,
+                                              float (*red)[C], float *__restrict__ slabs, float *__restrict__ grad_table) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t level = it.level_bin >> 16, bin = it.level_bin & 0xffffu, shift = bg.shift[level], brows = 1u << shift;
     __syncthreads();
     const uint32_t row0 = bin << shift, rows = umin(brows, g.size[level] - row0);
     const bool to_slab = it.slab_off < 0xfffffffeu, atomic_out = it.slab_off == 0xfffffffeu;
@@ -472,6 +634,104 @@ __global__ __launch_bounds__(256, 2) void k_bin_accum(const BinHdr *__restrict__
             } else store_row<C>(out + (size_t)r * C, acc);
         }
     }
+}
+
+template <uint32_t C>
+__global__ __launch_bounds__(256, SN_BIN_WGS) void k_bin_accum(const BinHdr *__restrict__ hdr, const BinItem *__restrict__ items, const BinShared *__restrict__ shared_bins,
+                                                      GridLevels g, BinGeom bg,
+                                                      const uint16_t *__restrict__ ekey, const float *__restrict__ econtrib,
+                                                      float *__restrict__ slabs, float *__restrict__ grad_table) {
+    SN_POISON_ALL();
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    const BinHdr h = *hdr;
+    if (blockIdx.x >= h.n_items) return;
+    const BinItem it = bin_item_of(blockIdx.x, h, items, shared_bins, bg);
+    BIN_TRACE(1, blockIdx.x, h.n_items, 0);
+    const uint32_t level = it.level_bin >> 16, brows = 1u << bg.shift[level];
+    uint32_t *end = lds_u;
+    float *sorted = reinterpret_cast<float *>(lds_u + BIN_ROWS_MAX);
+    __shared__ uint32_t wsum[4];
+    __shared__ float red[4][C];
+    const uint32_t tid = threadIdx.x;
+    // all of this thread's entries (keys and contributions: EPT * C floats) are requested before anything waits on them:
+    // one exposed memory latency per item instead of one per phase
+    constexpr uint32_t EPT = (e_cap(C) + 255u) / 256u;
+    uint32_t key[EPT];
+    float val[EPT][C];
+#pragma unroll
+    for (uint32_t j = 0; j < EPT; ++j) {
+        const uint32_t e = it.begin + j * 256u + tid;
+        const bool in = e < it.end;
+        key[j] = in ? (uint32_t)ekey[e] : 0xffffffffu;
+        load_row<float, (int)C>(econtrib + (size_t)(in ? e : it.begin) * C, val[j]);
+    }
+    bin_count_scan<EPT>(end, brows, key, wsum, blockIdx.x, h.n_items);
+#pragma unroll
+    for (uint32_t j = 0; j < EPT; ++j) {
+        if (key[j] == 0xffffffffu) continue;
+        const uint32_t slot = atomicAdd(&end[key[j]], 1u);
+        store_row<C>(sorted + (size_t)slot * C, val[j]);
+    }
+    BIN_TRACE(1, blockIdx.x, h.n_items, 5);
+    bin_sum_store<C>(it, g, bg, end, sorted, red, slabs, grad_table);
+#if SN_BIN_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    BIN_TRACE(1, blockIdx.x, h.n_items, 7);
+}
+
+// References in, rows out (entries made by k_bin_refs): per entry one gather of the sample's gradient row (C floats), one multiply by the
+// stored corner weight -- the product the reference hands to atomicAdd (gridencoder.cu:340) -- then the same LDS phases as k_bin_accum.
+// (A persistent, software-pipelined form -- next item's rows requested under the current item's summation -- was built and measured slower
+// than letting three resident workgroups per CU overlap each other: 228 vs 207 us, profiles/r05/bin_stats_*.txt.)
+template <uint32_t C>
+__global__ __launch_bounds__(256, SN_BIN_WGS) void k_bin_pull(const BinHdr *__restrict__ hdr, const BinItem *__restrict__ items, const BinShared *__restrict__ shared_bins,
+                                                     GridLevels g, BinGeom bg, BinPull pull, float *__restrict__ slabs, float *__restrict__ grad_table) {
+    SN_POISON_ALL();
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    constexpr uint32_t EPT = (e_cap(C) + 255u) / 256u;
+    const BinHdr h = *hdr;
+    if (blockIdx.x >= h.n_items) return;
+    const BinItem it = bin_item_of(blockIdx.x, h, items, shared_bins, bg);
+    BIN_TRACE(1, blockIdx.x, h.n_items, 0);
+    const uint32_t level = it.level_bin >> 16, brows = 1u << bg.shift[level];
+    uint32_t *end = lds_u;
+    float *sorted = reinterpret_cast<float *>(lds_u + BIN_ROWS_MAX);
+    __shared__ uint32_t wsum[4];
+    __shared__ float red[4][C];
+    const uint32_t tid = threadIdx.x;
+    uint2 ref[EPT];
+#pragma unroll
+    for (uint32_t j = 0; j < EPT; ++j) {
+        const uint32_t e = it.begin + j * 256u + tid;
+        ref[j] = e < it.end ? pull.eref[e] : make_uint2(0xffffffffu, 0u);
+    }
+    uint32_t key[EPT];
+    float val[EPT][C];
+#pragma unroll
+    for (uint32_t j = 0; j < EPT; ++j) {
+        const bool in = ref[j].x != 0xffffffffu;
+        const uint32_t b = in ? ref[j].x & ((1u << REF_KEY_SHIFT) - 1u) : 0u;
+        key[j] = in ? ref[j].x >> REF_KEY_SHIFT : 0xffffffffu;
+        if (in) load_row<float, (int)C>(pull.layout == SN_LAYOUT_LBC ? pull.grad + ((size_t)level * pull.B + b) * C : pull.grad + ((size_t)b * g.L + level) * C, val[j]);
+    }
+    bin_count_scan<EPT>(end, brows, key, wsum, blockIdx.x, h.n_items);
+#pragma unroll
+    for (uint32_t j = 0; j < EPT; ++j) {
+        if (key[j] == 0xffffffffu) continue;
+        const uint32_t slot = atomicAdd(&end[key[j]], 1u);
+        const float ww = __uint_as_float(ref[j].y);
+        float v[C];
+#pragma unroll
+        for (uint32_t q = 0; q < C; ++q) v[q] = ww * val[j][q];
+        store_row<C>(sorted + (size_t)slot * C, v);
+    }
+    BIN_TRACE(1, blockIdx.x, h.n_items, 5);
+    bin_sum_store<C>(it, g, bg, end, sorted, red, slabs, grad_table);
+#if SN_BIN_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    BIN_TRACE(1, blockIdx.x, h.n_items, 7);
 }
 
 // A split bin's rows = the sum of its items' slabs.  Coarse bins are small (4 rows x 8 channels) and split into MANY items, fine bins large
@@ -535,7 +795,7 @@ static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, u
         const uint64_t size = (uint64_t)(offsets_host[l + 1] - offsets_host[l]);
         if (size == 0 || size >= (1ull << 31)) return false;
         const double density = (double)B * (double)(1u << D) / (double)size;
-        double target = (double)bg->ecap / (2.0 * density);
+        double target = (double)bg->ecap / (SN_BIN_FILL * density);
         uint32_t s = 0;
         while ((2u << s) <= rmax && (double)(2u << s) <= target) ++s;
         while (((size + (1ull << s) - 1) >> s) > BIN_MAX_PER_LEVEL) { if ((2u << s) > rmax) return false; ++s; }
@@ -551,12 +811,15 @@ static bool bin_geometry(BinGeom *bg, const int32_t *offsets_host, uint32_t B, u
 }
 
 struct BinLayout {
-    size_t counts, cursor, hdr, block_sums, items, shared_bins, ekey, econtrib, slabs, total;
+    size_t counts, cursor, hdr, block_sums, items, shared_bins, ekey, econtrib, slabs, blkcnt, total;
+    uint32_t n_blk;            // 0: slots from global atomics (the per-block matrix would be too large)
     uint32_t max_items, max_shared_bins, total_bins;
 };
 
 // worst-case sizes: items <= n / E_CAP + bins; split bins <= n / E_CAP; slab floats: bin_geometry's bound
-static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t slab_floats) {
+constexpr uint64_t BLK_MATRIX_MAX = 16ull << 20;    // (blocks x bins) entries of the per-block count matrix: 64 MiB
+
+static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t slab_floats, uint32_t B) {
     BinLayout l;
     const uint32_t cap = e_cap(C);
     l.total_bins = (uint32_t)bins_used;
@@ -572,6 +835,9 @@ static BinLayout bin_layout(uint64_t n, uint32_t C, uint64_t bins_used, uint64_t
     l.ekey = o; o += align256((size_t)n * 2);
     l.econtrib = o; o += align256((size_t)n * C * 4);
     l.slabs = o; o += align256((size_t)(slab_floats + 64) * 4);
+    const uint64_t nblk = div_up(B, 256u * SPT);
+    l.n_blk = nblk * bins_used <= BLK_MATRIX_MAX ? (uint32_t)nblk : 0u;
+    l.blkcnt = o; o += align256((size_t)l.n_blk * l.total_bins * 4);
     l.total = o + 256;
     return l;
 }
@@ -591,7 +857,7 @@ size_t sn_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t 
     uint64_t bins_used = 0, slab_floats = 0;
     if (!bin_geometry(&bg, offsets_host, B, D, C, max_level, &bins_used, &slab_floats)) return 0;   // a level beyond 4096 bins of 4096 rows: use the atomic path
     if (slab_floats >= 0xffffff00ull) return 0;                                                       // slab offsets are 32-bit: use the atomic path
-    return bin_layout(n, C, bins_used, slab_floats).total;
+    return bin_layout(n, C, bins_used, slab_floats, B).total;
 }
 
 int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
@@ -616,7 +882,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
                   BIN_MAX_PER_LEVEL, BIN_ROWS_MAX);
         return SN_ERR_UNSUPPORTED;
     }
-    const BinLayout lay = bin_layout(n64, C, bins_used, slab_floats);
+    const BinLayout lay = bin_layout(n64, C, bins_used, slab_floats, B);
     SN_REQUIRE(table_aligned(grad) && table_aligned(workspace), "grid_encode_backward_binned: grad / workspace must be 16-byte aligned");
     if (workspace_bytes < lay.total) { set_error("grid_encode_backward_binned: workspace too small (%zu bytes, need %zu)", workspace_bytes, lay.total); return SN_ERR_WORKSPACE; }
     char *w = reinterpret_cast<char *>(workspace);
@@ -627,12 +893,14 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     uint16_t *ekey = reinterpret_cast<uint16_t *>(w + lay.ekey);
     float *econtrib = reinterpret_cast<float *>(w + lay.econtrib), *slabs = reinterpret_cast<float *>(w + lay.slabs);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bin_zero, dim3(div_up(lay.total_bins, 256u)), dim3(256), 0, st, counts, lay.total_bins);   // (a kernel, not hipMemsetAsync: one node type in a captured graph)
+    uint32_t *blkcnt = lay.n_blk ? reinterpret_cast<uint32_t *>(w + lay.blkcnt) : nullptr;
+    if (!blkcnt) hipLaunchKernelGGL(k_bin_zero, dim3(div_up(lay.total_bins, 256u)), dim3(256), 0, st, counts, lay.total_bins);   // (a kernel, not hipMemsetAsync: one node type in a captured graph)
     const dim3 gs(div_up(B, 256u * SPT), max_level), blk(256);
     const bool fast = D == 3 && levels_fast(g);          // branch-free row addressing (pair_rows)
-    if (D == 3 && fast) hipLaunchKernelGGL((k_bin_count<3, true>), gs, blk, 0, st, inputs, B, g, bg, counts);
-    else if (D == 3) hipLaunchKernelGGL((k_bin_count<3, false>), gs, blk, 0, st, inputs, B, g, bg, counts);
-    else hipLaunchKernelGGL((k_bin_count<2, false>), gs, blk, 0, st, inputs, B, g, bg, counts);
+    if (D == 3 && fast) hipLaunchKernelGGL((k_bin_count<3, true>), gs, blk, 0, st, inputs, B, g, bg, counts, blkcnt, lay.total_bins);
+    else if (D == 3) hipLaunchKernelGGL((k_bin_count<3, false>), gs, blk, 0, st, inputs, B, g, bg, counts, blkcnt, lay.total_bins);
+    else hipLaunchKernelGGL((k_bin_count<2, false>), gs, blk, 0, st, inputs, B, g, bg, counts, blkcnt, lay.total_bins);
+    if (blkcnt) hipLaunchKernelGGL(k_bin_colscan, dim3(div_up(lay.total_bins, 32u)), dim3(256), 0, st, blkcnt, lay.n_blk, lay.total_bins, counts);
     SN_LAUNCH_CHECK("k_bin_count");
     uint32_t *block_sums = reinterpret_cast<uint32_t *>(w + lay.block_sums);
     const dim3 gp(div_up(lay.total_bins, PLAN_BLOCK_BINS));
@@ -641,12 +909,34 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     SN_LAUNCH_CHECK("k_bin_plan");
     const size_t lds = (size_t)(BIN_ROWS_MAX + BIN_FLOATS) * sizeof(float);      // 80 KiB: two workgroups per CU
     const dim3 ga(lay.max_items), gm(lay.max_shared_bins < 2048u ? lay.max_shared_bins : 2048u);
+    // entries as products (push) or as references (pull, k_bin_refs): references pay when a product is long (C >= 8: 32+ bytes per pair);
+    // a reference holds the sample index in 22 bits
+    const bool pull = (g_bin_pull < 0 ? C >= 8u : g_bin_pull != 0) && C >= 2u && B <= (1u << REF_KEY_SHIFT);   // (C >= 2: the references live in the products' region)
+    uint2 *eref = reinterpret_cast<uint2 *>(econtrib);
+    const BinPull bp{grad, eref, B, layout};
+    constexpr size_t refs_lds = (size_t)REF_WINDOW * 2 * sizeof(uint32_t);
+    const dim3 blk_refs(REF_THREADS);
+#define SN_BIN_ACC(CC)                                                                                                           \
+    do {                                                                                                                         \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accum<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_bin_accum<CC>), ga, blk, lds, st, hdr, items, shared_bins, g, bg, ekey, econtrib, slabs, grad_embeddings); \
+    } while (0)
+#define SN_BIN_REFS(DD, FAST)                                                                                                    \
+    do {                                                                                                                         \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_refs<DD, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)refs_lds)); \
+        hipLaunchKernelGGL((k_bin_refs<DD, FAST>), gs, blk_refs, refs_lds, st, inputs, B, g, bg, cursor, blkcnt, lay.total_bins, eref); \
+    } while (0)
 #define SN_BIN_C(DD, CC)                                                                                                         \
     do {                                                                                                                         \
-        if (DD == 3 && fast) hipLaunchKernelGGL((k_bin_scatter<DD, CC, DD == 3>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, ekey, econtrib); \
-        else hipLaunchKernelGGL((k_bin_scatter<DD, CC, false>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, ekey, econtrib);     \
-        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accum<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_bin_accum<CC>), ga, blk, lds, st, hdr, items, shared_bins, g, bg, ekey, econtrib, slabs, grad_embeddings);      \
+        if (pull) {                                                                                                              \
+            if (DD == 3 && fast) SN_BIN_REFS(DD, DD == 3); else SN_BIN_REFS(DD, false);                                          \
+            SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pull<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_bin_pull<CC>), ga, blk, lds, st, hdr, items, shared_bins, g, bg, bp, slabs, grad_embeddings);  \
+        } else {                                                                                                                 \
+            if (DD == 3 && fast) hipLaunchKernelGGL((k_bin_scatter<DD, CC, DD == 3>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, blkcnt, lay.total_bins, ekey, econtrib); \
+            else hipLaunchKernelGGL((k_bin_scatter<DD, CC, false>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, blkcnt, lay.total_bins, ekey, econtrib); \
+            SN_BIN_ACC(CC);                                                                                                      \
+        }                                                                                                                        \
         hipLaunchKernelGGL((k_bin_merge<CC>), gm, blk, 0, st, hdr, shared_bins, g, bg, slabs, grad_embeddings);                  \
     } while (0)
 #define SN_BIN_D(DD)                                                                                                             \
@@ -655,8 +945,17 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     if (D == 3) { SN_BIN_D(3) } else { SN_BIN_D(2) }
 #undef SN_BIN_D
 #undef SN_BIN_C
+#undef SN_BIN_ACC
+#undef SN_BIN_REFS
     SN_LAUNCH_CHECK("k_bin_scatter / k_bin_accum / k_bin_merge");
     return SN_OK;
 }
+
+#if SN_BIN_TRACE
+int sn_bin_debug_trace(unsigned long long *out) {
+    SN_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_trace), sizeof(unsigned long long) * 2 * 16 * 16));
+    return SN_OK;
+}
+#endif
 
 }  // extern "C"

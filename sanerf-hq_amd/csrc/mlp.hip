@@ -1374,6 +1374,7 @@ extern "C" int sn_debug_set(const char *key, int value) {
     if (strcmp(key, "wide_jit") == 0) { g_wide_jit = value; return SN_OK; }
     if (strcmp(key, "wide_narrow1") == 0) { g_wide_narrow1 = value; return SN_OK; }
     if (strcmp(key, "mask_head16") == 0) { g_mask_head16 = value; return SN_OK; }
+    if (strcmp(key, "bin_pull") == 0) { g_bin_pull = value; return SN_OK; }          // grid_binned.hip: entries as products (0) or references (1); -1 = by C
     set_error("debug_set: unknown key '%s'", key);
     return SN_ERR_INVALID;
 #else

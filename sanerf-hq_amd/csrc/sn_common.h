@@ -307,4 +307,6 @@ static inline bool levels_fast(const GridLevels &g) {
 }
 
 
+extern int g_bin_pull;        // grid_binned.hip (entry form of the binned grid backward; set by sn_debug_set in experiments builds)
+
 }  // namespace sn
