@@ -383,6 +383,14 @@ int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights,
                     float bound, const sn_grid_desc *grid, const sn_mlp_desc *mlp, float *out,
                     void *workspace, size_t workspace_bytes, sn_stream_t stream);
 
+/* Training-time forward of a bias-free perceptron with 256-wide hidden layers and no skip connections (nerf/network.py:31-66: F.linear +
+ * activation per layer; the per-sample mask head in training, network.py:118-123, trainer.py:401-428) in ONE kernel, true fp32 products
+ * and accumulation on the matrix cores (v_mfma_f32_32x32x2_f32; results differ from a BLAS GEMM only by summation order).
+ * x [N, dims[0]] (dims[0] <= 256) -> out [N, dims[nl]] (<= 256, linear); hidden[l] [N, 256] for l < nl-1 receives the POST-activation output
+ * of layer l -- what torch's in-place activation leaves for autograd, and what sn_mlp_wide_backward / sn_linear_wgrad read.
+ * hidden is a host array of nl-1 device pointers.  All tensors row-major fp32, no alignment requirement beyond 4 bytes. */
+int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out, sn_stream_t stream);
+
 /* Backward-data pass of a 256-wide perceptron without skip layers (the autograd of nerf/network.py:31-66 for the per-sample
  * mask head in training, trainer.py:401-428) in one kernel: grad_out [N, dims[nl]] -> grad_in [N, dims[0]], and for every
  * hidden layer l < nl-1 grad_hidden[l] [N, 256] = d loss / d (pre-activation of layer l) -- what sn_linear_wgrad needs.

@@ -1350,6 +1350,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     }
 }
 
+#include "mlp_f32.inc"   // k_mlp_f32_train: the training forward in true fp32 on the matrix cores, activations fused, hidden outputs saved (round 5)
 #include "mlp16.inc"     // k_mask16: the fused mask head on 16-row tiles, two waves per SIMD, tile pipeline (round 5)
 
 // Which forward kernel: k_mlp_wide_j (operands just in time; SAM head MLP 0.449 -> 0.433 ms, mask MLP 0.119 -> 0.114 ms, 400x400 mask render
@@ -1549,6 +1550,34 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
 // run over the transposed weights in reverse layer order; the activation step is the mask from the forward's saved
 // outputs, so no rounding difference can flip a LeakyReLU branch (which is what rules out a split-fp16 FORWARD under the
 // 1e-3 gradient bar).
+extern "C" int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out, sn_stream_t stream) {
+    SN_REQUIRE(mlp, "mlp_wide_forward_train: mlp is NULL");
+    const uint32_t nl = mlp->num_layers;
+    SN_REQUIRE(nl >= 1 && nl <= SN_MAX_LAYERS, "mlp_wide_forward_train: num_layers=%u outside 1..%d", nl, SN_MAX_LAYERS);
+    SN_REQUIRE(mlp->activation <= 1u, "mlp_wide_forward_train: activation must be 0 (relu) or 1 (leaky_relu 0.01)");
+    SN_REQUIRE(mlp->skip_mask == 0u, "mlp_wide_forward_train: skip connections are not supported (use the torch layers)");
+    SN_REQUIRE(mlp->dims[0] >= 1 && mlp->dims[0] <= 256u, "mlp_wide_forward_train: input width %u outside 1..256", mlp->dims[0]);
+    SN_REQUIRE(mlp->dims[nl] >= 1 && mlp->dims[nl] <= 256u, "mlp_wide_forward_train: output width %u outside 1..256", mlp->dims[nl]);
+    if (N == 0) return SN_OK;
+    SN_REQUIRE(x && out && (nl == 1 || hidden), "mlp_wide_forward_train: NULL pointer");
+    F32Args a{};
+    a.x = x; a.n_rows = N; a.K0 = mlp->dims[0]; a.nl = nl; a.leaky = mlp->activation;
+    for (uint32_t l = 0; l < nl; ++l) {
+        SN_REQUIRE(mlp->weight[l] && !mlp->bias[l], "mlp_wide_forward_train: layer %u needs a weight and no bias", l);
+        if (l + 1 < nl) {
+            SN_REQUIRE(mlp->dims[l + 1] == 256u, "mlp_wide_forward_train: hidden width must be 256 (layer %u has %u)", l, mlp->dims[l + 1]);
+            SN_REQUIRE(hidden[l], "mlp_wide_forward_train: hidden[%u] is NULL", l);
+        }
+        a.w[l] = mlp->weight[l];
+        a.N[l] = mlp->dims[l + 1];
+        a.h[l] = l + 1 < nl ? hidden[l] : out;
+    }
+    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_f32_train), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F32_LDS_BYTES));
+    hipLaunchKernelGGL(k_mlp_f32_train, dim3(div_up(N, (uint32_t)F32_ROWS)), dim3(F32_THREADS), F32_LDS_BYTES, (hipStream_t)stream, a);
+    SN_LAUNCH_CHECK("k_mlp_f32_train");
+    return SN_OK;
+}
+
 extern "C" size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp) {
     if (!mlp || mlp->num_layers < 1 || mlp->num_layers > SN_MAX_LAYERS) return 0;
     sn_mlp_desc b = *mlp;

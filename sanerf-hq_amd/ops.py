@@ -486,25 +486,48 @@ class _small_linear(Function):
 
 WIDE_MLP_BACKWARD_MIN_ROWS = 16384
 WIDE_MLP_BACKWARD_FUSED = True      # False: the wide training MLP differentiates through torch (A/B, tests)
+WIDE_MLP_FORWARD_NATIVE = False     # True: the wide training MLP's forward as ONE kernel (sn_mlp_wide_forward_train: fp32 MFMA, fused activations).  Measured slower
+                                    # than the BLAS GEMMs + activation kernels (0.555 vs 0.377 ms for the mask head, csrc/mlp_f32.inc), so opt-in
 _wide_bwd_ws: dict = {}
 
 
 class _wide_mlp_train(Function):
     """A bias-free 256-wide perceptron without skip layers under autograd (the per-sample mask head in training,
-    network.py:118-123 / trainer.py:401-428).  Forward: the usual GEMMs (rocBLAS fp32 -- a split-fp16 forward would round
-    pre-activations differently and flip LeakyReLU branches of ~1e-6 of the units, which alone costs the 1e-3 gradient
-    budget) with every hidden output saved.  Backward: ONE kernel for the whole data path (sn_mlp_wide_backward: grad of the
+    network.py:118-123 / trainer.py:401-428).  Forward: the usual GEMMs (BLAS fp32; fp32 and not split-fp16: a forward that rounds
+    pre-activations differently flips LeakyReLU branches of ~1e-6 of the units, which alone costs the 1e-3 gradient budget) with every
+    hidden output saved -- or, with WIDE_MLP_FORWARD_NATIVE, one fp32-MFMA kernel with the activations fused (sn_mlp_wide_forward_train).  Backward: ONE kernel for the whole data path (sn_mlp_wide_backward: grad of the
     input and of every hidden pre-activation, masks from the saved outputs) + sn_linear_wgrad per layer."""
 
     @staticmethod
     def forward(ctx, x, leaky, *weights):
         hs = []
-        h = x
-        for i, w in enumerate(weights):
-            h = torch.nn.functional.linear(h, w)
-            if i + 1 < len(weights):
-                h = torch.nn.functional.leaky_relu(h, inplace=True) if leaky else torch.relu_(h)
-                hs.append(h)
+        if WIDE_MLP_FORWARD_NATIVE and x.shape[-1] <= 256 and weights[-1].shape[0] <= 256:
+            # one kernel for all layers: true fp32 on the matrix cores, activation fused, hidden outputs saved (sn_mlp_wide_forward_train)
+            nl = len(weights)
+            rows = x.numel() // x.shape[-1]
+            x2 = x.reshape(rows, x.shape[-1]).contiguous()
+            ws = [w.contiguous() for w in weights]
+            desc = _lib.MlpDesc()
+            desc.num_layers = nl
+            desc.activation = 1 if leaky else 0
+            desc.skip_mask = 0
+            desc.dims[0] = x2.shape[1]
+            for i, w in enumerate(ws):
+                desc.weight[i] = w.data_ptr()
+                desc.bias[i] = None
+                desc.dims[i + 1] = w.shape[0]
+            hs = [torch.empty(*x.shape[:-1], 256, device=x.device, dtype=torch.float32) for _ in range(nl - 1)]
+            h = torch.empty(*x.shape[:-1], ws[-1].shape[0], device=x.device, dtype=torch.float32)
+            hid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in hs])
+            _lib.check(_lib.lib().sn_mlp_wide_forward_train(C.byref(desc), _lib.dev(x2, "x"), rows, hid, _lib.dev(h, "out"), _lib.stream()),
+                       "sn_mlp_wide_forward_train")
+        else:
+            h = x
+            for i, w in enumerate(weights):
+                h = torch.nn.functional.linear(h, w)
+                if i + 1 < len(weights):
+                    h = torch.nn.functional.leaky_relu(h, inplace=True) if leaky else torch.relu_(h)
+                    hs.append(h)
         ctx.save_for_backward(x, *hs, *weights)
         ctx.nl, ctx.leaky = len(weights), bool(leaky)
         if WGRAD_SIDE_STREAM:

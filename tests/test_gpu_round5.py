@@ -215,3 +215,64 @@ def test_mask16_kernel_agrees_with_the_round4_kernel(gpu, N, T_, n_inst, L, E, e
     finally:
         _lib.check(_lib.lib().sn_debug_set(b"mask_head16", 8), "debug_set")
     assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,din,n_out,nl,leaky", [(20000, 143, 16, 3, True), (64 * 7 + 5, 143, 2, 3, True), (16384 + 77, 64, 5, 3, False),
+                                                  (4096, 256, 256, 2, True), (1000, 1, 40, 4, True), (33, 37, 33, 1, True)])
+def test_wide_mlp_native_fp32_forward(gpu, N, din, n_out, nl, leaky):
+    """sn_mlp_wide_forward_train (one kernel, v_mfma_f32_32x32x2_f32, activations fused, hidden outputs saved) against the layer-by-layer
+    torch forward in fp32 and in fp64: as close to the fp64 result as BLAS fp32 is (both are fp32 sums in another order), hidden outputs
+    equal to what torch's in-place activation leaves for autograd up to that round-off, ragged row counts and widths."""
+    import ctypes as C
+    from sanerf_hq_amd import _lib, synth
+    dims = [din] + [256] * (nl - 1) + [n_out]
+    ws = [torch.from_numpy(synth.linear_weight(dims[i + 1], dims[i], 900 + i, 2.0)).to(gpu) for i in range(nl)]
+    rng = np.random.default_rng(N)
+    x = torch.from_numpy(rng.standard_normal((N, din)).astype(np.float32)).to(gpu)
+    act = (lambda t: torch.nn.functional.leaky_relu(t)) if leaky else torch.relu
+
+    def ref(dtype):
+        h, hs = x.to(dtype), []
+        for i, w in enumerate(ws):
+            h = torch.nn.functional.linear(h, w.to(dtype))
+            if i + 1 < nl:
+                h = act(h)
+                hs.append(h)
+        return h, hs
+
+    y32, h32 = ref(torch.float32)
+    y64, h64 = ref(torch.float64)
+    desc = _lib.MlpDesc()
+    desc.num_layers, desc.activation, desc.skip_mask = nl, 1 if leaky else 0, 0
+    desc.dims[0] = din
+    for i, w in enumerate(ws):
+        desc.weight[i], desc.bias[i], desc.dims[i + 1] = w.data_ptr(), None, w.shape[0]
+    hs = [torch.full((N, 256), float("nan"), device=gpu) for _ in range(nl - 1)]
+    y = torch.full((N, n_out), float("nan"), device=gpu)
+    hid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in hs])
+    _lib.check(_lib.lib().sn_mlp_wide_forward_train(C.byref(desc), x.data_ptr(), N, hid, y.data_ptr(), _lib.stream()), "sn_mlp_wide_forward_train")
+    torch.cuda.synchronize()
+
+    def err(a, b64):
+        return float((a.double() - b64).norm() / b64.norm().clamp_min(1e-30))
+
+    assert torch.isfinite(y).all()
+    e_native, e_blas = err(y, y64), err(y32, y64)
+    assert e_native < max(2.0 * e_blas, 2e-7), (e_native, e_blas)
+    for a, b32, b64 in zip(hs, h32, h64):
+        assert torch.isfinite(a).all()
+        assert err(a, b64) < max(2.0 * err(b32, b64), 2e-7)
+    # and through the autograd route of the training MLP: same outputs, saved tensors feed the fused backward
+    from sanerf_hq_amd import ops
+    if nl >= 2 and N >= ops.WIDE_MLP_BACKWARD_MIN_ROWS and n_out <= 256:
+        xs = x.clone().requires_grad_(True)
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        ops.WIDE_MLP_FORWARD_NATIVE = True             # (opt-in: measured slower than the BLAS forward, csrc/mlp_f32.inc)
+        try:
+            ya = ops._wide_mlp_train.apply(xs, leaky, *wl)
+        finally:
+            ops.WIDE_MLP_FORWARD_NATIVE = False
+        assert torch.equal(ya, y)
+        ya.backward(torch.ones_like(ya))
+        assert all(w.grad is not None and torch.isfinite(w.grad).all() for w in wl) and torch.isfinite(xs.grad).all()

@@ -8,6 +8,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
 import test_gpu_round4 as t4
 from sanerf_hq_amd.graph import GraphedStep
 gpu = torch.device("cuda:0")
+if os.environ.get("SN_GRID_ATOMIC"):
+    from sanerf_hq_amd import ops as _o
+    _o.GRID_BACKWARD_MODE = "atomic"
+if os.environ.get("SN_NO_FUSED_BWD"):
+    from sanerf_hq_amd import ops as _o2
+    _o2.WIDE_MLP_BACKWARD_FUSED = False
+if os.environ.get("SN_FWD_BLAS"):
+    from sanerf_hq_amd import ops
+    ops.WIDE_MLP_FORWARD_NATIVE = False          # A/B: the training MLP's forward through BLAS
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 m_e, s_e = t4._c5_like_step(gpu, 99, False)
 m_g, s_g = t4._c5_like_step(gpu, 99, mode != "eager2")
