@@ -294,10 +294,9 @@ class NeRFRenderer(nn.Module):
                     # inference: grid gather -> matrix-core MLP -> compositing in one kernel, nothing per-sample written
                     results["instance_mask_logits"] = rm.mask_head(weights, xyzs, geo_feat, self.m_grid, mlp, self.bound)
                     return
-                if torch.is_grad_enabled() and self.m_grid.embeddings.requires_grad:
-                    mlp_in = torch.cat([self.m_grid(xyzs, bound=self.bound), geo_feat.detach()], dim=-1)
-                else:   # inference: features and geometry channels land in one [.., 143] buffer in a single pass
-                    mlp_in = self.m_grid.forward_cat(xyzs, geo_feat, bound=self.bound)
+                # features and (detached) geometry channels land in one [.., 143] buffer in a single pass; in training the table gets its gradient
+                # through ops._grid_encode_cat (the reference: torch.cat([m_grid(xyzs), geo_feat.detach()]), renderer.py:380)
+                mlp_in = self.m_grid.forward_cat(xyzs.detach(), geo_feat, bound=self.bound)
                 point_masks = self._head_mlp(self.mask_mlp, mlp_in)
             else:
                 raise RuntimeError("mask_mlp_type='lightweight_mask' is dimensionally inconsistent in the reference "

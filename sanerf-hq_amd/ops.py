@@ -154,6 +154,54 @@ class _grid_encode(Function):
 grid_encode = _grid_encode.apply
 
 
+class _grid_encode_cat(Function):
+    """cat([grid_encode(inputs, embeddings), extra.detach()], -1) under autograd in ONE forward pass (sn_grid_encode_forward_cat): the mask
+    head's MLP input in training (renderer.py:380: grid features next to the detached geometry channels).  Gradient: to the embeddings only
+    (the first L*C columns of the incoming gradient, through the same binned / atomic scatter as _grid_encode); inputs and extra get none."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, extra, per_level_scale, base_resolution, gridtype, align_corners, interpolation):
+        inputs = inputs.contiguous().float()
+        extra = extra.contiguous().float()
+        B, D = inputs.shape
+        L, Cc, E = offsets.shape[0] - 1, embeddings.shape[1], extra.shape[1]
+        S, H = float(np.float32(np.log2(per_level_scale))), int(base_resolution)
+        table = embeddings.contiguous()
+        offs = _host_offsets(offsets)
+        if offs[-1] != embeddings.shape[0]:
+            raise RuntimeError(f"offsets end at row {offs[-1]} but embeddings has {embeddings.shape[0]} rows")
+        out = torch.empty(B, L * Cc + E, device=inputs.device, dtype=torch.float32)
+        _lib.check(_lib.lib().sn_grid_encode_forward_cat(
+            _lib.dev(inputs, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table), _lib.host_i32(offs),
+            _lib.dev(extra, "extra"), E, _lib.dev(out, "outputs"), B, Cc, L, S, H, gridtype, int(align_corners), interpolation, _lib.stream()),
+            "grid_encode_forward_cat")
+        ctx.save_for_backward(inputs, table)
+        ctx.meta = (offs, B, D, Cc, L, S, H, gridtype, interpolation, bool(align_corners), embeddings.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, table = ctx.saved_tensors
+        offs, B, D, Cc, L, S, H, gridtype, interpolation, align_corners, emb_dtype = ctx.meta
+        g = grad[:, :L * Cc].contiguous().float()
+        grad_embeddings = torch.zeros(table.shape, device=table.device, dtype=torch.float32)   # grid.py:83
+        lib = _lib.lib()
+        need = _binned_workspace_bytes(B, D, Cc, L, L, offs, None)
+        if need:
+            ws = _binned_workspace(need, table.device)
+            _lib.check(lib.sn_grid_encode_backward_binned(
+                _lib.dev(g, "grad"), _lib.dev(inputs, "inputs"), _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"),
+                B, D, Cc, L, L, S, H, gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC,
+                ws.data_ptr(), ws.numel(), _lib.stream()), "grid_encode_backward_binned")
+        else:
+            _lib.check(lib.sn_grid_encode_backward(
+                _lib.dev(g, "grad"), _lib.dev(inputs, "inputs"), _lib.dev(table, "embeddings", None), _table_dtype(table),
+                _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"), B, D, Cc, L, L, S, H,
+                _lib.dev(None, "dy_dx"), _lib.dev(None, "grad_inputs"),
+                gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC, _lib.stream()), "grid_encode_backward")
+        return None, grad_embeddings.to(emb_dtype), None, None, None, None, None, None, None
+
+
 def grid_level_offsets(input_dim: int, num_levels: int, per_level_scale: float, base_resolution: int,
                        log2_hashmap_size: int) -> np.ndarray:
     """First row of every level (+ the total), int32 [L+1]: rows per level = min(2^log2T, res^D) rounded up to a
@@ -213,16 +261,26 @@ class GridEncoder(nn.Module):
                           flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
         return out.view(lead + [self.output_dim])
 
-    @torch.no_grad()
     def forward_cat(self, inputs, extra, bound=1):
-        """cat([self(inputs, bound), extra], -1) in one pass, inference only (the mask head's MLP input, renderer.py:380:
-        no [B, L*C] intermediate and no concatenation pass).  inputs [..., 3], extra [..., E] -> [..., L*C + E]."""
-        x = ((inputs + bound) / (2 * bound)).reshape(-1, self.input_dim).contiguous().float()
+        """cat([self(inputs, bound), extra.detach()], -1) in one pass (the mask head's MLP input, renderer.py:380: no [B, L*C] intermediate
+        and no concatenation pass).  inputs [..., 3], extra [..., E] -> [..., L*C + E].  With autograd on and a trainable fp32 table the
+        embeddings receive their gradient (ops._grid_encode_cat); inputs and extra never do."""
+        with torch.no_grad():
+            x = ((inputs + bound) / (2 * bound)).reshape(-1, self.input_dim).contiguous().float()
+            ex = extra.reshape(-1, extra.shape[-1]).contiguous().float()
         lead = list(inputs.shape[:-1])
-        ex = extra.reshape(-1, extra.shape[-1]).contiguous().float()
         B, E = x.shape[0], ex.shape[1]
         if ex.shape[0] != B or self.input_dim != 3:
             raise ValueError(f"forward_cat: inputs {tuple(inputs.shape)} / extra {tuple(extra.shape)} do not match (3-D inputs only)")
+        if torch.is_grad_enabled() and self.embeddings.requires_grad and self.embeddings.dtype == torch.float32 and x.is_cuda:
+            out = _grid_encode_cat.apply(x, self.embeddings, self.offsets, ex, self.per_level_scale, self.base_resolution,
+                                         self.gridtype_id, self.align_corners, self.interp_id)
+            return out.view(lead + [self.output_dim + E])
+        return self._forward_cat_nograd(x, ex, lead)
+
+    @torch.no_grad()
+    def _forward_cat_nograd(self, x, ex, lead):
+        B, E = x.shape[0], ex.shape[1]
         table = self.embeddings.detach().contiguous()
         out = torch.empty(B, self.output_dim + E, device=x.device, dtype=torch.float32)
         S = float(np.float32(np.log2(self.per_level_scale)))

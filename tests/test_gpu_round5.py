@@ -276,3 +276,32 @@ def test_wide_mlp_native_fp32_forward(gpu, N, din, n_out, nl, leaky):
         assert torch.equal(ya, y)
         ya.backward(torch.ones_like(ya))
         assert all(w.grad is not None and torch.isfinite(w.grad).all() for w in wl) and torch.isfinite(xs.grad).all()
+
+
+@pytest.mark.gpu
+def test_forward_cat_under_autograd_matches_cat_of_the_encoder(gpu):
+    """GridEncoder.forward_cat in training (ops._grid_encode_cat: grid features and the detached extra channels in one forward kernel) against
+    torch.cat([enc(x), extra.detach()]) as the reference writes it (renderer.py:380): same values, same table gradient (both through the
+    binned scatter: equal up to its summation order), no gradient to the extra channels."""
+    from sanerf_hq_amd.gridencoder import GridEncoder
+    torch.manual_seed(5)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=8, base_resolution=16, log2_hashmap_size=15, desired_resolution=256).to(gpu)
+    B, E = 40000, 15
+    x = (torch.rand(B, 3, device=gpu) * 2 - 1) * 0.98
+    extra = torch.randn(B, E, device=gpu, requires_grad=True)
+    gy = torch.randn(B, 16 * 8 + E, device=gpu)
+    a = enc.forward_cat(x, extra, bound=1.0)
+    assert a.requires_grad
+    a.backward(gy)
+    ga = enc.embeddings.grad.clone()
+    assert extra.grad is None                       # detached, as in the reference
+    enc.embeddings.grad = None
+    b = torch.cat([enc(x, bound=1.0), extra.detach()], dim=-1)
+    b.backward(gy)
+    gb = enc.embeddings.grad.clone()
+    assert torch.equal(a.detach(), b.detach())
+    assert float((ga - gb).norm() / gb.norm()) < 1e-6
+    assert torch.equal(ga != 0, gb != 0)
+    with torch.no_grad():                           # inference route: the same values
+        c = enc.forward_cat(x, extra, bound=1.0)
+    assert torch.equal(c, b.detach())
