@@ -391,6 +391,12 @@ int sn_rm_mask_head(const float *xyzs, const float *extra, const float *weights,
  * hidden is a host array of nl-1 device pointers.  All tensors row-major fp32, no alignment requirement beyond 4 bytes. */
 int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out, sn_stream_t stream);
 
+/* The same forward on the inference kernel of sn_mlp_wide_forward (split-fp16 x3 products with fp32 accumulation on the matrix cores, ~2^-22
+ * per product; any dims[0] <= 1024, biases allowed) with every hidden layer's post-activation output saved: hidden[l] [N, 256], 16-byte
+ * aligned.  workspace: sn_mlp_wide_workspace_bytes(mlp), 16-byte aligned.  Activations must stay inside the fp16 range (sn_mlp_wide_overflow). */
+int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out,
+                                    void *workspace, size_t workspace_bytes, sn_stream_t stream);
+
 /* Backward-data pass of a 256-wide perceptron without skip layers (the autograd of nerf/network.py:31-66 for the per-sample
  * mask head in training, trainer.py:401-428) in one kernel: grad_out [N, dims[nl]] -> grad_in [N, dims[0]], and for every
  * hidden layer l < nl-1 grad_hidden[l] [N, 256] = d loss / d (pre-activation of layer l) -- what sn_linear_wgrad needs.

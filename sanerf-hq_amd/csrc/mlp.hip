@@ -756,7 +756,9 @@ __device__ __forceinline__ void dma16x4(const void *gptr, uint32_t lds_byte_offs
                  "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" : : "v"(gptr), "s"(base) : "memory");
 }
 
-template <int XMODE, bool N1 = false>      // N1: the narrow last layer has <= 32 outputs -- ONE output tile per k-step instead of the padded pair (fused mask head:
+template <int XMODE, bool N1 = false, bool SAVE = false>   // SAVE (sn_mlp_wide_forward_train, split-fp16 form): every hidden layer's post-activation output is also
+                                           // written to a.dump[layer] ([N, 256] fp32) as its tiles leave the accumulators: what the backward pass needs.
+                                           // N1: the narrow last layer has <= 32 outputs -- ONE output tile per k-step instead of the padded pair (fused mask head:
                                            // n_inst = 2; a template so that the two forms of the layer are never both in one kernel: accumulators that meet at a
                                            // control-flow merge get copied wholesale)
 __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
@@ -912,9 +914,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     // ESC: the layer's last k-step -- finished tiles leave the accumulators for `prev` two tiles behind the matrix pipe (tiles 6 and 7 in
     // the next layer's FIRST chunk, before it overwrites them).  The empty asm makes the moved value opaque: without it the compiler keeps
     // reading the accumulator itself, whose life then overlaps the next layer's.
-    auto escape_tile = [&](auto tc) {
+    auto escape_tile = [&](auto tc, uint32_t lsrc) {       // lsrc: the layer whose outputs these are
         constexpr int t = decltype(tc)::value;
         static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; float v = acc[t][r]; asm("" : "+v"(v)); prev[16 * t + r] = v; });
+        if constexpr (SAVE) {       // register r of this lane = neuron 32 t + (r & 3) + 8 (r >> 2) + 4 half of row n
+            if (ok && lsrc < a.nl - 1u) {                     // (the first layer's first chunk "escapes" tiles of a layer that does not exist: lsrc = ~0)
+                float *drow = a.dump[lsrc] + (size_t)n * WIDE + 32u * t + 4u * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(drow + 8 * q) = make_float4(act(prev[16 * t + 4 * q]), act(prev[16 * t + 4 * q + 1]), act(prev[16 * t + 4 * q + 2]), act(prev[16 * t + 4 * q + 3]));
+            }
+        } else (void)lsrc;
     };
     auto chunk8 = [&](auto first_tag, auto esc_tag, auto extra_tag, uint32_t l, const uint32_t (&ob_h)[4], const uint32_t (&ob_l)[4], auto &&prep) {
         constexpr bool FIRST = decltype(first_tag)::value, ESC = decltype(esc_tag)::value;
@@ -943,8 +953,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch_first_pair(g + 1u);
             }
-            if constexpr (FIRST && mt < 2) escape_tile(int_tag<6 + mt>{});
-            if constexpr (ESC && mt >= 2) escape_tile(int_tag<mt - 2>{});
+            if constexpr (FIRST && mt < 2) escape_tile(int_tag<6 + mt>{}, l - 1u);
+            if constexpr (ESC && mt >= 2) escape_tile(int_tag<mt - 2>{}, l);
             prep(mtc);
             if constexpr (mt + 2 == WIDE_MT) {       // the tile's MFMAs were fenced in front of the synchronisation; what follows rides on tile 7
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -1155,7 +1165,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
             {
             // last layer with <= 64 outputs: 4 chunks of 4 k-steps x 1 tile pair (k_pack_mlp_wide); the operand of k-step k+1 is split
             // between the six MFMAs of k-step k.  Tiles 6 and 7 of the previous layer leave the accumulators first.
-            escape_tile(int_tag<6>{}); escape_tile(int_tag<7>{});
+            escape_tile(int_tag<6>{}, l - 1u); escape_tile(int_tag<7>{}, l - 1u);
             floatx16 c0, c1;
             bias_tile(l, 0, c0); bias_tile(l, 1, c1);
             static_for<WIDE_HKS / 4>([&](auto cc) {
@@ -1472,9 +1482,9 @@ extern "C" size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp) {
     return u4 * sizeof(uint4);
 }
 
-extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
-                                   const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
-                                   sn_stream_t stream) {
+static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
+                             const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
+                             sn_stream_t stream, float *const *hidden) {
     SN_REQUIRE(mlp, "mlp_wide: mlp is NULL");
     if (N == 0) return SN_OK;
     SN_REQUIRE(x && out && workspace, "mlp_wide: x/out/workspace must be device pointers");
@@ -1500,7 +1510,14 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
     hipLaunchKernelGGL(k_pack_mlp_wide, dim3(div_up(max_threads, 256), nl), dim3(256), 0, st, pa);
     SN_LAUNCH_CHECK("k_pack_mlp_wide");
     WideArgs wa;
+    memset(&wa, 0, sizeof(wa));
     wa.x = x; wa.out = out; wa.pack = pa.pack; wa.ln_w = ln_weight; wa.ln_b = ln_bias; wa.ln_eps = ln_eps;
+    if (hidden) {
+        for (uint32_t l = 0; l + 1 < nl; ++l) {
+            SN_REQUIRE(hidden[l] && table_aligned(hidden[l]), "mlp_wide_forward_train: hidden[%u] must be a 16-byte aligned device pointer", l);
+            wa.dump[l] = hidden[l];
+        }
+    }
     wa.N = N; wa.din = din; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
     for (uint32_t l = 0; l < nl; ++l) { wa.bias[l] = mlp->bias[l]; wa.layer[l] = pa.layer[l]; }
     // XMODE 1 row stride: a multiple of 4 floats (16-byte reads) with stride/4 odd (the 32 rows of a wave then start in
@@ -1537,19 +1554,40 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
             hipLaunchKernelGGL(k_mlp_wide_j<MODE>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);               \
         } else SN_MLP_LAUNCH_OLD(MODE);                                                                               \
     } while (0)
-    if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
+#define SN_MLP_LAUNCH_SAVE(MODE)                                                                                      \
+    do {                                                                                                              \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<MODE, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_mlp_wide_j<MODE, false, true>), dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);    \
+    } while (0)
+    if (hidden) { if (xmode == 2) SN_MLP_LAUNCH_SAVE(2); else if (xmode == 1) SN_MLP_LAUNCH_SAVE(1); else SN_MLP_LAUNCH_SAVE(0); }
+    else if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
 #undef SN_MLP_LAUNCH
+#undef SN_MLP_LAUNCH_SAVE
     SN_LAUNCH_CHECK("k_mlp_wide");
     return SN_OK;
 }
 
-// Backward-data pass of a 256-wide perceptron in one kernel (the autograd of nerf/network.py:31-66 for the per-sample mask
-// head during training, trainer.py:401-428): grad_in = ((grad_out W_{nl-1}) * act'(h_{nl-2}) ... W_0), with the gradient
-// w.r.t. every hidden pre-activation written out for the weight-gradient kernels (sn_linear_wgrad).  The same machinery
-// as the forward -- transposed formulation, split-fp16 products with fp32 accumulation, weights streamed through LDS --
-// run over the transposed weights in reverse layer order; the activation step is the mask from the forward's saved
-// outputs, so no rounding difference can flip a LeakyReLU branch (which is what rules out a split-fp16 FORWARD under the
-// 1e-3 gradient bar, DESIGN.md section 5).
+extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
+                                   const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
+                                   sn_stream_t stream) {
+    return wide_forward_impl(mlp, ln_weight, ln_bias, ln_eps, x, N, out, workspace, workspace_bytes, stream, nullptr);
+}
+
+// The training forward on the inference kernel (k_mlp_wide_j: split-fp16 x3 products, fp32 accumulation, ~2^-22 per product) with every
+// hidden layer's post-activation output saved as its tiles leave the accumulators.  Measured against the reference's gradients
+// (tests/golden/train_c5.npz) the three forwards -- BLAS fp32, fp32 MFMA, this -- give the SAME errors to three digits (7.8e-4 / 1.6e-4 /
+// 8.9e-4 relative L2 for the first two weight matrices and the table rows: tools/r5/fwd_modes_err.py): the error against the fixture comes
+// from elsewhere (the frozen field's 1e-5), not from how the mask MLP's pre-activations are rounded.
+extern "C" int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out,
+                                               void *workspace, size_t workspace_bytes, sn_stream_t stream) {
+    SN_REQUIRE(mlp && mlp->num_layers >= 1, "mlp_wide_forward_train_f16x3: mlp is NULL");
+    SN_REQUIRE(mlp->skip_mask == 0u, "mlp_wide_forward_train_f16x3: skip connections are not supported (use the torch layers)");
+    SN_REQUIRE(mlp->num_layers == 1 || hidden, "mlp_wide_forward_train_f16x3: hidden is NULL");
+    static float *const no_hidden[SN_MAX_LAYERS] = {};
+    return wide_forward_impl(mlp, nullptr, nullptr, 0.0f, x, N, out, workspace, workspace_bytes, stream, mlp->num_layers == 1 ? no_hidden : hidden);
+}
+
+// Training forward in one kernel, true fp32 on the matrix cores (mlp_f32.inc): opt-in, see the measurements there.
 extern "C" int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out, sn_stream_t stream) {
     SN_REQUIRE(mlp, "mlp_wide_forward_train: mlp is NULL");
     const uint32_t nl = mlp->num_layers;
@@ -1578,6 +1616,13 @@ extern "C" int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x,
     return SN_OK;
 }
 
+// Backward-data pass of a 256-wide perceptron in one kernel (the autograd of nerf/network.py:31-66 for the per-sample mask
+// head during training, trainer.py:401-428): grad_in = ((grad_out W_{nl-1}) * act'(h_{nl-2}) ... W_0), with the gradient
+// w.r.t. every hidden pre-activation written out for the weight-gradient kernels (sn_linear_wgrad).  The same machinery
+// as the forward -- transposed formulation, split-fp16 products with fp32 accumulation, weights streamed through LDS --
+// run over the transposed weights in reverse layer order; the activation step is the mask from the forward's saved
+// outputs, so no rounding difference can flip a LeakyReLU branch (which is what rules out a split-fp16 FORWARD under the
+// 1e-3 gradient bar, DESIGN.md section 5).
 extern "C" size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp) {
     if (!mlp || mlp->num_layers < 1 || mlp->num_layers > SN_MAX_LAYERS) return 0;
     sn_mlp_desc b = *mlp;

@@ -544,6 +544,11 @@ class _small_linear(Function):
 
 WIDE_MLP_BACKWARD_MIN_ROWS = 16384
 WIDE_MLP_BACKWARD_FUSED = True      # False: the wide training MLP differentiates through torch (A/B, tests)
+WIDE_MLP_FORWARD_F16X3 = True       # the wide training MLP's forward as ONE kernel on the inference path's matrix-core kernel (split-fp16 x3 products, ~2^-22 per
+                                    # product, fp32 accumulation; sn_mlp_wide_forward_train_f16x3) with the hidden outputs saved: 0.38 -> 0.2 ms for the mask head.
+                                    # Against the reference's gradients (train_c5.npz) it gives the same errors as the BLAS forward to three digits
+                                    # (tools/r5/fwd_modes_err.py).  Activations must stay inside the fp16 range (raymarching.mlp_wide_overflow()).  False: BLAS fp32
+_wide_fwd_ws: dict = {}
 WIDE_MLP_FORWARD_NATIVE = False     # True: the wide training MLP's forward as ONE kernel (sn_mlp_wide_forward_train: fp32 MFMA, fused activations).  Measured slower
                                     # than the BLAS GEMMs + activation kernels (0.555 vs 0.377 ms for the mask head, csrc/mlp_f32.inc), so opt-in
 _wide_bwd_ws: dict = {}
@@ -551,15 +556,43 @@ _wide_bwd_ws: dict = {}
 
 class _wide_mlp_train(Function):
     """A bias-free 256-wide perceptron without skip layers under autograd (the per-sample mask head in training,
-    network.py:118-123 / trainer.py:401-428).  Forward: the usual GEMMs (BLAS fp32; fp32 and not split-fp16: a forward that rounds
-    pre-activations differently flips LeakyReLU branches of ~1e-6 of the units, which alone costs the 1e-3 gradient budget) with every
-    hidden output saved -- or, with WIDE_MLP_FORWARD_NATIVE, one fp32-MFMA kernel with the activations fused (sn_mlp_wide_forward_train).  Backward: ONE kernel for the whole data path (sn_mlp_wide_backward: grad of the
+    network.py:118-123 / trainer.py:401-428).  Forward: one matrix-core kernel (split-fp16 x3 products, WIDE_MLP_FORWARD_F16X3) with every
+    hidden output saved; or the usual BLAS fp32 GEMMs; or, with WIDE_MLP_FORWARD_NATIVE, one fp32-MFMA kernel (sn_mlp_wide_forward_train).
+    (Rounds 2-4 kept the BLAS forward for fear that differently rounded pre-activations flip LeakyReLU branches and spend the 1e-3 gradient
+    budget; measured in round 5, the error against the reference's gradients is the same to three digits for all three forwards.)  Backward: ONE kernel for the whole data path (sn_mlp_wide_backward: grad of the
     input and of every hidden pre-activation, masks from the saved outputs) + sn_linear_wgrad per layer."""
 
     @staticmethod
     def forward(ctx, x, leaky, *weights):
         hs = []
-        if WIDE_MLP_FORWARD_NATIVE and x.shape[-1] <= 256 and weights[-1].shape[0] <= 256:
+        if WIDE_MLP_FORWARD_F16X3 and not WIDE_MLP_FORWARD_NATIVE:
+            # one kernel for all layers on the inference path's matrix-core kernel (split-fp16 x3 products, fp32 accumulation), hidden outputs saved
+            nl = len(weights)
+            rows = x.numel() // x.shape[-1]
+            x2 = x.reshape(rows, x.shape[-1]).contiguous()
+            ws = [w.contiguous() for w in weights]
+            desc = _lib.MlpDesc()
+            desc.num_layers = nl
+            desc.activation = 1 if leaky else 0
+            desc.skip_mask = 0
+            desc.dims[0] = x2.shape[1]
+            for i, w in enumerate(ws):
+                desc.weight[i] = w.data_ptr()
+                desc.bias[i] = None
+                desc.dims[i + 1] = w.shape[0]
+            lib = _lib.lib()
+            need = int(lib.sn_mlp_wide_workspace_bytes(C.byref(desc)))
+            if need == 0:
+                raise RuntimeError("wide MLP forward: " + lib.sn_last_error().decode())
+            wsb = _wide_fwd_ws.get(x.device)
+            if wsb is None or wsb.numel() < need:
+                wsb = _wide_fwd_ws[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+            hs = [torch.empty(*x.shape[:-1], 256, device=x.device, dtype=torch.float32) for _ in range(nl - 1)]
+            h = torch.empty(*x.shape[:-1], ws[-1].shape[0], device=x.device, dtype=torch.float32)
+            hid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in hs])
+            _lib.check(lib.sn_mlp_wide_forward_train_f16x3(C.byref(desc), _lib.dev(x2, "x"), rows, hid, _lib.dev(h, "out"),
+                                                           wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_mlp_wide_forward_train_f16x3")
+        elif WIDE_MLP_FORWARD_NATIVE and x.shape[-1] <= 256 and weights[-1].shape[0] <= 256:
             # one kernel for all layers: true fp32 on the matrix cores, activation fused, hidden outputs saved (sn_mlp_wide_forward_train)
             nl = len(weights)
             rows = x.numel() // x.shape[-1]

@@ -853,8 +853,12 @@ def test_wide_mlp_fused_backward_matches_autograd(gpu, N, din, n_out, leaky):
         y.backward(gy)
         return y.detach(), xs.grad, [w.grad for w in wl]
 
-    assert not ops.WIDE_MLP_FORWARD_NATIVE     # the BLAS forward on both sides: this test is about the backward (a forward that rounds
-    ya, gxa, gwa = run(True)                   # differently flips a few LeakyReLU branches, which per-row tolerances would flag)
+    ops.WIDE_MLP_FORWARD_F16X3 = False         # the BLAS forward on both sides: this test is about the backward (a forward that rounds
+    try:                                       # differently flips a few LeakyReLU branches, which per-row tolerances would flag)
+        assert not ops.WIDE_MLP_FORWARD_NATIVE
+        ya, gxa, gwa = run(True)
+    finally:
+        ops.WIDE_MLP_FORWARD_F16X3 = True
     yb, gxb, gwb = run(False)
     assert torch.equal(ya, yb)                                            # the forward is the same GEMM chain
     # per-row accuracy of the input gradient: relative to each row's own magnitude (small rows are not swamped)

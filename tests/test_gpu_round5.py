@@ -275,6 +275,18 @@ def test_wide_mlp_native_fp32_forward(gpu, N, din, n_out, nl, leaky):
             ops.WIDE_MLP_FORWARD_NATIVE = False
         assert torch.equal(ya, y)
         ya.backward(torch.ones_like(ya))
+        # the default training forward (split-fp16 x3 on the inference kernel, hidden outputs saved): outputs and saved tensors within the
+        # split's 2^-22 per product of the fp64 result, gradients through the same fused backward
+        xs2 = x.clone().requires_grad_(True)
+        wl2 = [w.clone().requires_grad_(True) for w in ws]
+        assert ops.WIDE_MLP_FORWARD_F16X3
+        yc = ops._wide_mlp_train.apply(xs2, leaky, *wl2)
+        assert err(yc.detach(), y64) < 2e-6
+        for a, b64 in zip(yc.grad_fn.saved_tensors[1:nl], h64):
+            assert err(a, b64) < 2e-6 and torch.isfinite(a).all()
+        yc.backward(torch.ones_like(yc))
+        for wa_, wb_ in zip(wl2, wl):
+            assert float((wa_.grad - wb_.grad).norm() / wb_.grad.norm()) < 1e-3
         assert all(w.grad is not None and torch.isfinite(w.grad).all() for w in wl) and torch.isfinite(xs.grad).all()
 
 

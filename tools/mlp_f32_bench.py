@@ -24,8 +24,11 @@ for N, din, n_out in ((131072, 143, 16), (131072, 143, 2), (524288, 143, 16), (6
             h = torch.nn.functional.linear(h, w)
             if i < 2: h = torch.nn.functional.leaky_relu(h, inplace=True)
         return h
+    need = int(_lib.lib().sn_mlp_wide_workspace_bytes(C.byref(desc))); wsb = torch.empty(need, dtype=torch.uint8, device=gpu)
+    def f16x3():
+        _lib.check(_lib.lib().sn_mlp_wide_forward_train_f16x3(C.byref(desc), x.data_ptr(), N, hid, y.data_ptr(), wsb.data_ptr(), wsb.numel(), _lib.stream()), "fwd16")
     res = {}
-    for name, fn in (("native", native), ("blas", blas)):
+    for name, fn in (("native", native), ("blas", blas), ("f16x3", f16x3)):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,7 +37,7 @@ for N, din, n_out in ((131072, 143, 16), (131072, 143, 2), (524288, 143, 16), (6
         e1.record(); torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 20
     flops = 2.0 * N * sum(dims[i] * dims[i + 1] for i in range(3))
-    print(f"N={N} {din}->256->256->{n_out}: native {res['native']:.3f} ms ({flops / res['native'] / 1e9:.1f} TFLOP/s fp32) | torch {res['blas']:.3f} ms ({flops / res['blas'] / 1e9:.1f})")
+    print(f"N={N} {din}->256->256->{n_out}: native {res['native']:.3f} ms ({flops / res['native'] / 1e9:.1f} TFLOP/s fp32) | torch {res['blas']:.3f} ms ({flops / res['blas'] / 1e9:.1f}) | split-fp16 x3 with saved hidden outputs {res['f16x3']:.3f} ms")
 
 lib = _lib.lib()
 if os.environ.get("SN_TRACE"):
