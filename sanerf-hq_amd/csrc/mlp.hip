@@ -1621,8 +1621,8 @@ extern "C" int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x,
 // w.r.t. every hidden pre-activation written out for the weight-gradient kernels (sn_linear_wgrad).  The same machinery
 // as the forward -- transposed formulation, split-fp16 products with fp32 accumulation, weights streamed through LDS --
 // run over the transposed weights in reverse layer order; the activation step is the mask from the forward's saved
-// outputs, so no rounding difference can flip a LeakyReLU branch (which is what rules out a split-fp16 FORWARD under the
-// 1e-3 gradient bar).
+// outputs, so no rounding difference can flip a LeakyReLU branch.  (Rounds 2-4 held a split-fp16 FORWARD to be ruled out by the same
+// argument; measured against the reference's gradients in round 5 it is not -- sn_mlp_wide_forward_train_f16x3 above)
 extern "C" size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp) {
     if (!mlp || mlp->num_layers < 1 || mlp->num_layers > SN_MAX_LAYERS) return 0;
     sn_mlp_desc b = *mlp;
