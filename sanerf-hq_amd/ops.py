@@ -272,10 +272,13 @@ class GridEncoder(nn.Module):
         B, E = x.shape[0], ex.shape[1]
         if ex.shape[0] != B or self.input_dim != 3:
             raise ValueError(f"forward_cat: inputs {tuple(inputs.shape)} / extra {tuple(extra.shape)} do not match (3-D inputs only)")
-        if torch.is_grad_enabled() and self.embeddings.requires_grad and self.embeddings.dtype == torch.float32 and x.is_cuda:
-            out = _grid_encode_cat.apply(x, self.embeddings, self.offsets, ex, self.per_level_scale, self.base_resolution,
-                                         self.gridtype_id, self.align_corners, self.interp_id)
-            return out.view(lead + [self.output_dim + E])
+        if torch.is_grad_enabled() and self.embeddings.requires_grad:
+            if self.embeddings.dtype == torch.float32 and x.is_cuda and not torch.is_autocast_enabled():
+                out = _grid_encode_cat.apply(x, self.embeddings, self.offsets, ex, self.per_level_scale, self.base_resolution,
+                                             self.gridtype_id, self.align_corners, self.interp_id)
+                return out.view(lead + [self.output_dim + E])
+            # a half table / autocast (grid.py:43-46) keeps the encoder's own autograd path and a concatenation, as the reference writes it
+            return torch.cat([self(inputs, bound=bound), extra.detach()], dim=-1)
         return self._forward_cat_nograd(x, ex, lead)
 
     @torch.no_grad()
