@@ -8,7 +8,7 @@ import sys
 
 d0 = sys.argv[1]
 sets = (("pmc_kernels_mask_head.txt", ("k_mask16",)), ("pmc_kernels_c3_sam_head.txt", ("k_feat_stage",)),
-        ("pmc_kernels_train_mask.txt", ("k_bin_scatter", "k_bin_accum", "k_linear_wgrad_mfma", "k_mlp_wide")),
+        ("pmc_kernels_train_mask.txt", ("k_bin_refs", "k_bin_pull", "k_bin_scatter", "k_bin_accum", "k_linear_wgrad_mfma", "k_mlp_wide", "k_grid_forward")),
         ("pmc_kernels_ref_f16.txt", ("k_prop_stage", "k_final_stage")), ("pmc_kernels_flat128_f16.txt", ("k_final_stage",)))
 print("workload      kernel               cycles/launch  (ms at 2.3 GHz)  MfmaUtil VALUBusy TA-busy  gather-instr  L1-acc/instr  L2-hit  FETCH_SIZE  WRITE_SIZE")
 for f, ks in sets:
@@ -17,11 +17,15 @@ for f, ks in sets:
         continue
     d = {}
     for ln in open(path):
-        m = re.match(r"(\S+)\s+(\S+)\s+dispatches=\s*(\d+) mean=(\S+)", ln)
+        m = re.match(r"(.*?)\s+(\S+)\s+dispatches=\s*(\d+) mean=(\S+)", ln)
         if m:
-            d[(m.group(1), m.group(2))] = float(m.group(4))
+            d[(m.group(1).strip(), m.group(2))] = float(m.group(4))
+    names = sorted({n for n, _ in d})
     for k in ks:
-        g = lambda c: d.get((k, c), float("nan"))   # noqa: E731
+        full = [n for n in names if n == k or (k + "<") in n or ("::" + k + "(") in n]       # templated kernels print with their signature
+        if not full:
+            continue
+        g = lambda c: d.get((full[0], c), float("nan"))   # noqa: E731
         act = g("GRBM_GUI_ACTIVE") / 8
         hit = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) * 100
         print(f"{f[12:-4]:13s} {k:20s} {act:13.0f}  {act / 2.3e6:15.3f}  {g('MfmaUtil'):8.1f} {g('VALUBusy'):8.1f} {g('TA_TA_BUSY_sum') / 256 / act * 100:6.1f}%  {g('SQ_INSTS_VMEM_RD'):12.4g}  "
