@@ -2183,6 +2183,7 @@ extern "C" int sn_linear_wgrad(const float *x, const float *dy, uint32_t M, uint
         else if (vec) { if (K <= 128) SN_WGM(4, true, false, 1); else SN_WGM(8, true, false, sn::div_up(K, 256)); }   // (two half-width workgroups per CU: slower)
         else if (K <= 64) SN_WGM(2, false, false, 1);
         else if (K <= 128) SN_WGM(4, false, false, 1);
+        else if (K <= 160) SN_WGM(5, false, false, 1);            // (the mask head's first layer: 143 inputs)
         else if (K <= 192) SN_WGM(6, false, false, 1);
         else SN_WGM(8, false, false, sn::div_up(K, 256));
 #undef SN_WGM
