@@ -394,8 +394,11 @@ int sn_mlp_wide_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t N
 /* The same forward on the inference kernel of sn_mlp_wide_forward (split-fp16 x3 products with fp32 accumulation on the matrix cores, ~2^-22
  * per product; any dims[0] <= 1024, biases allowed) with every hidden layer's post-activation output saved: hidden[l] [N, 256], 16-byte
  * aligned.  workspace: sn_mlp_wide_workspace_bytes(mlp), 16-byte aligned.  Activations must stay inside the fp16 range (sn_mlp_wide_overflow). */
-int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out,
-                                    void *workspace, size_t workspace_bytes, sn_stream_t stream);
+int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, uint32_t *const *sign_bits,
+                                    float *out, void *workspace, size_t workspace_bytes, sn_stream_t stream);
+/* sign_bits (NULL, or a host array of nl-1 device pointers, entries may be NULL): sign_bits[l] [N, 8] uint32, 16-byte aligned, receives one
+ * bit per hidden unit of layer l (set = output > 0) in the kernels' register order -- an opaque companion of hidden[l] for
+ * sn_mlp_wide_backward_bits, which then reads 32 bytes per row and layer instead of 1 KiB. */
 
 /* Backward-data pass of a 256-wide perceptron without skip layers (the autograd of nerf/network.py:31-66 for the per-sample
  * mask head in training, trainer.py:401-428) in one kernel: grad_out [N, dims[nl]] -> grad_in [N, dims[0]], and for every
@@ -405,6 +408,8 @@ int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint
  * scaled by a power of two (exact) so that small gradient rows keep their precision.  hidden / grad_hidden are host arrays of
  * nl-1 device pointers. */
 size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp);
+int sn_mlp_wide_backward_bits(const sn_mlp_desc *mlp, const float *grad_out, const uint32_t *const *sign_bits, uint32_t N,
+                              float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes, sn_stream_t stream);
 int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, uint32_t N,
                          float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes, sn_stream_t stream);
 

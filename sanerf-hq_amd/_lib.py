@@ -109,7 +109,8 @@ _SIGNATURES = {
     "sn_mlp_wide_forward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _f32, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
     "sn_mlp_wide_overflow": (_int, [_vp]),
     "sn_mlp_wide_forward_train": (_int, [C.POINTER(MlpDesc), _vp, _u32, _vp, _vp, _vp]),
-    "sn_mlp_wide_forward_train_f16x3": (_int, [C.POINTER(MlpDesc), _vp, _u32, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "sn_mlp_wide_forward_train_f16x3": (_int, [C.POINTER(MlpDesc), _vp, _u32, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "sn_mlp_wide_backward_bits": (_int, [C.POINTER(MlpDesc), _vp, _vp, _u32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_mlp_wide_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "sn_mlp_wide_backward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _u32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_rm_mask_head_workspace_bytes": (C.c_size_t, [C.POINTER(MlpDesc)]),

@@ -67,6 +67,10 @@ struct WideArgs {
     // activation derivative taken from the forward's saved outputs and written out (the weight gradients need them)
     const float *mask[SN_MAX_LAYERS];     // [N, 256] post-activation output of the forward layer that FED forward layer nl-1-b
     float *dump[SN_MAX_LAYERS];           // [N, 256] out: gradient w.r.t. that layer's pre-activation
+    // sign bits of a hidden layer's outputs, 16 bytes per (row, half-wave): bit 16 t + r of lane (row, half) = (output register r of tile t > 0), i.e.
+    // neuron 32 t + (r & 3) + 8 (r >> 2) + 4 half.  Written by the SAVE forward (k_mlp_wide_j), read by the backward (k_mlp_wide<5>) INSTEAD of the
+    // [N, 256] fp32 outputs: the branch of a LeakyReLU / ReLU unit is all the backward data path needs of them (1 KiB -> 32 bytes per row and layer)
+    uint32_t *bits[SN_MAX_LAYERS];
 };
 
 struct PackArgs {
@@ -383,7 +387,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
     // below 2^-14 would lose their lo half to fp16 subnormals, so every row is scaled by a power of two that brings its
     // largest entry to [1, 2) -- exact -- and the outputs are scaled back, exactly, on the way out
     float row_scale = 1.0f, row_unscale = 1.0f;
-    if constexpr (XMODE == 4) {
+    constexpr bool BWD = XMODE == 4 || XMODE == 5;       // 5: the activation branches come from sign bits (a.bits) instead of the saved outputs (a.mask)
+    if constexpr (BWD) {
         float mx = 0.0f;
         for (uint32_t c = 8u * half; c < a.din; c += 16u) {
 #pragma unroll
@@ -527,19 +532,26 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide(WideArgs a) {
             run_chunk(bh, bl, npairs);
         }
         }
-        if constexpr (XMODE == 4) {
+        if constexpr (BWD) {
             if (l + 1u < a.nl) {
                 // derivative of the activation (network.py:65-66; leaky_relu / relu keep the sign, so the saved OUTPUT tells the
                 // branch, as in torch's in-place backward), gradient w.r.t. the pre-activation written out, then split
                 const float slope = a.leaky ? 0.01f : 0.0f;
-                const float *mrow = a.mask[l] + (size_t)(ok ? n : a.N - 1u) * WIDE;
+                const float *mrow = XMODE == 5 ? nullptr : a.mask[l] + (size_t)(ok ? n : a.N - 1u) * WIDE;
+                uint4 sb = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (XMODE == 5) sb = *reinterpret_cast<const uint4 *>(a.bits[l] + ((size_t)(ok ? n : a.N - 1u) * 2u + half) * 4u);
+                const uint32_t sw[4] = {sb.x, sb.y, sb.z, sb.w};
                 float *drow = a.dump[l] + (size_t)(ok ? n : 0u) * WIDE;
 #pragma unroll
                 for (int mt = 0; mt < WIDE_MT; ++mt) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const uint32_t m0 = 32u * mt + 8u * q + 4u * half;
-                        const float4 h = *reinterpret_cast<const float4 *>(mrow + m0);
+                        float4 h;
+                        if constexpr (XMODE == 5) {       // bit 16 mt + r, r = 4 q + i
+                            const uint32_t w = sw[mt >> 1] >> (16 * (mt & 1) + 4 * q);
+                            h = make_float4((w & 1u) ? 1.0f : 0.0f, (w & 2u) ? 1.0f : 0.0f, (w & 4u) ? 1.0f : 0.0f, (w & 8u) ? 1.0f : 0.0f);
+                        } else h = *reinterpret_cast<const float4 *>(mrow + m0);
                         float4 v;
                         v.x = acc[mt][4 * q + 0] * (h.x > 0.0f ? 1.0f : slope);
                         v.y = acc[mt][4 * q + 1] * (h.y > 0.0f ? 1.0f : slope);
@@ -914,6 +926,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     // ESC: the layer's last k-step -- finished tiles leave the accumulators for `prev` two tiles behind the matrix pipe (tiles 6 and 7 in
     // the next layer's FIRST chunk, before it overwrites them).  The empty asm makes the moved value opaque: without it the compiler keeps
     // reading the accumulator itself, whose life then overlaps the next layer's.
+    uint32_t sbits[4] = {0u, 0u, 0u, 0u};                  // SAVE: sign bits of the layer whose tiles are leaving (this lane's 8 tiles x 16 registers)
     auto escape_tile = [&](auto tc, uint32_t lsrc) {       // lsrc: the layer whose outputs these are
         constexpr int t = decltype(tc)::value;
         static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; float v = acc[t][r]; asm("" : "+v"(v)); prev[16 * t + r] = v; });
@@ -923,6 +936,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4 *>(drow + 8 * q) = make_float4(act(prev[16 * t + 4 * q]), act(prev[16 * t + 4 * q + 1]), act(prev[16 * t + 4 * q + 2]), act(prev[16 * t + 4 * q + 3]));
+                // the units' branches as bits (WideArgs::bits): the output is positive exactly when the pre-activation is
+                uint32_t b16 = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) b16 |= (prev[16 * t + r] > 0.0f ? 1u : 0u) << r;
+                if constexpr ((t & 1) == 0) sbits[t >> 1] = b16; else sbits[t >> 1] |= b16 << 16;
+                if constexpr (t == WIDE_MT - 1) {               // tile 7 is the last one of a layer to leave the accumulators
+                    if (a.bits[lsrc]) *reinterpret_cast<uint4 *>(a.bits[lsrc] + ((size_t)n * 2u + half) * 4u) = make_uint4(sbits[0], sbits[1], sbits[2], sbits[3]);
+                }
             }
         } else (void)lsrc;
     };
@@ -1484,7 +1505,7 @@ extern "C" size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp) {
 
 static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
                              const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
-                             sn_stream_t stream, float *const *hidden) {
+                             sn_stream_t stream, float *const *hidden, uint32_t *const *sign_bits = nullptr) {
     SN_REQUIRE(mlp, "mlp_wide: mlp is NULL");
     if (N == 0) return SN_OK;
     SN_REQUIRE(x && out && workspace, "mlp_wide: x/out/workspace must be device pointers");
@@ -1516,6 +1537,10 @@ static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, con
         for (uint32_t l = 0; l + 1 < nl; ++l) {
             SN_REQUIRE(hidden[l] && table_aligned(hidden[l]), "mlp_wide_forward_train: hidden[%u] must be a 16-byte aligned device pointer", l);
             wa.dump[l] = hidden[l];
+            if (sign_bits && sign_bits[l]) {
+                SN_REQUIRE(table_aligned(sign_bits[l]), "mlp_wide_forward_train: sign_bits[%u] must be 16-byte aligned", l);
+                wa.bits[l] = sign_bits[l];
+            }
         }
     }
     wa.N = N; wa.din = din; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
@@ -1578,13 +1603,13 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
 // (tests/golden/train_c5.npz) the three forwards -- BLAS fp32, fp32 MFMA, this -- give the SAME errors to three digits (7.8e-4 / 1.6e-4 /
 // 8.9e-4 relative L2 for the first two weight matrices and the table rows: tools/r5/fwd_modes_err.py): the error against the fixture comes
 // from elsewhere (the frozen field's 1e-5), not from how the mask MLP's pre-activations are rounded.
-extern "C" int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out,
-                                               void *workspace, size_t workspace_bytes, sn_stream_t stream) {
+extern "C" int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, uint32_t *const *sign_bits,
+                                               float *out, void *workspace, size_t workspace_bytes, sn_stream_t stream) {
     SN_REQUIRE(mlp && mlp->num_layers >= 1, "mlp_wide_forward_train_f16x3: mlp is NULL");
     SN_REQUIRE(mlp->skip_mask == 0u, "mlp_wide_forward_train_f16x3: skip connections are not supported (use the torch layers)");
     SN_REQUIRE(mlp->num_layers == 1 || hidden, "mlp_wide_forward_train_f16x3: hidden is NULL");
     static float *const no_hidden[SN_MAX_LAYERS] = {};
-    return wide_forward_impl(mlp, nullptr, nullptr, 0.0f, x, N, out, workspace, workspace_bytes, stream, mlp->num_layers == 1 ? no_hidden : hidden);
+    return wide_forward_impl(mlp, nullptr, nullptr, 0.0f, x, N, out, workspace, workspace_bytes, stream, mlp->num_layers == 1 ? no_hidden : hidden, sign_bits);
 }
 
 // Training forward in one kernel, true fp32 on the matrix cores (mlp_f32.inc): opt-in, see the measurements there.
@@ -1633,14 +1658,13 @@ extern "C" size_t sn_mlp_wide_backward_workspace_bytes(const sn_mlp_desc *mlp) {
     return sn_mlp_wide_workspace_bytes(&b);
 }
 
-extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, uint32_t N,
-                                    float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes,
-                                    sn_stream_t stream) {
+static int wide_backward_impl(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, const uint32_t *const *sign_bits, uint32_t N,
+                              float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes, sn_stream_t stream) {
     SN_REQUIRE(mlp, "mlp_wide_backward: mlp is NULL");
     if (N == 0) return SN_OK;
     const uint32_t nl = mlp->num_layers;
     SN_REQUIRE(nl >= 2 && nl <= SN_MAX_LAYERS, "mlp_wide_backward: num_layers=%u outside 2..%d", nl, SN_MAX_LAYERS);
-    SN_REQUIRE(grad_out && hidden && grad_hidden && grad_in && workspace, "mlp_wide_backward: NULL pointer");
+    SN_REQUIRE(grad_out && (hidden || sign_bits) && grad_hidden && grad_in && workspace, "mlp_wide_backward: NULL pointer");
     SN_REQUIRE(table_aligned(workspace) && table_aligned(grad_in), "mlp_wide_backward: workspace/grad_in must be 16-byte aligned");
     if (mlp->skip_mask != 0u) { set_error("mlp_wide_backward: skip layers are not supported (use autograd's GEMMs)"); return SN_ERR_UNSUPPORTED; }
     sn_mlp_desc b = *mlp;                                                   // the backward pass as an MLP over the transposed weights
@@ -1669,16 +1693,42 @@ extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_ou
     wa.N = N; wa.din = b.dims[0]; wa.nl = nl; wa.leaky = mlp->activation; wa.total_chunks = (uint32_t)(u4 / WIDE_CHUNK_U4);
     for (uint32_t l = 0; l < nl; ++l) wa.layer[l] = pa.layer[l];
     for (uint32_t l = 0; l + 1 < nl; ++l) {                                   // after backward layer l: forward layer nl-2-l's output
-        SN_REQUIRE(hidden[nl - 2 - l] && grad_hidden[nl - 2 - l], "mlp_wide_backward: hidden[%u] / grad_hidden[%u] is NULL", nl - 2 - l, nl - 2 - l);
-        SN_REQUIRE(table_aligned(hidden[nl - 2 - l]) && table_aligned(grad_hidden[nl - 2 - l]), "mlp_wide_backward: hidden tensors must be 16-byte aligned");
-        wa.mask[l] = hidden[nl - 2 - l];
+        SN_REQUIRE(grad_hidden[nl - 2 - l] && table_aligned(grad_hidden[nl - 2 - l]), "mlp_wide_backward: grad_hidden[%u] must be a 16-byte aligned device pointer", nl - 2 - l);
+        if (sign_bits) {
+            SN_REQUIRE(sign_bits[nl - 2 - l] && table_aligned(sign_bits[nl - 2 - l]), "mlp_wide_backward_bits: sign_bits[%u] must be a 16-byte aligned device pointer", nl - 2 - l);
+            wa.bits[l] = const_cast<uint32_t *>(sign_bits[nl - 2 - l]);
+        } else {
+            SN_REQUIRE(hidden[nl - 2 - l] && table_aligned(hidden[nl - 2 - l]), "mlp_wide_backward: hidden[%u] must be a 16-byte aligned device pointer", nl - 2 - l);
+            wa.mask[l] = hidden[nl - 2 - l];
+        }
         wa.dump[l] = grad_hidden[nl - 2 - l];
     }
     const size_t lds = (size_t)WIDE_NBUF * WIDE_CHUNK_U4 * sizeof(uint4) + (size_t)SN_MAX_LAYERS * WIDE * sizeof(float) + 256u;
-    SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_mlp_wide<4>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);
+    if (sign_bits) {
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mlp_wide<5>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);
+    } else {
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mlp_wide<4>, dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);
+    }
     SN_LAUNCH_CHECK("k_mlp_wide<4>");
     return SN_OK;
+}
+
+extern "C" int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, uint32_t N,
+                                    float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes,
+                                    sn_stream_t stream) {
+    return wide_backward_impl(mlp, grad_out, hidden, nullptr, N, grad_in, grad_hidden, workspace, workspace_bytes, stream);
+}
+
+// The same pass with the units' branches read from the sign bits the SAVE forward wrote (sn_mlp_wide_forward_train_f16x3: 32 bytes per row
+// and layer) instead of the [N, 256] fp32 outputs: 268 MB less to read for the mask head's 131 072 rows, and no 1 KiB-per-row loads whose
+// latency this kernel (one wave per SIMD) cannot hide.
+extern "C" int sn_mlp_wide_backward_bits(const sn_mlp_desc *mlp, const float *grad_out, const uint32_t *const *sign_bits, uint32_t N,
+                                         float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes,
+                                         sn_stream_t stream) {
+    SN_REQUIRE(sign_bits, "mlp_wide_backward_bits: sign_bits is NULL");
+    return wide_backward_impl(mlp, grad_out, nullptr, sign_bits, N, grad_in, grad_hidden, workspace, workspace_bytes, stream);
 }
 
 // Mask head in one kernel (renderer.py:304-305, 376-385): k_mlp_wide<3> builds each sample's MLP input -- the C = 8 hash-grid

@@ -552,6 +552,7 @@ WIDE_MLP_FORWARD_F16X3 = True       # the wide training MLP's forward as ONE ker
                                     # Against the reference's gradients (train_c5.npz) it gives the same errors as the BLAS forward to three digits
                                     # (tools/r5/fwd_modes_err.py).  Activations must stay inside the fp16 range (raymarching.mlp_wide_overflow()).  False: BLAS fp32
 _wide_fwd_ws: dict = {}
+WIDE_MLP_SIGN_BITS = True           # the split-fp16 training forward also writes one sign bit per hidden unit and the backward data path reads those (A/B, tests: False)
 WIDE_MLP_FORWARD_NATIVE = False     # True: the wide training MLP's forward as ONE kernel (sn_mlp_wide_forward_train: fp32 MFMA, fused activations).  Measured slower
                                     # than the BLAS GEMMs + activation kernels (0.555 vs 0.377 ms for the mask head, csrc/mlp_f32.inc), so opt-in
 _wide_bwd_ws: dict = {}
@@ -593,8 +594,13 @@ class _wide_mlp_train(Function):
             hs = [torch.empty(*x.shape[:-1], 256, device=x.device, dtype=torch.float32) for _ in range(nl - 1)]
             h = torch.empty(*x.shape[:-1], ws[-1].shape[0], device=x.device, dtype=torch.float32)
             hid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in hs])
-            _lib.check(lib.sn_mlp_wide_forward_train_f16x3(C.byref(desc), _lib.dev(x2, "x"), rows, hid, _lib.dev(h, "out"),
+            # one bit per hidden unit (set = output > 0): all the backward DATA path needs of the saved outputs (32 bytes per row and layer
+            # instead of 1 KiB; the weight gradients still read the outputs themselves)
+            bits = [torch.empty(rows, 8, device=x.device, dtype=torch.int32) for _ in range(nl - 1)] if WIDE_MLP_SIGN_BITS else []
+            bid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in bits]) if bits else None
+            _lib.check(lib.sn_mlp_wide_forward_train_f16x3(C.byref(desc), _lib.dev(x2, "x"), rows, hid, bid, _lib.dev(h, "out"),
                                                            wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_mlp_wide_forward_train_f16x3")
+            ctx.sign_bits = bits
         elif WIDE_MLP_FORWARD_NATIVE and x.shape[-1] <= 256 and weights[-1].shape[0] <= 256:
             # one kernel for all layers: true fp32 on the matrix cores, activation fused, hidden outputs saved (sn_mlp_wide_forward_train)
             nl = len(weights)
@@ -659,8 +665,14 @@ class _wide_mlp_train(Function):
         gh = [torch.empty(N, 256, device=x.device, dtype=torch.float32) for _ in range(nl - 1)]
         hid = (C.c_void_p * (nl - 1))(*[h.reshape(N, 256).data_ptr() for h in hs])
         ghp = (C.c_void_p * (nl - 1))(*[g.data_ptr() for g in gh])
-        _lib.check(lib.sn_mlp_wide_backward(C.byref(desc), _lib.dev(gy2, "grad_output"), hid, N, _lib.dev(gx, "grad_input"), ghp,
-                                            ws_buf.data_ptr(), ws_buf.numel(), _lib.stream()), "sn_mlp_wide_backward")
+        bits = getattr(ctx, "sign_bits", None)
+        if bits:
+            bid = (C.c_void_p * (nl - 1))(*[t.data_ptr() for t in bits])
+            _lib.check(lib.sn_mlp_wide_backward_bits(C.byref(desc), _lib.dev(gy2, "grad_output"), bid, N, _lib.dev(gx, "grad_input"), ghp,
+                                                     ws_buf.data_ptr(), ws_buf.numel(), _lib.stream()), "sn_mlp_wide_backward_bits")
+        else:
+            _lib.check(lib.sn_mlp_wide_backward(C.byref(desc), _lib.dev(gy2, "grad_output"), hid, N, _lib.dev(gx, "grad_input"), ghp,
+                                                ws_buf.data_ptr(), ws_buf.numel(), _lib.stream()), "sn_mlp_wide_backward")
         grads_w = []
         inputs = [x2.contiguous()] + [h.reshape(N, 256) for h in hs]
         outs = gh + [gy2]

@@ -317,3 +317,34 @@ def test_forward_cat_under_autograd_matches_cat_of_the_encoder(gpu):
     with torch.no_grad():                           # inference route: the same values
         c = enc.forward_cat(x, extra, bound=1.0)
     assert torch.equal(c, b.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,din,n_out,leaky", [(20000, 143, 2, True), (16384 + 77, 64, 5, False), (40000, 143, 16, True)])
+def test_wide_mlp_backward_from_sign_bits_is_bit_identical(gpu, N, din, n_out, leaky):
+    """The split-fp16 training forward also writes one sign bit per hidden unit (32 bytes per row and layer); the backward data path that reads
+    those (sn_mlp_wide_backward_bits, k_mlp_wide<5>) must give exactly what the one reading the [N, 256] fp32 outputs gives (k_mlp_wide<4>):
+    same arithmetic, the branch of every unit taken from a bit instead of a comparison."""
+    from sanerf_hq_amd import ops, synth
+    ws = [torch.from_numpy(synth.linear_weight(o, i, 950 + k, 2.0)).to(gpu) for k, (o, i) in enumerate([(256, din), (256, 256), (n_out, 256)])]
+    rng = np.random.default_rng(N)
+    x = torch.from_numpy(rng.standard_normal((N, din)).astype(np.float32)).to(gpu)
+    gy = torch.from_numpy((rng.standard_normal((N, n_out)) * 10.0 ** rng.uniform(-9, -1, (N, 1))).astype(np.float32)).to(gpu)
+
+    def run(bits):
+        ops.WIDE_MLP_SIGN_BITS = bits
+        try:
+            xs = x.clone().requires_grad_(True)
+            wl = [w.clone().requires_grad_(True) for w in ws]
+            y = ops._wide_mlp_train.apply(xs, leaky, *wl)
+            assert bool(y.grad_fn.sign_bits) == bits
+            y.backward(gy)
+            return y.detach(), xs.grad, [w.grad for w in wl]
+        finally:
+            ops.WIDE_MLP_SIGN_BITS = True
+
+    ya, gxa, gwa = run(True)
+    yb, gxb, gwb = run(False)
+    assert torch.equal(ya, yb) and torch.equal(gxa, gxb)
+    for a_, b_ in zip(gwa, gwb):
+        assert torch.equal(a_, b_)
