@@ -768,8 +768,12 @@ __device__ __forceinline__ void dma16x4(const void *gptr, uint32_t lds_byte_offs
                  "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" : : "v"(gptr), "s"(base) : "memory");
 }
 
-template <int XMODE, bool N1 = false, bool SAVE = false>   // SAVE (sn_mlp_wide_forward_train, split-fp16 form): every hidden layer's post-activation output is also
-                                           // written to a.dump[layer] ([N, 256] fp32) as its tiles leave the accumulators: what the backward pass needs.
+template <int XMODE, bool N1 = false, int SAVE = 0>   // SAVE 1 (sn_mlp_wide_forward_train_f16x3): every hidden layer's post-activation output is also written to
+                                           // a.dump[layer] ([N, 256] fp32), and its signs to a.bits[layer], as its tiles leave the accumulators: what the backward
+                                           // pass needs.  SAVE 2 (sn_mlp_wide_backward_bits): the BACKWARD data path on this kernel -- the "MLP" is the transposed
+                                           // one in reverse layer order, a tile leaving the accumulators is multiplied by the activation's derivative (from
+                                           // a.bits) and written to a.dump (the gradient w.r.t. that layer's pre-activation), no activation on the way to the
+                                           // next layer, rows scaled by a power of two on the way in and back on the way out (as k_mlp_wide<4>).
                                            // N1: the narrow last layer has <= 32 outputs -- ONE output tile per k-step instead of the padded pair (fused mask head:
                                            // n_inst = 2; a template so that the two forms of the layer are never both in one kernel: accumulators that meet at a
                                            // control-flow merge get copied wholesale)
@@ -787,6 +791,30 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     bool ok = n < a.N;
     const float *xrow = a.x + (size_t)(ok ? n : 0u) * a.din;
     const uint32_t ntiles = XMODE == 3 ? a.T >> 2 : 1u;
+    float row_scale = 1.0f, row_unscale = 1.0f;            // SAVE 2: see k_mlp_wide<4>
+    uint32_t sbits[4] = {0u, 0u, 0u, 0u};                  // SAVE 1: sign bits of the layer whose tiles are leaving (this lane's 8 tiles x 16 registers); SAVE 2: those read
+    if constexpr (SAVE == 2) {
+        float mx = 0.0f;
+        for (uint32_t c = 8u * half; c < a.din; c += 16u) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t cc = c + i;
+                const float t = xrow[cc < a.din ? cc : a.din - 1u];
+                mx = fmaxf(mx, cc < a.din ? fabsf(t) : 0.0f);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const uint32_t mbits = __float_as_uint(mx);
+        const int e = (int)((mbits >> 23) & 255u) - 127;
+        if (mx > 0.0f && mx < __builtin_inff() && e > -100 && e < 100) {
+            row_scale = __uint_as_float((uint32_t)(127 - e) << 23);
+            row_unscale = __uint_as_float((uint32_t)(127 + e) << 23);
+        }
+        if (a.nl > 1u) {
+            const uint4 sb = *reinterpret_cast<const uint4 *>(a.bits[0] + ((size_t)(ok ? n : a.N - 1u) * 2u + half) * 4u);
+            sbits[0] = sb.x; sbits[1] = sb.y; sbits[2] = sb.z; sbits[3] = sb.w;
+        }
+    }
     float *lds_bias = reinterpret_cast<float *>(lds_w + WIDE_NBUF * WIDE_CHUNK_U4);      // [nl][WIDE], zero where absent
     float *lds_x = lds_bias + SN_MAX_LAYERS * WIDE;                               // [128][xs]
     const uint32_t xs = a.xs;
@@ -911,7 +939,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     prefetch_first_pair(0u);
 
     const float act_slope = a.leaky ? 0.01f : 0.0f;
-    auto act = [&](float t) { return __builtin_fmaxf(t, t * act_slope); };   // k_mlp_wide: multiply + max (network.py:65-66)
+    auto act = [&](float t) { if constexpr (SAVE == 2) return t; else return __builtin_fmaxf(t, t * act_slope); };   // k_mlp_wide: multiply + max (network.py:65-66); backward: escape_tile applied the derivative
     auto bias_tile = [&](uint32_t l, int mt, floatx16 &b) {      // register r of this lane = neuron 32 mt + (r&3) + 8 (r>>2) + 4 half
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -926,11 +954,37 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
     // ESC: the layer's last k-step -- finished tiles leave the accumulators for `prev` two tiles behind the matrix pipe (tiles 6 and 7 in
     // the next layer's FIRST chunk, before it overwrites them).  The empty asm makes the moved value opaque: without it the compiler keeps
     // reading the accumulator itself, whose life then overlaps the next layer's.
-    uint32_t sbits[4] = {0u, 0u, 0u, 0u};                  // SAVE: sign bits of the layer whose tiles are leaving (this lane's 8 tiles x 16 registers)
     auto escape_tile = [&](auto tc, uint32_t lsrc) {       // lsrc: the layer whose outputs these are
         constexpr int t = decltype(tc)::value;
+        if constexpr (SAVE == 2) {  // backward: times the activation's derivative (bit 16 t + r), parked for the next layer, written out unscaled
+            const float slope = a.leaky ? 0.01f : 0.0f;
+            const bool hid = lsrc < a.nl - 1u;
+            const uint32_t w16 = sbits[t >> 1] >> (16 * (t & 1));
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                float v = acc[t][r] * ((!hid || ((w16 >> r) & 1u)) ? 1.0f : slope);
+                asm("" : "+v"(v));
+                prev[16 * t + r] = v;
+            });
+            if (hid) {
+                if (ok) {
+                    float *drow = a.dump[lsrc] + (size_t)n * WIDE + 32u * t + 4u * half;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4 *>(drow + 8 * q) = make_float4(prev[16 * t + 4 * q] * row_unscale, prev[16 * t + 4 * q + 1] * row_unscale,
+                                                                              prev[16 * t + 4 * q + 2] * row_unscale, prev[16 * t + 4 * q + 3] * row_unscale);
+                }
+                if constexpr (t == WIDE_MT - 1) {           // the layer's last tile has left: fetch the next hidden layer's bits (used from its last k-step on)
+                    if (lsrc + 2u < a.nl) {
+                        const uint4 sb = *reinterpret_cast<const uint4 *>(a.bits[lsrc + 1u] + ((size_t)(ok ? n : a.N - 1u) * 2u + half) * 4u);
+                        sbits[0] = sb.x; sbits[1] = sb.y; sbits[2] = sb.z; sbits[3] = sb.w;
+                    }
+                }
+            }
+            return;
+        }
         static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; float v = acc[t][r]; asm("" : "+v"(v)); prev[16 * t + r] = v; });
-        if constexpr (SAVE) {       // register r of this lane = neuron 32 t + (r & 3) + 8 (r >> 2) + 4 half of row n
+        if constexpr (SAVE == 1) {  // register r of this lane = neuron 32 t + (r & 3) + 8 (r >> 2) + 4 half of row n
             if (ok && lsrc < a.nl - 1u) {                     // (the first layer's first chunk "escapes" tiles of a layer that does not exist: lsrc = ~0)
                 float *drow = a.dump[lsrc] + (size_t)n * WIDE + 32u * t + 4u * half;
 #pragma unroll
@@ -1017,6 +1071,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
                 const float t = xrow[c < a.din ? c : a.din - 1u];
                 v[i] = (ok && c < a.din) ? t : 0.0f;
             }
+        }
+        if constexpr (SAVE == 2) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) v[i] *= row_scale;
         }
     };
     // operand = input k-step kxn: loads at tile 0, split in tiles 2..5
@@ -1337,7 +1395,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd)
                 *reinterpret_cast<float4 *>(reg + r * RS + 32u * mt + 8u * qd + 4u * half) =
-                    make_float4(acc[mt][4 * qd], acc[mt][4 * qd + 1], acc[mt][4 * qd + 2], acc[mt][4 * qd + 3]);
+                    make_float4(acc[mt][4 * qd] * row_unscale, acc[mt][4 * qd + 1] * row_unscale, acc[mt][4 * qd + 2] * row_unscale, acc[mt][4 * qd + 3] * row_unscale);   // (row_unscale = 1 outside the backward mode)
         if (half == 0u) { stat[2u * r] = mean; stat[2u * r + 1u] = rstd; }
         float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (a.ln_w) { w4 = reinterpret_cast<const float4 *>(a.ln_w)[lane]; b4 = reinterpret_cast<const float4 *>(a.ln_b)[lane]; }
@@ -1365,6 +1423,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float t = acc[mt][4 * qd + i];
+                if constexpr (SAVE == 2) t *= row_unscale;
                 if (a.ln_w) {              // wave-uniform; index clamped so that the loads need no per-lane branch
                     const uint32_t mi = m0 + i < LL.out ? m0 + i : LL.out - 1u;
                     t = (t - mean) * rstd * a.ln_w[mi] + a.ln_b[mi];
@@ -1391,12 +1450,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wide_j(WideArgs a) {
 #ifdef SN_EXPERIMENTS
 static int g_wide_jit = 1;
 static int g_wide_narrow1 = 1;       // sn_debug_set("wide_narrow1", 0): the fused mask head's last layer as a padded tile PAIR as before (A/B)
+static int g_wide_bwd_j = 0;         // sn_debug_set("wide_bwd_j", 1): sn_mlp_wide_backward_bits on k_mlp_wide_j<.., 2> instead of k_mlp_wide<5> (A/B: measured equal, 0.213 vs 0.212 ms,
+                                     // bit-identical -- the pass is bound by its 348 MB of output, not by the skeleton; profiles/r05/mlp_bwd_ab.txt)
 static int g_mask_head16 = 8;        // sn_debug_set("mask_head16", 0): the fused mask head on k_mlp_wide_j<3> (rounds 3-4) also where k_mask16 (mlp16.inc) takes it (A/B)
 static bool wide_jit(int xmode) { (void)xmode; return g_wide_jit != 0; }
 #else
 static constexpr bool wide_jit(int) { return true; }
 static constexpr int g_wide_narrow1 = 1;
 static constexpr int g_mask_head16 = 8;
+static constexpr int g_wide_bwd_j = 0;
 
 #endif
 
@@ -1406,6 +1468,7 @@ extern "C" int sn_debug_set(const char *key, int value) {
     if (strcmp(key, "wide_jit") == 0) { g_wide_jit = value; return SN_OK; }
     if (strcmp(key, "wide_narrow1") == 0) { g_wide_narrow1 = value; return SN_OK; }
     if (strcmp(key, "mask_head16") == 0) { g_mask_head16 = value; return SN_OK; }
+    if (strcmp(key, "wide_bwd_j") == 0) { g_wide_bwd_j = value; return SN_OK; }
     if (strcmp(key, "bin_pull") == 0) { g_bin_pull = value; return SN_OK; }          // grid_binned.hip: entries as products (0) or references (1); -1 = by C
     set_error("debug_set: unknown key '%s'", key);
     return SN_ERR_INVALID;
@@ -1505,7 +1568,9 @@ extern "C" size_t sn_mlp_wide_workspace_bytes(const sn_mlp_desc *mlp) {
 
 static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, const float *ln_bias, float ln_eps,
                              const float *x, uint32_t N, float *out, void *workspace, size_t workspace_bytes,
-                             sn_stream_t stream, float *const *hidden, uint32_t *const *sign_bits = nullptr) {
+                             sn_stream_t stream, float *const *hidden, uint32_t *const *sign_bits = nullptr, const sn_mlp_desc *bwd_of = nullptr) {
+    // bwd_of: `mlp` is the TRANSPOSED perceptron of *bwd_of in reverse layer order (sn_mlp_wide_backward_bits): weights are packed transposed, hidden[l] receives
+    // the gradient w.r.t. the pre-activation that follows backward layer l, sign_bits[l] are READ (k_mlp_wide_j<.., 2>)
     SN_REQUIRE(mlp, "mlp_wide: mlp is NULL");
     if (N == 0) return SN_OK;
     SN_REQUIRE(x && out && workspace, "mlp_wide: x/out/workspace must be device pointers");
@@ -1518,11 +1583,12 @@ static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, con
     SN_REQUIRE(workspace_bytes >= u4 * sizeof(uint4), "mlp_wide: workspace too small (%zu bytes, need %zu)", workspace_bytes, u4 * sizeof(uint4));
     const uint32_t nl = mlp->num_layers, din = mlp->dims[0];
     hipStream_t st = (hipStream_t)stream;
-    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = 0; pa.pair_ks = 0;
+    pa.din = din; pa.nl = nl; pa.pack = reinterpret_cast<uint4 *>(workspace); pa.transposed = bwd_of ? 1 : 0; pa.pair_ks = 0;
     uint32_t max_threads = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         pa.w[l] = mlp->weight[l];
-        pa.in_dim[l] = (l == 0 ? din : (uint32_t)WIDE) + ((l > 0 && ((mlp->skip_mask >> l) & 1u)) ? din : 0u);
+        pa.in_dim[l] = bwd_of ? bwd_of->dims[nl - 1 - l]                      // columns of the forward layer's [out, in] weight
+                              : (l == 0 ? din : (uint32_t)WIDE) + ((l > 0 && ((mlp->skip_mask >> l) & 1u)) ? din : 0u);
         SN_REQUIRE(l == 0 || mlp->dims[l] == (uint32_t)WIDE, "mlp_wide: dims[%u] must be %d", l, WIDE);
         const uint32_t nks = (pa.layer[l].uses_h ? WIDE_HKS : 0) + pa.layer[l].x_ks;
         const uint32_t th = nks * (uint32_t)WIDE_MT * 64u;
@@ -1537,6 +1603,7 @@ static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, con
         for (uint32_t l = 0; l + 1 < nl; ++l) {
             SN_REQUIRE(hidden[l] && table_aligned(hidden[l]), "mlp_wide_forward_train: hidden[%u] must be a 16-byte aligned device pointer", l);
             wa.dump[l] = hidden[l];
+            if (bwd_of) SN_REQUIRE(sign_bits && sign_bits[l], "mlp_wide_backward_bits: sign bits of a hidden layer are missing");
             if (sign_bits && sign_bits[l]) {
                 SN_REQUIRE(table_aligned(sign_bits[l]), "mlp_wide_forward_train: sign_bits[%u] must be 16-byte aligned", l);
                 wa.bits[l] = sign_bits[l];
@@ -1581,13 +1648,25 @@ static int wide_forward_impl(const sn_mlp_desc *mlp, const float *ln_weight, con
     } while (0)
 #define SN_MLP_LAUNCH_SAVE(MODE)                                                                                      \
     do {                                                                                                              \
-        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<MODE, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_mlp_wide_j<MODE, false, true>), dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);    \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<MODE, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_mlp_wide_j<MODE, false, 1>), dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);    \
     } while (0)
+#define SN_MLP_LAUNCH_BWD(MODE)                                                                                       \
+    do {                                                                                                              \
+        SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_wide_j<MODE, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_mlp_wide_j<MODE, false, 2>), dim3(div_up(N, WIDE_ROWS)), dim3(256), lds, st, wa);       \
+    } while (0)
+#ifdef SN_EXPERIMENTS
+    if (bwd_of) { if (xmode == 2) SN_MLP_LAUNCH_BWD(2); else if (xmode == 1) SN_MLP_LAUNCH_BWD(1); else SN_MLP_LAUNCH_BWD(0); }
+    else
+#else
+    SN_REQUIRE(!bwd_of, "mlp_wide: the backward on k_mlp_wide_j is compiled into experiments builds only");
+#endif
     if (hidden) { if (xmode == 2) SN_MLP_LAUNCH_SAVE(2); else if (xmode == 1) SN_MLP_LAUNCH_SAVE(1); else SN_MLP_LAUNCH_SAVE(0); }
     else if (xmode == 2) SN_MLP_LAUNCH(2); else if (xmode == 1) SN_MLP_LAUNCH(1); else SN_MLP_LAUNCH(0);
 #undef SN_MLP_LAUNCH
 #undef SN_MLP_LAUNCH_SAVE
+#undef SN_MLP_LAUNCH_BWD
     SN_LAUNCH_CHECK("k_mlp_wide");
     return SN_OK;
 }
@@ -1728,7 +1807,26 @@ extern "C" int sn_mlp_wide_backward_bits(const sn_mlp_desc *mlp, const float *gr
                                          float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes,
                                          sn_stream_t stream) {
     SN_REQUIRE(sign_bits, "mlp_wide_backward_bits: sign_bits is NULL");
-    return wide_backward_impl(mlp, grad_out, nullptr, sign_bits, N, grad_in, grad_hidden, workspace, workspace_bytes, stream);
+    if (g_wide_bwd_j == 0) return wide_backward_impl(mlp, grad_out, nullptr, sign_bits, N, grad_in, grad_hidden, workspace, workspace_bytes, stream);   // k_mlp_wide<5>: the product path
+    // experiments builds: the same pass on k_mlp_wide_j (operands just in time, tiles leave the accumulators under the next MFMAs): the transposed perceptron in
+    // reverse layer order.  Measured equal to k_mlp_wide<5> (see g_wide_bwd_j).
+    SN_REQUIRE(mlp, "mlp_wide_backward_bits: mlp is NULL");
+    if (N == 0) return SN_OK;
+    const uint32_t nl = mlp->num_layers;
+    SN_REQUIRE(nl >= 2 && nl <= SN_MAX_LAYERS, "mlp_wide_backward_bits: num_layers=%u outside 2..%d", nl, SN_MAX_LAYERS);
+    SN_REQUIRE(grad_out && grad_hidden && grad_in && workspace, "mlp_wide_backward_bits: NULL pointer");
+    if (mlp->skip_mask != 0u) { set_error("mlp_wide_backward_bits: skip layers are not supported (use autograd's GEMMs)"); return SN_ERR_UNSUPPORTED; }
+    sn_mlp_desc b = *mlp;
+    for (uint32_t l = 0; l <= nl; ++l) b.dims[l] = mlp->dims[nl - l];
+    for (uint32_t l = 0; l < nl; ++l) { b.weight[l] = mlp->weight[nl - 1 - l]; b.bias[l] = nullptr; }
+    float *dump_r[SN_MAX_LAYERS] = {};
+    uint32_t *bits_r[SN_MAX_LAYERS] = {};
+    for (uint32_t l = 0; l + 1 < nl; ++l) {                                   // after backward layer l: forward layer nl-2-l's output
+        SN_REQUIRE(grad_hidden[nl - 2 - l] && sign_bits[nl - 2 - l], "mlp_wide_backward_bits: grad_hidden[%u] / sign_bits[%u] is NULL", nl - 2 - l, nl - 2 - l);
+        dump_r[l] = grad_hidden[nl - 2 - l];
+        bits_r[l] = const_cast<uint32_t *>(sign_bits[nl - 2 - l]);
+    }
+    return wide_forward_impl(&b, nullptr, nullptr, 0.0f, grad_out, N, grad_in, workspace, workspace_bytes, stream, dump_r, bits_r, mlp);
 }
 
 // Mask head in one kernel (renderer.py:304-305, 376-385): k_mlp_wide<3> builds each sample's MLP input -- the C = 8 hash-grid
