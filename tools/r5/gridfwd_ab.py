@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""GridEncoder.forward_cat (k_grid_forward_rows, C = 8 fp32) at the training step's and the 400x400 mask render's sizes."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from sanerf_hq_amd.gridencoder import GridEncoder
+gpu = torch.device("cuda:0")
+enc = GridEncoder(input_dim=3, num_levels=16, level_dim=8, base_resolution=16, log2_hashmap_size=19, desired_resolution=512).to(gpu)
+for B, coherent in ((131072, True), (131072, False), (5120000, True)):
+    if coherent:   # samples along rays, as a render produces them
+        R = B // 32
+        o = torch.rand(R, 1, 3, device=gpu) * 1.6 - 0.8; d = torch.nn.functional.normalize(torch.randn(R, 1, 3, device=gpu), dim=-1)
+        t = torch.sort(torch.rand(R, 32, 1, device=gpu) - 0.5, dim=1).values
+        x = (o + d * t).clamp(-0.99, 0.99).reshape(-1, 3)
+    else:
+        x = torch.rand(B, 3, device=gpu) * 1.98 - 0.99
+    ex = torch.randn(B, 15, device=gpu)
+    with torch.no_grad():
+        for _ in range(3): y = enc.forward_cat(x, ex, bound=1.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): y = enc.forward_cat(x, ex, bound=1.0)
+        e1.record(); torch.cuda.synchronize()
+    print(f"B={B} {'along rays' if coherent else 'uniform   '}: {e0.elapsed_time(e1) / 10:.3f} ms  checksum {float(y.double().sum()):.6f}")
