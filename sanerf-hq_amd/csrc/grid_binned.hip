@@ -909,9 +909,10 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     SN_LAUNCH_CHECK("k_bin_plan");
     const size_t lds = (size_t)(BIN_ROWS_MAX + BIN_FLOATS) * sizeof(float);      // 80 KiB: two workgroups per CU
     const dim3 ga(lay.max_items), gm(lay.max_shared_bins < 2048u ? lay.max_shared_bins : 2048u);
-    // entries as products (push) or as references (pull, k_bin_refs): references pay when a product is long (C >= 8: 32+ bytes per pair);
+    // entries as products (push) or as references (pull, k_bin_refs).  References win at every C measured (C = 8: 0.55 -> 0.33 ms, C = 2: 0.26 -> 0.235, 0.27 -> 0.26,
+    // 0.16 -> 0.144 ms; profiles/r05/bin_stats_*.txt): even where a product is as short as a reference the sorted runs replace scattered 8 + 2 byte stores;
     // a reference holds the sample index in 22 bits
-    const bool pull = (g_bin_pull < 0 ? C >= 8u : g_bin_pull != 0) && C >= 2u && B <= (1u << REF_KEY_SHIFT);   // (C >= 2: the references live in the products' region)
+    const bool pull = (g_bin_pull < 0 ? true : g_bin_pull != 0) && C >= 2u && B <= (1u << REF_KEY_SHIFT);   // (C >= 2: the references live in the products' region)
     uint2 *eref = reinterpret_cast<uint2 *>(econtrib);
     const BinPull bp{grad, eref, B, layout};
     constexpr size_t refs_lds = (size_t)REF_WINDOW * 2 * sizeof(uint32_t);

@@ -16,6 +16,9 @@ from sanerf_hq_amd import ops  # noqa: E402
 from sanerf_hq_amd.gridencoder import grid_encode  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("SN_BIN_PULL") is not None:          # experiments build: entries as products (0) / references (1) whatever C
+    from sanerf_hq_amd import _lib as _l
+    _l.check(_l.lib().sn_debug_set(b"bin_pull", int(os.environ["SN_BIN_PULL"])), "sn_debug_set")
 CASES = [("mask / SAM grid  C=8 L=16 T=2^19, 4096 rays x 32", dict(L=16, C=8, log2T=19, desired=512), 4096, 32),
          ("main grid        C=2 L=16 T=2^19, 4096 rays x 32", dict(L=16, C=2, log2T=19, desired=4096), 4096, 32),
          ("proposal grid 0  C=2 L=5  T=2^17, 4096 rays x 128", dict(L=5, C=2, log2T=17, desired=128), 4096, 128),
