@@ -237,7 +237,8 @@ typedef struct sn_render_tuning {
                                   * the vector-ALU-bound proposal stages of one band overlap the texture-path-bound last stage of the other
                                   * (bit-neutral): 0 automatic (>= 2048 workgroups: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 fp16;
                                   * >= 512 with the feature stage: 400x400 + SAM head 3.00 -> 2.82 ms), 1 never, 2 whenever the image has two bands
-                                  * of whole tile rows */
+                                  * of whole tile rows, K > 2: K bands dealt alternately to the two streams (measured, profiles/r05/band_count_ab.txt: two bands
+                                  * are the optimum at 400 / 800 / 1600 pixels -- 800x800 fp16: 3.84 none, 3.59 two, 4.18 four; 1600x1600: 13.36, 12.71, 12.70) */
     int32_t exact_early_out;     /* the last stage leaves the march once the transmittance of all 64 rays of a wave has underflowed to EXACTLY 0 (every later
                                   * weight is alpha * 0: bit-neutral; opaque scenes only): 2 = on, 0 / 1 = off (the default: behind proposal stages it buys nothing, in a
                                   * single-stage schedule 6.07 -> 4.43 ms on an opaque field at 0.5-1 % cost on a semi-transparent one).

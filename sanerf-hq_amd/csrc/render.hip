@@ -2873,7 +2873,8 @@ static BandPlan band_plan(const sn_render_cfg *cfg, uint32_t N, uint32_t W) {
     // (400x400 + SAM-feature head, BASELINE configs[2]: 3.00 -> 2.82 ms, 2.58 -> 2.41 with fp16 tables; without it 400x400 gains nothing)
     if (mode == 0 && blocks_for(N, W, tile_log2w(cfg)) < (cfg->with_feat ? 512u : 2048u)) return p;
     const uint32_t rows = N / W;
-    const uint32_t half_rows = ((rows / 2u + 15u) / 16u) * 16u;          // whole 16-row tile rows; the first band takes the odd one
+    const uint32_t nbands = mode > 2 ? (uint32_t)mode : 2u;              // band_streams = K > 2: K bands, dealt alternately to the two streams (A/B; measured: see DESIGN section 7)
+    const uint32_t half_rows = (((rows + nbands - 1u) / nbands + 15u) / 16u) * 16u;   // whole 16-row tile rows; the first bands take the odd ones
     if (half_rows == 0u || half_rows >= rows) return p;
     const uint64_t c = (uint64_t)half_rows * W;
     if (c < p.chunk) p.chunk = (uint32_t)c;                               // (images beyond the scratch cap keep its chunks and alternate them)
