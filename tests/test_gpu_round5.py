@@ -348,3 +348,23 @@ def test_wide_mlp_backward_from_sign_bits_is_bit_identical(gpu, N, din, n_out, l
     assert torch.equal(ya, yb) and torch.equal(gxa, gxb)
     for a_, b_ in zip(gwa, gwb):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bands", [3, 4, 7])
+def test_more_than_two_row_bands_are_bit_identical(gpu, bands):
+    """tuning.band_streams = K > 2: K row bands dealt alternately to the two HIP streams (measured slower than two bands, kept as an A/B switch):
+    every output, the per-stage tensors included, equals the single-stream render bit for bit, ragged last band included."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    steps = [48, 24, 16]
+    params = synthetic_params(steps, heads=False, seed=23)
+    model = product_model(params, steps, False, gpu)
+    H, W = 120, 72                                     # 7.5 tile rows of 16: the last band is ragged
+    ro, rd = rm.generate_rays(synth.orbit_pose(1.1, 15.0, 75.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    plan = rm.RenderPlan(model, steps, torch.float32)
+    want = ("inds", "weights", "bins")
+    one = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=want, tuning=rm.Tuning(band_streams=1)).items()}
+    many = {k: v.clone() for k, v in rm.render_rays(plan, ro, rd, tile_w=W, want=want, tuning=rm.Tuning(band_streams=bands), out={}).items()}
+    assert set(one) == set(many) and "image" in one
+    for k in one:
+        assert torch.equal(one[k], many[k]), k
