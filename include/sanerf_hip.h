@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 10
+#define SN_ABI_VERSION 11
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -188,6 +188,38 @@ int sn_rm_mask_nll(const float *logits, const int64_t *labels, uint32_t N, uint3
  * into [-2,2]^3 like sn_rm_contract if `contract`).  Nothing here is differentiated by the reference. */
 int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
                            uint32_t N, uint32_t T, int contract, float *real_bins, float *rays_t, float *xyzs, sn_stream_t stream);
+
+/* The same with the grid encoder's first step folded in (gridencoder/grid.py:156): grid_bound > 0 makes `xyzs` receive
+ * (x + grid_bound) / (2 grid_bound), the unit-cube coordinates sn_grid_encode_forward takes; grid_bound = 0 = sn_rm_sample_positions. */
+int sn_rm_sample_positions_ex(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
+                              uint32_t N, uint32_t T, int contract, float grid_bound, float *real_bins, float *rays_t, float *xyzs,
+                              sn_stream_t stream);
+
+/* Training-time jitter of the sampling positions (perturb=True) from a caller-supplied uniform [0,1) tensor `uniform` [N,T] (NULL: none):
+ *   kind 0 (renderer.py:262-270, stage-0 bins, T = num_steps[0] + 1): out = clamp(linspace(0, 1, T) + (uniform - 0.5) / (T - 1), 0, 1)
+ *   kind 1 (renderer.py:97-102, sample_pdf's u):                       out = linspace(0.5/T, 1 - 0.5/T, T) + (uniform - 0.5) / T
+ * out [N,T].  The reference draws torch.rand_like per stage; one draw for all stages, sliced, is statistically the same. */
+int sn_rm_jitter(const float *uniform, uint32_t N, uint32_t T, int kind, float *out, sn_stream_t stream);
+
+/* Per-ray sums of the training path in one pass (renderer.py:327-347 with network.py:164-170's colour = cat([geo_feat, SH(d)])):
+ *   weights_sum[n] = sum_t w;  depth[n] = sum_t w rays_t;  f_image[n, 0:15] = sum_t w raw[n,t,1:16];  f_image[n, 15:31] = SH4(d/|d|) weights_sum
+ * raw [N,T,16] = grid_mlp's output ([sigma_raw | 15 geometry channels], network.py:94,151-153), rays_d [N,3] un-normalised.
+ * The backward entry returns d/d weights [N,T] and d/d raw [N,T,16] (channel 0 = 0) from the gradients of the three outputs
+ * (each may be NULL = zero).  raw / grad_raw 16-byte aligned. */
+int sn_rm_ray_composite(const float *weights, const float *rays_t, const float *raw, const float *rays_d, uint32_t N, uint32_t T,
+                        float *weights_sum, float *depth, float *f_image, sn_stream_t stream);
+int sn_rm_ray_composite_backward(const float *weights, const float *rays_t, const float *raw, const float *rays_d, const float *grad_weights_sum,
+                                 const float *grad_depth, const float *grad_f_image, uint32_t N, uint32_t T, float *grad_weights, float *grad_raw,
+                                 sn_stream_t stream);
+
+/* sn_rm_proposal_loss with every written value multiplied by scale * (scale_dev ? *scale_dev : 1): the mean's 1 / (N Tr) and autograd's
+ * incoming (device-resident) gradient scalar without extra elementwise passes. */
+int sn_rm_proposal_loss_scaled(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                               uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, sn_stream_t stream);
+
+/* Clears `bytes` bytes at `ptr` (both multiples of 16) with a kernel on `stream` -- capturable in a HIP graph, unlike a memset node whose
+ * replays faulted once the allocator had reused the memory (round 4); the zeros_like of gridencoder/grid.py:83. */
+int sn_zero(void *ptr, size_t bytes, sn_stream_t stream);
 
 /* nerf/renderer.py:333-338,361,384: out[n,k] = sum_t weights[n,t] * values[n,t,k]  (K may be 1). */
 int sn_rm_composite(const float *weights, const float *values, uint32_t N, uint32_t T, uint32_t K,
@@ -413,6 +445,27 @@ int sn_mlp_wide_backward_bits(const sn_mlp_desc *mlp, const float *grad_out, con
                               float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes, sn_stream_t stream);
 int sn_mlp_wide_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *const *hidden, uint32_t N,
                          float *grad_in, float *const *grad_hidden, void *workspace, size_t workspace_bytes, sn_stream_t stream);
+
+/* The reference's SMALL bias-free ReLU perceptrons under training (nerf/network.py:9-29 `MLP` as instantiated at network.py:94, 98, 143:
+ * grid_mlp 32-64-64-16, view_mlp 31-32-32-3, prop_mlp 10-16-1; also BASELINE configs[0]'s 16-32-16 / 31-32-3), one kernel per direction on
+ * the matrix cores in true fp32 (v_mfma_f32_32x32x2_f32: exact products, fixed summation order), replacing F.linear + F.relu per layer.
+ *   forward:  out [N, dL] = raw output; hidden[l] [N, d_{l+1}] = post-ReLU output of layer l (l < L-1), 16-byte aligned.
+ *             act: SN_SMALL_ACT_TRUNC_EXP0  aux_out [N]     = exp(out[:, 0])                      (trunc_exp, activation.py:5-11, network.py:155,179)
+ *                  SN_SMALL_ACT_SIGMOID_BG  aux_out [N, dL] = sigmoid(out) + (1 - aux_in[n]) * bg  (renderer.py:349-353; aux_in = weights_sum, dL <= 4)
+ *   backward: the whole data path.  grad_out [N, dL] (gradient of `out`, may be NULL) and grad_aux (gradient of aux_out, may be NULL; the
+ *             activation's derivative is applied here: trunc_exp's exp(clamp(x, -15, 15)), activation.py:13-17) are combined into
+ *             grad_last [N, dL] (gradient of the last pre-activation), then grad_hidden[l] [N, d_{l+1}] = gradient of layer l's pre-activation
+ *             (ReLU branch from the sign of hidden[l], as torch's in-place backward) and grad_in [N, d0] (NULL: not wanted).
+ *             grad_aux_in [N] (act SIGMOID_BG, may be NULL) = gradient of aux_in.  Weight gradients: sn_linear_wgrad on
+ *             (x, grad_hidden[0]), (hidden[l-1], grad_hidden[l]), (hidden[L-2], grad_last).
+ * sn_mlp_small_supported: 1 if this build instantiates the descriptor's widths (others: SN_ERR_UNSUPPORTED, the caller keeps its own layers). */
+enum { SN_SMALL_ACT_NONE = 0, SN_SMALL_ACT_TRUNC_EXP0 = 1, SN_SMALL_ACT_SIGMOID_BG = 2 };
+int sn_mlp_small_supported(const sn_mlp_desc *mlp);
+int sn_mlp_small_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, float *out, int32_t act,
+                               const float *aux_in, float bg, float *aux_out, sn_stream_t stream);
+int sn_mlp_small_backward(const sn_mlp_desc *mlp, const float *grad_out, const float *grad_aux, int32_t act, const float *out_raw, float bg,
+                          const float *const *hidden, uint32_t N, float *grad_in, float *const *grad_hidden, float *grad_last, float *grad_aux_in,
+                          sn_stream_t stream);
 
 /* Weight gradient of an nn.Linear over a training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order
  * (deterministic).  K, N <= 64 (the radiance / proposal MLPs, nerf/network.py:9-29): register-tiled VALU kernel.

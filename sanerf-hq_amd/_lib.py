@@ -73,7 +73,7 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 10  # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 11  # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),
@@ -102,6 +102,15 @@ _SIGNATURES = {
     "sn_rm_distort_loss": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_proposal_loss": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_sample_positions": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _vp, _vp, _vp, _vp]),
+    "sn_rm_sample_positions_ex": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _f32, _vp, _vp, _vp, _vp]),
+    "sn_rm_jitter": (_int, [_vp, _u32, _u32, _int, _vp, _vp]),
+    "sn_rm_ray_composite": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "sn_rm_ray_composite_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "sn_rm_proposal_loss_scaled": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp]),
+    "sn_zero": (_int, [_vp, C.c_size_t, _vp]),
+    "sn_mlp_small_supported": (_int, [C.POINTER(MlpDesc)]),
+    "sn_mlp_small_forward_train": (_int, [C.POINTER(MlpDesc), _vp, _u32, _vp, _vp, _i32, _vp, _f32, _vp, _vp]),
+    "sn_mlp_small_backward": (_int, [C.POINTER(MlpDesc), _vp, _vp, _i32, _vp, _f32, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "sn_rm_composite": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     "sn_rm_composite_backward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     "sn_rm_grid_composite": (_int, [_vp, _vp, _u32, _u32, _f32, C.POINTER(GridDesc), _u32, _vp, _vp]),

@@ -7,6 +7,7 @@
 // reference's [N, T] row-major layout so they interoperate with torch code on either side.
 // The fused renderer (render.hip) inlines the same arithmetic with a [T, N] scratch layout.
 #include "sn_common.h"
+#include "sh_basis.inc"
 
 #include <float.h>
 
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void k_weights_backward(const float *__restric
 // (contracted if asked).  Same arithmetic as the fused renderer's real_bin / sample position.
 __global__ __launch_bounds__(256) void k_sample_positions(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                           const float *__restrict__ nears, const float *__restrict__ fars,
-                                                          const float *__restrict__ bins, uint32_t N, uint32_t T, int contract,
+                                                          const float *__restrict__ bins, uint32_t N, uint32_t T, int contract, float grid_bound,
                                                           float *__restrict__ real_bins, float *__restrict__ rays_t, float *__restrict__ xyzs) {
     SN_POISON_ALL();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,7 +360,126 @@ __global__ __launch_bounds__(256) void k_sample_positions(const float *__restric
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const float m = rays_d[(size_t)n * 3 + k] * tmid; p[k] = rays_o[(size_t)n * 3 + k] + m; }
     if (contract) contract3(p[0], p[1], p[2]);
+    if (grid_bound > 0.0f) {                     // gridencoder/grid.py:156: (x + bound) / (2 * bound), the encoder's own first step
+        const float two_b = 2.0f * grid_bound;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = (p[k] + grid_bound) / two_b;
+    }
     xyzs[o * 3 + 0] = p[0]; xyzs[o * 3 + 1] = p[1]; xyzs[o * 3 + 2] = p[2];
+}
+
+// Training-time jitter of a stage's sampling positions from ONE uniform random tensor (the reference draws torch.rand_like per stage):
+//   kind 0  renderer.py:262-270   out[n,i] = clamp(linspace(0, 1, T)[i] + (r[n,i] - 0.5) / (T - 1), 0, 1)      stage-0 bins, T = num_steps[0] + 1
+//   kind 1  renderer.py:97-102    out[n,i] = linspace(0.5/T, 1 - 0.5/T, T)[i] + (r[n,i] - 0.5) / T              sample_pdf's u
+// r == NULL: no jitter (perturb=False): the plain linspace rows.
+__global__ __launch_bounds__(256) void k_jitter(const float *__restrict__ r, uint32_t N, uint32_t T, int kind, float *__restrict__ out) {
+    SN_POISON_ALL();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)N * T) return;
+    const uint32_t i = (uint32_t)(t % T);
+    const float u = r ? r[t] - 0.5f : 0.0f;
+    if (kind == 0) {
+        const float step = T > 1u ? 1.0f / (float)(T - 1u) : 0.0f;
+        float v = linspace_at(0.0f, 1.0f, step, T, i);
+        if (r) { v = v + u / (float)(T - 1u); v = fminf(fmaxf(v, 0.0f), 1.0f); }
+        out[t] = v;
+    } else {
+        const float lo = (float)(0.5 / T), hi = (float)(1 - 0.5 / T);        // Python doubles rounded once, as torch.linspace receives them
+        const float step = T > 1u ? (hi - lo) / (float)(T - 1u) : 0.0f;
+        float v = linspace_at(lo, hi, step, T, i);
+        if (r) v = v + u / (float)T;
+        out[t] = v;
+    }
+}
+
+// Per-ray head of the training path (renderer.py:327-347 + network.py:164-170) without per-sample colour tensors:
+//   weights_sum = sum_t w;  depth = sum_t w t_mid;  f_image[0:15] = sum_t w raw[t, 1:16];  f_image[15:31] = SH4(d / |d|) * weights_sum
+// (the direction is constant along a ray, so sum_t w_t SH(d) = SH(d) sum_t w_t -- the reference evaluates SH per sample, renderer.py:293-295).
+// raw [N,T,16] is grid_mlp's output ([sigma_raw | geo_feat]); 16 lanes per ray, lane c owns channel c (lane 0: weights_sum and depth).
+__global__ __launch_bounds__(256) void k_ray_composite(const float *__restrict__ weights, const float *__restrict__ rays_t, const float *__restrict__ raw,
+                                                       const float *__restrict__ rays_d, uint32_t N, uint32_t T, float *__restrict__ wsum,
+                                                       float *__restrict__ depth, float *__restrict__ f_image) {
+    SN_POISON_ALL();
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, n_raw = gid >> 4, c = gid & 15u;
+    const uint32_t n = n_raw < N ? n_raw : N - 1u;
+    const float *w = weights + (size_t)n * T, *tm = rays_t + (size_t)n * T, *rw = raw + (size_t)n * T * 16u + c;
+    float acc = 0.0f, dsum = 0.0f;
+    if (c == 0u) {
+        for (uint32_t j = 0; j < T; ++j) { const float wj = w[j]; acc += wj; dsum = __builtin_fmaf(wj, tm[j], dsum); }
+    } else {
+        for (uint32_t j = 0; j < T; ++j) acc = __builtin_fmaf(w[j], rw[(size_t)j * 16u], acc);
+    }
+    const float ws = __shfl(acc, (int)(threadIdx.x & 48u), 64);            // lane 0 of the ray's 16-lane group
+    float x = rays_d[(size_t)n * 3], y = rays_d[(size_t)n * 3 + 1], z = rays_d[(size_t)n * 3 + 2];
+    const float inv = 1.0f / sqrtf(x * x + y * y + z * z);                 // renderer.py:294
+    x *= inv; y *= inv; z *= inv;
+    float sh[16];
+    {
+        const unsigned C = 4u;
+        SN_SH_POWERS
+        (void)x4; (void)x5; (void)x6; (void)x7; (void)y4; (void)y5; (void)y6; (void)y7; (void)z4; (void)z5; (void)z6; (void)z7;
+        SN_SH_VALUES(sh);
+    }
+    float mine = sh[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mine = c == (uint32_t)k ? sh[k] : mine;
+    if (n_raw >= N) return;
+    float *f = f_image + (size_t)n * 31u;
+    if (c == 0u) { wsum[n] = acc; depth[n] = dsum; }
+    else f[c - 1u] = acc;
+    if (c < 16u) f[15u + c] = mine * ws;
+}
+
+// Backward of k_ray_composite, one thread per sample:
+//   d/d w[n,t]      = sum_c g_f[c] raw[n,t,1+c] + (g_wsum + sum_k g_f[15+k] SH_k) + g_depth t_mid[n,t]
+//   d/d raw[n,t,1+c] = w[n,t] g_f[c];   d/d raw[n,t,0] = 0
+__global__ __launch_bounds__(256) void k_ray_composite_backward(const float *__restrict__ weights, const float *__restrict__ rays_t,
+                                                                const float *__restrict__ raw, const float *__restrict__ rays_d,
+                                                                const float *__restrict__ g_wsum, const float *__restrict__ g_depth,
+                                                                const float *__restrict__ g_f, uint32_t N, uint32_t T,
+                                                                float *__restrict__ g_weights, float *__restrict__ g_raw) {
+    SN_POISON_ALL();
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= (uint64_t)N * T) return;
+    const uint32_t n = (uint32_t)(t / T);
+    float x = rays_d[(size_t)n * 3], y = rays_d[(size_t)n * 3 + 1], z = rays_d[(size_t)n * 3 + 2];
+    const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
+    x *= inv; y *= inv; z *= inv;
+    float sh[16];
+    {
+        const unsigned C = 4u;
+        SN_SH_POWERS
+        (void)x4; (void)x5; (void)x6; (void)x7; (void)y4; (void)y5; (void)y6; (void)y7; (void)z4; (void)z5; (void)z6; (void)z7;
+        SN_SH_VALUES(sh);
+    }
+    const float *gf = g_f ? g_f + (size_t)n * 31u : nullptr;
+    float k_ray = g_wsum ? g_wsum[n] : 0.0f;
+    if (gf) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) k_ray = __builtin_fmaf(gf[15 + k], sh[k], k_ray);
+    }
+    const float4 *rp = reinterpret_cast<const float4 *>(raw + t * 16u);
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    const float rv[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    const float w = weights[t];
+    float gw = k_ray;
+    float go[16];
+    go[0] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        const float g = gf ? gf[c] : 0.0f;
+        gw = __builtin_fmaf(g, rv[1 + c], gw);
+        go[1 + c] = w * g;
+    }
+    if (g_depth) gw = __builtin_fmaf(g_depth[n], rays_t[t], gw);
+    g_weights[t] = gw;
+    float4 *op = reinterpret_cast<float4 *>(g_raw + t * 16u);
+    op[0] = float4{go[0], go[1], go[2], go[3]}; op[1] = float4{go[4], go[5], go[6], go[7]};
+    op[2] = float4{go[8], go[9], go[10], go[11]}; op[3] = float4{go[12], go[13], go[14], go[15]};
+}
+
+__global__ __launch_bounds__(256) void k_zero16(uint4 *__restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) p[i] = uint4{0u, 0u, 0u, 0u};
 }
 
 // Inter-level proposal loss of one proposal stage against the final stage (nerf/renderer.py:30-57), one wave per ray:
@@ -373,9 +493,11 @@ __global__ __launch_bounds__(256) void k_sample_positions(const float *__restric
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__ bins, const float *__restrict__ weights,
                                                        const float *__restrict__ ref_bins, const float *__restrict__ ref_w,
-                                                       uint32_t N, uint32_t T, uint32_t Tr, float *__restrict__ out) {
+                                                       uint32_t N, uint32_t T, uint32_t Tr, float scale, const float *__restrict__ scale_dev,
+                                                       float *__restrict__ out) {
     SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(8))) double pl_lds[];
+    const float sc = scale_dev ? scale * scale_dev[0] : scale;      // (scale 1 and no device factor: the plain value / gradient, exact)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_raw = blockIdx.x * 4u + wave;
     const uint32_t n = n_raw < N ? n_raw : N - 1u;           // spare waves redo the last ray and store nothing
@@ -424,7 +546,7 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
     if constexpr (!BACKWARD) {
 #pragma unroll
         for (int k = 32; k >= 1; k >>= 1) part += __shfl_xor(part, k);
-        if (lane == 0u && n_raw < N) out[n] = part;
+        if (lane == 0u && n_raw < N) out[n] = part * sc;
     } else {
         __builtin_amdgcn_wave_barrier();
         double acc = 0.0;
@@ -440,7 +562,7 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
             while (a0 < a1) { const uint32_t mid = (a0 + a1) >> 1; if (hi_s[mid] >= (int32_t)i) a1 = mid; else a0 = mid + 1u; }
             uint32_t c0 = 0u, c1 = Tr;                       // jb + 1 = number of j with lo_j <= i
             while (c0 < c1) { const uint32_t mid = (c0 + c1) >> 1; if (lo_s[mid] <= (int32_t)i) c0 = mid + 1u; else c1 = mid; }
-            out[(size_t)n * T + i] = c0 > a0 ? (float)(G[c0] - G[a0]) : 0.0f;
+            out[(size_t)n * T + i] = (c0 > a0 ? (float)(G[c0] - G[a0]) : 0.0f) * sc;
         }
     }
 }
@@ -632,18 +754,68 @@ int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigma
     return SN_OK;
 }
 
-int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
-                           uint32_t N, uint32_t T, int contract, float *real_bins, float *rays_t, float *xyzs, sn_stream_t stream) {
+int sn_rm_sample_positions_ex(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
+                              uint32_t N, uint32_t T, int contract, float grid_bound, float *real_bins, float *rays_t, float *xyzs, sn_stream_t stream) {
     SN_REQUIRE(rays_o && rays_d && nears && fars && bins && real_bins && rays_t && xyzs, "sample_positions: NULL pointer");
+    SN_REQUIRE(grid_bound >= 0.0f, "sample_positions: grid_bound must be >= 0 (0 = positions as they are)");
     if (N == 0) return SN_OK;
     hipLaunchKernelGGL(k_sample_positions, dim3(div_up((uint64_t)N * (T + 1), 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars,
-                       bins, N, T, contract, real_bins, rays_t, xyzs);
+                       bins, N, T, contract, grid_bound, real_bins, rays_t, xyzs);
     SN_LAUNCH_CHECK("k_sample_positions");
     return SN_OK;
 }
 
-int sn_rm_proposal_loss(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
-                        uint32_t Tr, float *loss_per_ray, float *grad_weights, sn_stream_t stream) {
+int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *bins,
+                           uint32_t N, uint32_t T, int contract, float *real_bins, float *rays_t, float *xyzs, sn_stream_t stream) {
+    return sn_rm_sample_positions_ex(rays_o, rays_d, nears, fars, bins, N, T, contract, 0.0f, real_bins, rays_t, xyzs, stream);
+}
+
+int sn_rm_jitter(const float *uniform, uint32_t N, uint32_t T, int kind, float *out, sn_stream_t stream) {
+    SN_REQUIRE(out, "jitter: NULL pointer");
+    SN_REQUIRE(kind == 0 || kind == 1, "jitter: kind 0 (stage-0 bins) or 1 (sample_pdf u), got %d", kind);
+    SN_REQUIRE(T >= 1, "jitter: T >= 1");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_jitter, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, uniform, N, T, kind, out);
+    SN_LAUNCH_CHECK("k_jitter");
+    return SN_OK;
+}
+
+int sn_rm_ray_composite(const float *weights, const float *rays_t, const float *raw, const float *rays_d, uint32_t N, uint32_t T,
+                        float *weights_sum, float *depth, float *f_image, sn_stream_t stream) {
+    SN_REQUIRE(weights && rays_t && raw && rays_d && weights_sum && depth && f_image, "ray_composite: NULL pointer");
+    if (N == 0) return SN_OK;
+    hipLaunchKernelGGL(k_ray_composite, dim3(div_up((uint64_t)N * 16u, 256)), dim3(256), 0, (hipStream_t)stream, weights, rays_t, raw, rays_d, N, T,
+                       weights_sum, depth, f_image);
+    SN_LAUNCH_CHECK("k_ray_composite");
+    return SN_OK;
+}
+
+int sn_rm_ray_composite_backward(const float *weights, const float *rays_t, const float *raw, const float *rays_d, const float *grad_weights_sum,
+                                 const float *grad_depth, const float *grad_f_image, uint32_t N, uint32_t T, float *grad_weights, float *grad_raw,
+                                 sn_stream_t stream) {
+    SN_REQUIRE(weights && rays_t && raw && rays_d && grad_weights && grad_raw, "ray_composite_backward: NULL pointer");
+    SN_REQUIRE(table_aligned(raw) && table_aligned(grad_raw), "ray_composite_backward: raw / grad_raw must be 16-byte aligned");
+    if (N == 0 || T == 0) return SN_OK;
+    hipLaunchKernelGGL(k_ray_composite_backward, dim3(div_up((uint64_t)N * T, 256)), dim3(256), 0, (hipStream_t)stream, weights, rays_t, raw, rays_d,
+                       grad_weights_sum, grad_depth, grad_f_image, N, T, grad_weights, grad_raw);
+    SN_LAUNCH_CHECK("k_ray_composite_backward");
+    return SN_OK;
+}
+
+int sn_zero(void *ptr, size_t bytes, sn_stream_t stream) {
+    SN_REQUIRE(ptr || bytes == 0, "zero: NULL pointer");
+    SN_REQUIRE(table_aligned(ptr) && bytes % 16u == 0, "zero: pointer and size must be multiples of 16 bytes");
+    if (bytes == 0) return SN_OK;
+    const size_t n16 = bytes / 16u;
+    uint32_t blocks = div_up(n16, 256 * 4);
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(k_zero16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint4 *>(ptr), n16);
+    SN_LAUNCH_CHECK("k_zero16");
+    return SN_OK;
+}
+
+int sn_rm_proposal_loss_scaled(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                               uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, sn_stream_t stream) {
     SN_REQUIRE(bins && weights && ref_bins && ref_weights, "proposal_loss: NULL pointer");
     SN_REQUIRE((loss_per_ray != nullptr) != (grad_weights != nullptr), "proposal_loss: pass exactly one of loss_per_ray (forward) / grad_weights (backward)");
     SN_REQUIRE(T >= 1 && Tr >= 1 && T <= 512 && Tr <= 512, "proposal_loss: 1..512 samples per ray (got %u, %u)", T, Tr);
@@ -655,13 +827,18 @@ int sn_rm_proposal_loss(const float *bins, const float *weights, const float *re
     };
     if (loss_per_ray) {
         const size_t lds = lds_bytes(false);
-        hipLaunchKernelGGL(k_proposal_loss<false>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, loss_per_ray);
+        hipLaunchKernelGGL(k_proposal_loss<false>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, loss_per_ray);
     } else {
         const size_t lds = lds_bytes(true);
-        hipLaunchKernelGGL(k_proposal_loss<true>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, grad_weights);
+        hipLaunchKernelGGL(k_proposal_loss<true>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, grad_weights);
     }
     SN_LAUNCH_CHECK("k_proposal_loss");
     return SN_OK;
+}
+
+int sn_rm_proposal_loss(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                        uint32_t Tr, float *loss_per_ray, float *grad_weights, sn_stream_t stream) {
+    return sn_rm_proposal_loss_scaled(bins, weights, ref_bins, ref_weights, N, T, Tr, 1.0f, nullptr, loss_per_ray, grad_weights, stream);
 }
 
 int sn_rm_distort_loss(const float *bins, const float *weights, uint32_t N, uint32_t T, float *loss_per_ray, float *grad_weights,

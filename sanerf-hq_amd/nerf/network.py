@@ -15,7 +15,8 @@ import torch.nn.functional as F
 
 from ..activation import trunc_exp
 from ..encoding import get_encoder
-from ..ops import small_linear, wide_mlp_fusable, wide_mlp_train
+from ..ops import (SMALL_ACT_SIGMOID_BG, SMALL_ACT_TRUNC_EXP0, small_linear, small_mlp_fusable, small_mlp_train,
+                   wide_mlp_fusable, wide_mlp_train)
 from .renderer import NeRFRenderer
 
 # constants the reference hard-codes in NeRFNetwork.__init__ (network.py:90-143)
@@ -40,10 +41,25 @@ class MLP(nn.Module):
         self.net = _chain([dim_in] + [dim_hidden] * (num_layers - 1) + [dim_out], bias)
 
     def forward(self, x):
+        if small_mlp_fusable(x, list(self.net)):                 # training, one of the reference network's shapes: one kernel per direction
+            return small_mlp_train(x, list(self.net))[0]
         *hidden, last = self.net
         for layer in hidden:
             x = F.relu(small_linear(x, layer), inplace=True)
         return small_linear(x, last)
+
+    def forward_trunc_exp(self, x):
+        """(raw, trunc_exp(raw[..., 0])) -- network.py:155,179; folded into the kernel when the fused training route applies."""
+        if small_mlp_fusable(x, list(self.net)):
+            return small_mlp_train(x, list(self.net), SMALL_ACT_TRUNC_EXP0)
+        raw = self.forward(x)
+        return raw, trunc_exp(raw[..., 0])
+
+    def forward_sigmoid_bg(self, x, weights_sum, bg: float):
+        """sigmoid(self(x)) + (1 - weights_sum)[..., None] * bg -- renderer.py:349-353; one kernel when the fused training route applies."""
+        if small_mlp_fusable(x, list(self.net)) and self.net[-1].weight.shape[0] <= 4:
+            return small_mlp_train(x, list(self.net), SMALL_ACT_SIGMOID_BG, weights_sum, float(bg))[1]
+        return torch.sigmoid(self.forward(x)) + (1 - weights_sum).unsqueeze(-1) * bg
 
 
 class SkipConnMLP(nn.Module):
@@ -107,8 +123,19 @@ class NeRFNetwork(NeRFRenderer):
     # ---- field queries (network.py:146-186) ----
     def common_forward(self, x):
         grid_output = self.grid(x, bound=self.bound)
-        raw = self.grid_mlp(grid_output)
-        return trunc_exp(raw[..., 0]), raw[..., 1:], grid_output
+        raw, sigma = self.grid_mlp.forward_trunc_exp(grid_output)
+        return sigma, raw[..., 1:], grid_output
+
+    # ---- the same queries on unit-cube coordinates (raymarching.sample_positions(grid_bound=self.bound)): what the renderer's training
+    # ---- path calls when this class's own forward() / density() are in effect (NeRFRenderer._unit_field_ok) ----
+    def field_unit(self, x01):
+        """(sigma [..], raw [.., 16]) of network.py:146-170 without the colour concatenation: raw = [sigma_raw | geo_feat]."""
+        raw, sigma = self.grid_mlp.forward_trunc_exp(self.grid.forward_unit(x01))
+        return sigma, raw
+
+    def density_unit(self, x01, proposal):
+        raw, sigma = self.prop_mlp[proposal].forward_trunc_exp(self.prop_encoders[proposal].forward_unit(x01))
+        return sigma
 
     def forward(self, x, d, **kwargs) -> Dict[str, torch.Tensor]:
         sigma, geo, grid_output = self.common_forward(x)
@@ -116,8 +143,8 @@ class NeRFNetwork(NeRFRenderer):
 
     def density(self, x, proposal=-1):
         if 0 <= proposal < len(self.prop_encoders):
-            raw = self.prop_mlp[proposal](self.prop_encoders[proposal](x, bound=self.bound))
-            return dict(sigma=trunc_exp(raw.squeeze(-1)), geo_feat=None)
+            raw, sigma = self.prop_mlp[proposal].forward_trunc_exp(self.prop_encoders[proposal](x, bound=self.bound))
+            return dict(sigma=sigma, geo_feat=None)
         sigma, geo, _ = self.common_forward(x)
         return dict(sigma=sigma, geo_feat=geo)
 

@@ -37,6 +37,8 @@ def sample_pdf(bins, weights, T, perturb=False):
 
 def proposal_loss(all_bins, all_weights):
     """Inter-level proposal loss (nerf/renderer.py:30-57)."""
+    if (len(all_bins) > 1 and all(w.is_cuda and w.dim() == 2 and w.shape[-1] <= rm.PROPOSAL_LOSS_MAX_T for w in all_weights)):
+        return rm.proposal_loss_all(all_bins, all_weights)       # one autograd node, one kernel per stage and direction
     ref_bins = all_bins[-1].detach()
     ref_w = all_weights[-1].detach()
     total = 0
@@ -332,9 +334,102 @@ class NeRFRenderer(nn.Module):
         return results
 
     # ---------------------------------------------------------------------------------------
+    fused_training_ops = True     # RGB-mode training: unit-cube positions, fused small MLPs, one-kernel per-ray head (False: the operator chain)
+
+    def _unit_path_ok(self, rays_o, bg_color, return_mask) -> bool:
+        """The training route built from the fused training operators (_run_autograd_unit): the reference network's own field
+        (raw = [sigma_raw | 15 geometry channels], degree-4 SH, scalar background) without feature heads."""
+        opt = self.opt
+        return (self.fused_training_ops and rays_o.is_cuda and not torch.is_tensor(bg_color) and not opt.with_sam and not return_mask > 0
+                and self._fused_kind() == "main" and hasattr(self, "field_unit") and hasattr(self, "density_unit")
+                and max(opt.num_steps) <= rm.WEIGHTS_BACKWARD_MAX_T and not torch.is_autocast_enabled())
+
+    def _run_autograd_unit(self, rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal):
+        """renderer.py:261-357 for RGB-mode training out of the fused training operators: per stage one geometry kernel that emits the grid
+        encoder's unit-cube coordinates, grid_encode, ONE kernel for the stage's perceptron (trunc_exp folded in), one for sigma -> weights;
+        then one kernel for weights_sum / depth / f_image (SH once per ray) and one for view_mlp + sigmoid + background.  All jitter comes from
+        ONE torch.rand call.  Same results as _run_autograd up to fp32 round-off (tests/test_gpu_train_ops.py)."""
+        opt = self.opt
+        rays_o = rays_o.contiguous()
+        rays_d = rays_d.contiguous()
+        N = rays_o.shape[0]
+        device = rays_o.device
+        steps = list(opt.num_steps)
+        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if cam_near_far is not None:
+            nears = torch.maximum(nears, cam_near_far[:, [0]])
+            fars = torch.minimum(fars, cam_near_far[:, [1]])
+        rand = torch.rand(N * sum(T + 1 for T in steps), device=device) if perturb else None
+        cursor = [0]
+
+        def draw(T1):                                       # the next N*T1 uniform numbers (contiguous), or None
+            if rand is None:
+                return None
+            r = rand[cursor[0]:cursor[0] + N * T1]
+            cursor[0] += N * T1
+            return r
+
+        prop_needs_grad = update_proposal and torch.is_grad_enabled() and any(
+            p.requires_grad for m in (list(self.prop_encoders) + list(self.prop_mlp)) for p in m.parameters())
+        wants_prop_loss = self.training and opt.lambda_proposal > 0 and update_proposal
+        all_bins, all_weights = [], []
+        bins = weights = None
+        first_stage = 0
+        if len(steps) > 1 and not prop_needs_grad and not wants_prop_loss and self.fused_proposals:
+            # proposal stages that receive no gradient: the fused inference kernels on the same jitter (see _run_autograd)
+            if perturb:
+                b0 = rm.jitter(draw(steps[0] + 1), N, steps[0] + 1, 0)
+                u_tabs = {k: rm.jitter(draw(steps[k] + 1), N, steps[k] + 1, 1) for k in range(1, len(steps))}
+            else:
+                b0, u_tabs = torch.linspace(0, 1, steps[0] + 1, device=device), None
+            with torch.no_grad():
+                got = rm.render_rays(self._get_plan(), rays_o, rays_d, cam_near_far=cam_near_far, bins0_table=b0, u_tables=u_tabs,
+                                     skip_final=True, out={})
+            bins = got[f"bins{len(steps) - 1}"]
+            first_stage = len(steps) - 1
+        last = len(steps) - 1
+        raw = rays_t = None
+        for k, T in enumerate(steps):
+            if k < first_stage:
+                continue
+            if k == first_stage and first_stage > 0:
+                pass
+            elif k == 0:
+                bins = rm.jitter(draw(T + 1), N, T + 1, 0, device=device)
+            elif perturb:
+                bins = rm.sample_pdf(bins, weights, T + 1, False, u=rm.jitter(draw(T + 1), N, T + 1, 1))
+            else:
+                bins = rm.sample_pdf(bins, weights, T + 1, False)
+            real_bins, rays_t, x01 = rm.sample_positions(rays_o, rays_d, nears, fars, bins, contract=opt.contract, grid_bound=float(self.bound))
+            if k != last:
+                with torch.set_grad_enabled(update_proposal and torch.is_grad_enabled()):
+                    sigmas = self.density_unit(x01, k)
+            else:
+                sigmas, raw = self.field_unit(x01)
+            weights = rm.weights_from_sigma(real_bins, sigmas, opt.background == "last_sample")
+            if self.training:
+                all_bins.append(bins)
+                all_weights.append(weights)
+        weights_sum, depth, f_image = rm.ray_composite(weights, rays_t, raw, rays_d)
+        image = self.view_mlp.forward_sigmoid_bg(f_image, weights_sum, float(bg_color))
+        results = {}
+        if self.training and not opt.with_mask:
+            results["num_points"] = N * steps[-1]
+            results["weights"] = weights
+            if opt.lambda_proposal > 0 and update_proposal:
+                results["proposal_loss"] = proposal_loss(all_bins, all_weights)
+            if opt.lambda_distort > 0:
+                results["distort_loss"] = distort_loss(bins, weights)
+        results["weights_sum"] = weights_sum
+        results["depth"] = depth
+        results["image"] = image
+        return results
+
     def _run_autograd(self, rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal,
                       return_feats, return_mask, H, W):
         """The stage loop of renderer.py:261-357 in torch autograd over the HIP encoders."""
+        if self._unit_path_ok(rays_o, bg_color, return_mask):
+            return self._run_autograd_unit(rays_o, rays_d, bg_color, perturb, cam_near_far, update_proposal)
         opt = self.opt
         rays_o = rays_o.contiguous()
         rays_d = rays_d.contiguous()

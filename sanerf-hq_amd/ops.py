@@ -88,6 +88,17 @@ def _binned_workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def _zeros_f32(shape, device) -> torch.Tensor:
+    """zeros_like(embeddings) of grid.py:83 with the fill as a library kernel on the current stream (sn_zero)."""
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    nbytes = t.numel() * 4
+    if nbytes and nbytes % 16 == 0 and t.data_ptr() % 16 == 0:
+        _lib.check(_lib.lib().sn_zero(t.data_ptr(), nbytes, _lib.stream()), "zero")
+    else:
+        t.zero_()
+    return t
+
+
 class _grid_encode(Function):
     """forward/backward contract of gridencoder/grid.py:24-95."""
 
@@ -132,7 +143,7 @@ class _grid_encode(Function):
         inputs, table, dy_dx = ctx.saved_tensors
         offs, B, D, Cc, L, S, H, gridtype, interpolation, max_level, align_corners, emb_dtype = ctx.meta
         grad = grad.contiguous().float()
-        grad_embeddings = torch.zeros(table.shape, device=table.device, dtype=torch.float32)   # grid.py:83
+        grad_embeddings = _zeros_f32(table.shape, table.device)                                # grid.py:83
         grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
         lib = _lib.lib()
         need = _binned_workspace_bytes(B, D, Cc, L, max_level, offs, dy_dx)
@@ -184,7 +195,7 @@ class _grid_encode_cat(Function):
         inputs, table = ctx.saved_tensors
         offs, B, D, Cc, L, S, H, gridtype, interpolation, align_corners, emb_dtype = ctx.meta
         g = grad[:, :L * Cc].contiguous().float()
-        grad_embeddings = torch.zeros(table.shape, device=table.device, dtype=torch.float32)   # grid.py:83
+        grad_embeddings = _zeros_f32(table.shape, table.device)                                # grid.py:83
         lib = _lib.lib()
         need = _binned_workspace_bytes(B, D, Cc, L, L, offs, None)
         if need:
@@ -257,6 +268,15 @@ class GridEncoder(nn.Module):
         inputs = (inputs + bound) / (2 * bound)   # [-bound, bound] -> [0, 1] (grid.py:156)
         lead = list(inputs.shape[:-1])
         flat = inputs.view(-1, self.input_dim)
+        out = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                          flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
+        return out.view(lead + [self.output_dim])
+
+    def forward_unit(self, x01, max_level=None):
+        """forward() for inputs that are already the unit-cube coordinates (inputs + bound) / (2 bound) of grid.py:156
+        (raymarching.sample_positions(grid_bound=...) produces them in the same kernel as the positions)."""
+        lead = list(x01.shape[:-1])
+        flat = x01.reshape(-1, self.input_dim)
         out = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                           flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
         return out.view(lead + [self.output_dim])
@@ -543,6 +563,146 @@ class _small_linear(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
         return gx, gw, gb
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's small ReLU perceptrons under autograd: one kernel per direction (csrc/mlp_small.hip)
+# ---------------------------------------------------------------------------------------------
+SMALL_MLP_FUSED = True              # False: nn.Linear layers through torch / rocBLAS (A/B, tests)
+SMALL_ACT_NONE, SMALL_ACT_TRUNC_EXP0, SMALL_ACT_SIGMOID_BG = 0, 1, 2
+_small_ws: dict = {}
+
+
+def _small_desc(weights):
+    desc = _lib.MlpDesc()
+    desc.num_layers = len(weights)
+    desc.activation = 0
+    desc.skip_mask = 0
+    desc.dims[0] = weights[0].shape[1]
+    for i, w in enumerate(weights):
+        desc.weight[i] = w.data_ptr()
+        desc.bias[i] = None
+        desc.dims[i + 1] = w.shape[0]
+    return desc
+
+
+def _wgrad_into(x2, gy2, gw, cache=_small_ws):
+    """gw[N,K] = gy2[M,N]^T x2[M,K] through sn_linear_wgrad (fixed summation order)."""
+    lib = _lib.lib()
+    M, K, N = x2.shape[0], x2.shape[1], gy2.shape[1]
+    need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
+    if need == 0:
+        raise RuntimeError("sn_linear_wgrad: " + lib.sn_last_error().decode())
+    ws = cache.get(x2.device)
+    if ws is None or ws.numel() < need:
+        ws = cache[x2.device] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x2.device)
+    _lib.check(lib.sn_linear_wgrad(_lib.dev(x2, "x"), _lib.dev(gy2, "grad_output"), M, K, N, _lib.dev(gw, "grad_weight"),
+                                   ws.data_ptr(), ws.numel(), _lib.stream()), "sn_linear_wgrad")
+
+
+class _small_mlp_train(Function):
+    """A bias-free ReLU `MLP` (network.py:9-29) of the reference network's sizes under autograd, with what follows it on the training path
+    folded in: act = SMALL_ACT_TRUNC_EXP0 also returns trunc_exp(out[..., 0]) (network.py:155,179; activation.py:5-17), act =
+    SMALL_ACT_SIGMOID_BG also returns sigmoid(out) + (1 - aux_in) * bg (renderer.py:349-353).  Forward: ONE kernel (sn_mlp_small_forward_train,
+    true fp32 on the matrix cores, hidden outputs saved).  Backward: ONE kernel for the data path (sn_mlp_small_backward) + sn_linear_wgrad per
+    layer.  Returns (raw output, activated output or None)."""
+
+    @staticmethod
+    def forward(ctx, x, act, aux_in, bg, *weights):
+        lib = _lib.lib()
+        lead = x.shape[:-1]
+        rows = x.numel() // x.shape[-1]
+        x2 = x.detach().reshape(rows, x.shape[-1]).contiguous().float()
+        ws = [w.detach().contiguous() for w in weights]
+        desc = _small_desc(ws)
+        nl = len(ws)
+        dev = x.device
+        hs = [torch.empty(rows, w.shape[0], device=dev, dtype=torch.float32) for w in ws[:-1]]
+        dout = ws[-1].shape[0]
+        out = torch.empty(rows, dout, device=dev, dtype=torch.float32)
+        aux = None
+        if act == SMALL_ACT_TRUNC_EXP0:
+            aux = torch.empty(rows, device=dev, dtype=torch.float32)
+        elif act == SMALL_ACT_SIGMOID_BG:
+            aux = torch.empty(rows, dout, device=dev, dtype=torch.float32)
+        ai = aux_in.detach().reshape(rows).contiguous().float() if aux_in is not None else None
+        hid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in hs])
+        _lib.check(lib.sn_mlp_small_forward_train(C.byref(desc), _lib.dev(x2, "x"), rows, hid, _lib.dev(out, "out"), int(act),
+                                                  _lib.dev(ai, "aux_in"), float(bg), _lib.dev(aux, "aux_out"), _lib.stream()),
+                   "sn_mlp_small_forward_train")
+        ctx.save_for_backward(x2, out, *hs, *ws)
+        ctx.meta = (nl, int(act), float(bg), tuple(x.shape), aux_in is not None)
+        ctx.set_materialize_grads(False)
+        out_v = out.view(*lead, dout)
+        if aux is None:
+            ctx.mark_non_differentiable()
+            return out_v, None
+        return out_v, (aux.view(*lead) if act == SMALL_ACT_TRUNC_EXP0 else aux.view(*lead, dout))
+
+    @staticmethod
+    def backward(ctx, g_out, g_aux):
+        nl, act, bg, xshape, has_aux_in = ctx.meta
+        saved = ctx.saved_tensors
+        x2, out = saved[0], saved[1]
+        hs, ws = saved[2:1 + nl], saved[1 + nl:]
+        n_w = len(ws)
+        if g_out is None and g_aux is None:
+            return (None,) * (4 + n_w)
+        lib = _lib.lib()
+        rows, dev = x2.shape[0], x2.device
+        dout = ws[-1].shape[0]
+        go = g_out.reshape(rows, dout).contiguous().float() if g_out is not None else None
+        ga = g_aux.reshape(rows, -1).contiguous().float() if g_aux is not None else None
+        desc = _small_desc(ws)
+        need_x = ctx.needs_input_grad[0]
+        gx = torch.empty(rows, x2.shape[1], device=dev, dtype=torch.float32) if need_x else None
+        ghs = [torch.empty_like(h) for h in hs]
+        glast = torch.empty(rows, dout, device=dev, dtype=torch.float32)
+        g_aux_in = torch.empty(rows, device=dev, dtype=torch.float32) if (has_aux_in and ctx.needs_input_grad[2] and ga is not None) else None
+        hid = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in hs])
+        ghp = (C.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in ghs])
+        _lib.check(lib.sn_mlp_small_backward(C.byref(desc), _lib.dev(go, "grad_out"), _lib.dev(ga, "grad_aux"), act, _lib.dev(out, "out_raw"), bg,
+                                             hid, rows, _lib.dev(gx, "grad_in"), ghp, _lib.dev(glast, "grad_last"), _lib.dev(g_aux_in, "grad_aux_in"),
+                                             _lib.stream()), "sn_mlp_small_backward")
+        ins = [x2] + list(hs)
+        gys = ghs + [glast]
+        gws = []
+        for i in range(nl):
+            if not ctx.needs_input_grad[4 + i]:
+                gws.append(None)
+                continue
+            gw = torch.empty(ws[i].shape, device=dev, dtype=torch.float32)
+            _wgrad_into(ins[i], gys[i], gw)
+            gws.append(gw)
+        g_ai = None
+        if g_aux_in is not None:
+            g_ai = g_aux_in
+        return (gx.view(xshape) if need_x else None), None, g_ai, None, *gws
+
+
+def small_mlp_fusable(x: torch.Tensor, layers) -> bool:
+    """Training-time route of an `MLP` through _small_mlp_train: CUDA fp32, autograd on, bias-free, widths this build instantiates."""
+    if not (SMALL_MLP_FUSED and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()):
+        return False
+    if not (1 <= len(layers) <= 4) or any(l.bias is not None or l.weight.dtype != torch.float32 for l in layers):
+        return False
+    if not (x.requires_grad or any(l.weight.requires_grad for l in layers)):
+        return False
+    key = (x.shape[-1],) + tuple(l.weight.shape[0] for l in layers)
+    ok = _small_supported.get(key)
+    if ok is None:
+        if x.shape[-1] != layers[0].weight.shape[1] or any(a.weight.shape[0] != b.weight.shape[1] for a, b in zip(layers[:-1], layers[1:])):
+            return False
+        ok = _small_supported[key] = bool(_lib.lib().sn_mlp_small_supported(C.byref(_small_desc([l.weight for l in layers]))))
+    return ok
+
+
+_small_supported: dict = {}
+
+
+def small_mlp_train(x: torch.Tensor, layers, act: int = SMALL_ACT_NONE, aux_in=None, bg: float = 0.0):
+    """(raw, activated) of the fused small perceptron; see _small_mlp_train."""
+    return _small_mlp_train.apply(x, act, aux_in, bg, *[l.weight for l in layers])
 
 
 WIDE_MLP_BACKWARD_MIN_ROWS = 16384

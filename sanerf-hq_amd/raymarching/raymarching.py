@@ -216,9 +216,10 @@ class _NoCtx:
         pass
 
 
-def sample_positions(rays_o, rays_d, nears, fars, bins, contract: bool = True):
+def sample_positions(rays_o, rays_d, nears, fars, bins, contract: bool = True, grid_bound: float = 0.0):
     """One stage's geometry (renderer.py:277-285), no autograd: bins [N,T+1] -> (real_bins [N,T+1], rays_t [N,T],
-    xyzs [N,T,3]); positions are contracted into [-2,2]^3 when `contract`."""
+    xyzs [N,T,3]); positions are contracted into [-2,2]^3 when `contract`.  grid_bound > 0: the positions come back as the
+    grid encoder's unit-cube coordinates (x + grid_bound) / (2 grid_bound) (gridencoder/grid.py:156) -- for `grid_encode` itself."""
     rays_o, rays_d = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
     bins = bins.detach().contiguous().float()
     N, T = bins.shape[0], bins.shape[1] - 1
@@ -229,11 +230,122 @@ def sample_positions(rays_o, rays_d, nears, fars, bins, contract: bool = True):
     real_bins = torch.empty(N, T + 1, device=dev, dtype=torch.float32)
     rays_t = torch.empty(N, T, device=dev, dtype=torch.float32)
     xyzs = torch.empty(N, T, 3, device=dev, dtype=torch.float32)
-    _lib.check(_lib.lib().sn_rm_sample_positions(_lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.dev(nears, "nears"),
-                                                 _lib.dev(fars, "fars"), _lib.dev(bins, "bins"), N, T, int(contract),
-                                                 _lib.dev(real_bins, "real_bins"), _lib.dev(rays_t, "rays_t"), _lib.dev(xyzs, "xyzs"),
-                                                 _lib.stream()), "sample_positions")
+    _lib.check(_lib.lib().sn_rm_sample_positions_ex(_lib.dev(rays_o, "rays_o"), _lib.dev(rays_d, "rays_d"), _lib.dev(nears, "nears"),
+                                                    _lib.dev(fars, "fars"), _lib.dev(bins, "bins"), N, T, int(contract), float(grid_bound),
+                                                    _lib.dev(real_bins, "real_bins"), _lib.dev(rays_t, "rays_t"), _lib.dev(xyzs, "xyzs"),
+                                                    _lib.stream()), "sample_positions")
     return real_bins, rays_t, xyzs
+
+
+def jitter(uniform: Optional[torch.Tensor], N: int, T: int, kind: int, device=None) -> torch.Tensor:
+    """Sampling positions of a training stage from one uniform [0,1) tensor (sn_rm_jitter): kind 0 = the stage-0 bins of renderer.py:262-270
+    (T = num_steps[0] + 1 edges, clamped to [0,1]), kind 1 = sample_pdf's u of renderer.py:97-102.  uniform: [N,T] (contiguous) or None."""
+    if uniform is not None:
+        uniform = uniform.reshape(N, T)
+        device = uniform.device
+    out = torch.empty(N, T, device=device, dtype=torch.float32)
+    _lib.check(_lib.lib().sn_rm_jitter(_lib.dev(uniform, "uniform"), N, T, int(kind), _lib.dev(out, "out"), _lib.stream()), "jitter")
+    return out
+
+
+class _ray_composite(Function):
+    """weights [N,T], rays_t [N,T], raw [N,T,16] (grid_mlp's output), rays_d [N,3] -> (weights_sum [N], depth [N], f_image [N,31]) in one
+    kernel (sn_rm_ray_composite; renderer.py:327-347 with colour = cat([geo_feat, SH(d)]), network.py:164-170); differentiable w.r.t.
+    weights and raw."""
+
+    @staticmethod
+    def forward(ctx, weights, rays_t, raw, rays_d):
+        w = weights.detach().contiguous().float()
+        tm = rays_t.detach().contiguous().float()
+        r = raw.detach().contiguous().float()
+        d = rays_d.detach().contiguous().float()
+        N, T = w.shape
+        assert r.shape == (N, T, 16) and d.shape == (N, 3)
+        ws = torch.empty(N, device=w.device, dtype=torch.float32)
+        depth = torch.empty(N, device=w.device, dtype=torch.float32)
+        f = torch.empty(N, 31, device=w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().sn_rm_ray_composite(_lib.dev(w, "weights"), _lib.dev(tm, "rays_t"), _lib.dev(r, "raw"), _lib.dev(d, "rays_d"), N, T,
+                                                  _lib.dev(ws, "weights_sum"), _lib.dev(depth, "depth"), _lib.dev(f, "f_image"), _lib.stream()),
+                   "ray_composite")
+        ctx.save_for_backward(w, tm, r, d)
+        ctx.set_materialize_grads(False)
+        return ws, depth, f
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_f):
+        w, tm, r, d = ctx.saved_tensors
+        if g_ws is None and g_depth is None and g_f is None:
+            return None, None, None, None
+        N, T = w.shape
+        c = lambda t: t.contiguous().float() if t is not None else None        # noqa: E731
+        g_ws, g_depth, g_f = c(g_ws), c(g_depth), c(g_f)
+        gw = torch.empty_like(w)
+        gr = torch.empty_like(r)
+        _lib.check(_lib.lib().sn_rm_ray_composite_backward(_lib.dev(w, "weights"), _lib.dev(tm, "rays_t"), _lib.dev(r, "raw"), _lib.dev(d, "rays_d"),
+                                                           _lib.dev(g_ws, "grad_weights_sum"), _lib.dev(g_depth, "grad_depth"), _lib.dev(g_f, "grad_f_image"),
+                                                           N, T, _lib.dev(gw, "grad_weights"), _lib.dev(gr, "grad_raw"), _lib.stream()),
+                   "ray_composite_backward")
+        return gw, None, gr, None
+
+
+def ray_composite(weights, rays_t, raw, rays_d):
+    return _ray_composite.apply(weights, rays_t, raw, rays_d)
+
+
+class _proposal_loss_all(Function):
+    """The whole inter-level proposal loss (nerf/renderer.py:30-57) as one autograd node: one kernel per proposal stage forward and backward,
+    the mean's 1 / (N Tr) and the incoming gradient scalar applied inside the kernels (sn_rm_proposal_loss_scaled)."""
+
+    @staticmethod
+    def forward(ctx, ref_bins, ref_weights, *bw):
+        ref_bins, ref_w = ref_bins.detach().contiguous().float(), ref_weights.detach().contiguous().float()
+        N, Tr = ref_w.shape
+        S = len(bw) // 2
+        bins = [b.detach().contiguous().float() for b in bw[:S]]
+        ws = [w.detach().contiguous().float() for w in bw[S:]]
+        per_ray = torch.empty(S, N, device=ref_w.device, dtype=torch.float32)
+        scale = 1.0 / float(N * Tr)
+        for k in range(S):
+            _lib.check(_lib.lib().sn_rm_proposal_loss_scaled(_lib.dev(bins[k], "bins"), _lib.dev(ws[k], "weights"), _lib.dev(ref_bins, "ref_bins"),
+                                                             _lib.dev(ref_w, "ref_weights"), N, ws[k].shape[1], Tr, scale, None,
+                                                             per_ray[k].data_ptr(), None, _lib.stream()), "proposal_loss")
+        ctx.save_for_backward(ref_bins, ref_w, *bins, *ws)
+        ctx.S = S
+        return per_ray.sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        ref_bins, ref_w = saved[0], saved[1]
+        S = ctx.S
+        bins, ws = saved[2:2 + S], saved[2 + S:]
+        N, Tr = ref_w.shape
+        scale = 1.0 / float(N * Tr)
+        g = grad_out.detach().reshape(1).contiguous().float()         # stays on the device: no host sync
+        out = []
+        for k in range(S):
+            gw = torch.empty_like(ws[k])
+            _lib.check(_lib.lib().sn_rm_proposal_loss_scaled(_lib.dev(bins[k], "bins"), _lib.dev(ws[k], "weights"), _lib.dev(ref_bins, "ref_bins"),
+                                                             _lib.dev(ref_w, "ref_weights"), N, ws[k].shape[1], Tr, scale, _lib.dev(g, "grad_out"),
+                                                             None, _lib.dev(gw, "grad_weights"), _lib.stream()), "proposal_loss_backward")
+            out.append(gw)
+        return (None, None) + (None,) * S + tuple(out)
+
+
+def proposal_loss_all(all_bins, all_weights):
+    """sum over the proposal stages of proposal_loss_stage(...) against the last entry (renderer.py:30-57), one autograd node."""
+    return _proposal_loss_all.apply(all_bins[-1], all_weights[-1], *all_bins[:-1], *all_weights[:-1])
+
+
+def zeros_f32(shape, device) -> torch.Tensor:
+    """torch.zeros(shape) whose fill is a library kernel on the current stream (sn_zero; capturable)."""
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    nbytes = t.numel() * 4
+    if nbytes % 16 == 0 and t.data_ptr() % 16 == 0 and nbytes > 0:
+        _lib.check(_lib.lib().sn_zero(t.data_ptr(), nbytes, _lib.stream()), "zero")
+    else:
+        t.zero_()
+    return t
 
 
 class _proposal_loss_stage(Function):

@@ -28,8 +28,39 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sanerf_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names, "ctypes signature table out of sync with the header"
-    assert lib.sn_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.sn_abi_version() == _lib.ABI_VERSION == 11
     assert lib.sn_build_flags() == 0, "the product library carries neither the experiment kernels nor the LDS poisoning"
+
+
+def test_round6_entry_points_validate_their_arguments():
+    """The training entry points added with ABI 11 answer bad arguments with error codes before any launch."""
+    from sanerf_hq_amd import _lib
+    l = _lib.lib()
+    d = _lib.MlpDesc()
+    d.num_layers, d.activation, d.skip_mask = 3, 0, 0
+    for i, v in enumerate((32, 64, 64, 16)):
+        d.dims[i] = v
+    assert l.sn_mlp_small_supported(ctypes.byref(d)) == 1
+    d.dims[1] = 48
+    assert l.sn_mlp_small_supported(ctypes.byref(d)) == 0
+    dummy = ctypes.c_void_p(16)
+    for i in range(3):
+        d.weight[i] = 16
+    hid = (ctypes.c_void_p * 2)(16, 16)
+    assert l.sn_mlp_small_forward_train(ctypes.byref(d), dummy, 4, hid, dummy, 0, None, 0.0, None, None) == -2      # widths not instantiated
+    assert b"not instantiated" in l.sn_last_error()
+    d.dims[1] = 64
+    assert l.sn_mlp_small_forward_train(ctypes.byref(d), dummy, 4, hid, dummy, 1, None, 0.0, None, None) == -1      # activated output without destination
+    assert l.sn_mlp_small_forward_train(ctypes.byref(d), dummy, 4, hid, dummy, 7, None, 0.0, dummy, None) == -1
+    assert b"unknown output activation" in l.sn_last_error()
+    assert l.sn_mlp_small_backward(ctypes.byref(d), None, None, 0, None, 0.0, hid, 4, None, hid, dummy, None, None) == -1
+    assert b"no incoming gradient" in l.sn_last_error()
+    d.bias[0] = 16
+    assert l.sn_mlp_small_supported(ctypes.byref(d)) == 0
+    assert l.sn_rm_jitter(None, 4, 8, 2, dummy, None) == -1 and b"kind" in l.sn_last_error()
+    assert l.sn_zero(ctypes.c_void_p(8), 16, None) == -1
+    assert l.sn_rm_sample_positions_ex(dummy, dummy, dummy, dummy, dummy, 4, 8, 1, -1.0, dummy, dummy, dummy, None) == -1
+    assert l.sn_rm_ray_composite(None, dummy, dummy, dummy, 4, 8, dummy, dummy, dummy, None) == -1
 
 
 def test_library_reports_missing_device_loudly():

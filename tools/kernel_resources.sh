@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../sanerf-hq_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics \
   -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wno-unused-function "$@" \
-  -Rpass-analysis=kernel-resource-usage -c render.hip -o /dev/null 2>&1 | python3 -c "
+  -Rpass-analysis=kernel-resource-usage -c ${SN_SRC:-render.hip} -o /dev/null 2>&1 | python3 -c "
 import re,sys
 cur=None; rows=[]
 for ln in sys.stdin:
