@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ i
 // store covers a few whole runs.  512 threads x 2 samples = the 1024 samples per block of k_bin_count (same blockIdx.x -> same matrix row).
 constexpr uint32_t REF_THREADS = 512, REF_SPT = 256u * SPT / REF_THREADS;
 constexpr uint32_t REF_WINDOW = 4096;                           // positions of the block's sorted order staged in LDS at a time
-constexpr uint32_t REF_KEY_SHIFT = 22;                           // sample index below, row inside the bin above: B <= 2^22, rows per bin <= 2^10
+constexpr uint32_t REF_KEY_SHIFT = 22;                           // sample index below, row inside the bin above: B < 2^22, rows per bin <= 2^10
 static_assert(BIN_ROWS_MAX <= (1u << (32u - REF_KEY_SHIFT)), "row-in-bin must fit above the sample index");
 
 template <uint32_t D, bool FAST>
@@ -912,7 +912,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     // entries as products (push) or as references (pull, k_bin_refs).  References win at every C measured (C = 8: 0.55 -> 0.33 ms, C = 2: 0.26 -> 0.235, 0.27 -> 0.26,
     // 0.16 -> 0.144 ms; profiles/r05/bin_stats_*.txt): even where a product is as short as a reference the sorted runs replace scattered 8 + 2 byte stores;
     // a reference holds the sample index in 22 bits
-    const bool pull = (g_bin_pull < 0 ? true : g_bin_pull != 0) && C >= 2u && B <= (1u << REF_KEY_SHIFT);   // (C >= 2: the references live in the products' region)
+    const bool pull = (g_bin_pull < 0 ? true : g_bin_pull != 0) && C >= 2u && B < (1u << REF_KEY_SHIFT);     // (strictly below: sample 2^22 - 1 in row 1023 of a bin would encode the 'no entry' key 0xffffffff)   // (C >= 2: the references live in the products' region)
     uint2 *eref = reinterpret_cast<uint2 *>(econtrib);
     const BinPull bp{grad, eref, B, layout};
     constexpr size_t refs_lds = (size_t)REF_WINDOW * 2 * sizeof(uint32_t);

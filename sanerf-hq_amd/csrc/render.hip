@@ -3065,7 +3065,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
     if (io->skip_final) SN_REQUIRE(cfg->num_stages >= 2 && io->bins[cfg->num_stages - 1] && !cfg->with_feat,
                                    "render_rays: skip_final needs >= 2 stages, io->bins[last] for the resampled bins, and no feature stage");
     else SN_REQUIRE(io->image && io->depth && io->weights_sum, "render_rays: outputs must be device pointers");
-    SN_REQUIRE(io->out_stride == 0u || io->out_stride >= 3u, "render_rays: out_stride %u must be 0 (dense outputs) or at least 3 floats", io->out_stride);
+    SN_REQUIRE(io->out_stride == 0u || io->out_stride >= 5u, "render_rays: out_stride %u must be 0 (dense outputs) or at least 5 floats (rgb | depth | weights_sum per row)", io->out_stride);
+    SN_REQUIRE(cfg->tuning.wave_tile >= 0 && cfg->tuning.wave_tile <= 5, "render_rays: tuning.wave_tile %d outside 0..5", cfg->tuning.wave_tile);
+    SN_REQUIRE(!(rs_enabled(cfg) && cfg->tuning.wave_tile != 0 && cfg->tuning.wave_tile != 3), "render_rays: the role-split experiment is built for 8x8 wave tiles (tuning.wave_tile 0 or 3)");
     const uint32_t S = cfg->num_stages;
     SN_REQUIRE(S >= 1 && S <= SN_MAX_STAGES, "render_rays: num_stages=%u outside 1..%d", S, SN_MAX_STAGES);
     for (uint32_t k = 0; k < S; ++k) SN_REQUIRE(cfg->num_steps[k] >= 1, "render_rays: num_steps[%u] must be >= 1", k);

@@ -711,6 +711,10 @@ WIDE_MLP_FORWARD_F16X3 = True       # the wide training MLP's forward as ONE ker
                                     # product, fp32 accumulation; sn_mlp_wide_forward_train_f16x3) with the hidden outputs saved: 0.38 -> 0.2 ms for the mask head.
                                     # Against the reference's gradients (train_c5.npz) it gives the same errors as the BLAS forward to three digits
                                     # (tools/r5/fwd_modes_err.py).  Activations must stay inside the fp16 range (raymarching.mlp_wide_overflow()).  False: BLAS fp32
+WIDE_MLP_RANGE_CHECK_EVERY = 64    # with the split-fp16 forward: every this many training forwards the library's sticky overflow flag is read (one device
+                                    # synchronisation; skipped while a HIP graph is being captured) and a RuntimeError names the cause -- an activation or
+                                    # input at or beyond 65504 makes the logits, the loss and every gradient non-finite.  0: never check
+_wide_fwd_calls = [0]
 _wide_fwd_ws: dict = {}
 WIDE_MLP_SIGN_BITS = True           # the split-fp16 training forward also writes one sign bit per hidden unit and the backward data path reads those (A/B, tests: False)
 WIDE_MLP_FORWARD_NATIVE = False     # True: the wide training MLP's forward as ONE kernel (sn_mlp_wide_forward_train: fp32 MFMA, fused activations).  Measured slower
@@ -761,6 +765,17 @@ class _wide_mlp_train(Function):
             _lib.check(lib.sn_mlp_wide_forward_train_f16x3(C.byref(desc), _lib.dev(x2, "x"), rows, hid, bid, _lib.dev(h, "out"),
                                                            wsb.data_ptr(), wsb.numel(), _lib.stream()), "sn_mlp_wide_forward_train_f16x3")
             ctx.sign_bits = bits
+            _wide_fwd_calls[0] += 1
+            if (WIDE_MLP_RANGE_CHECK_EVERY and _wide_fwd_calls[0] % WIDE_MLP_RANGE_CHECK_EVERY == 0
+                    and not torch.cuda.is_current_stream_capturing()):
+                flag = C.c_int32(0)
+                _lib.check(lib.sn_mlp_wide_overflow(C.byref(flag)), "sn_mlp_wide_overflow")
+                if flag.value:
+                    raise RuntimeError(
+                        "wide MLP training forward: an activation or input left the fp16 range (|v| >= 65504) of the split-fp16 matrix-core "
+                        "forward during the last %d calls; logits, loss and gradients of those steps are not finite.  Set "
+                        "sanerf_hq_amd.ops.WIDE_MLP_FORWARD_F16X3 = False (fp32 BLAS forward, no range limit) or rescale the inputs."
+                        % WIDE_MLP_RANGE_CHECK_EVERY)
         elif WIDE_MLP_FORWARD_NATIVE and x.shape[-1] <= 256 and weights[-1].shape[0] <= 256:
             # one kernel for all layers: true fp32 on the matrix cores, activation fused, hidden outputs saved (sn_mlp_wide_forward_train)
             nl = len(weights)

@@ -759,8 +759,8 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
 
     def buf(name, shape, dtype=torch.float32):
         t = res.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
-            t = torch.empty(shape, device=device, dtype=dtype)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device or not t.is_contiguous():
+            t = torch.empty(shape, device=device, dtype=dtype)     # (a strided view left by an earlier packed= call is not reused)
             res[name] = t
         return t
 

@@ -355,3 +355,30 @@ def test_fused_route_selection_is_host_logic():
     assert Small(make_opt(num_steps=[32]), bias=True)._fused_kind() is None           # biases: not the reference's structure
     assert Small(make_opt(num_steps=[32]), level_dim=4)._fused_kind() is None         # the size-agnostic kernel is built for level_dim 2
     assert Small(make_opt(num_steps=[32, 16]))._fused_kind() is None                  # a proposal stage without the reference's proposal networks
+
+
+@pytest.mark.parametrize("T_", [32, 64, 128])
+def test_distort_loss_statement_vs_fp64_brute_force_with_degenerate_rays(T_):
+    """nerf.renderer.distort_loss (the O(T) cumulative-sum statement; what the reference gets from the third-party eff_distloss,
+    renderer.py:17-27) against the published O(T^2) definition in fp64, value and gradient, on random rays, zero-width intervals, all mass in
+    one bin and an empty ray.  The HIP kernel is held to the same brute force in tests/test_gpu_ops.py."""
+    from sanerf_hq_amd.nerf import renderer as R
+    rng = np.random.default_rng(T_)
+    N = 16
+    b = np.sort(rng.uniform(0, 1, (N, T_ + 1)), axis=1)
+    w = rng.uniform(0, 1, (N, T_)) ** 4
+    b[1, T_ // 3: 2 * T_ // 3 + 1] = b[1, T_ // 3]
+    w[2] = 0.0; w[2, T_ // 2] = 1.0
+    w[3] = 0.0
+    b[4] = 0.5
+    bd = torch.from_numpy(b)
+    wd = torch.from_numpy(w).requires_grad_(True)
+    d = bd[:, 1:] - bd[:, :-1]
+    m = bd[:, :-1] + d / 2
+    ref = ((wd[:, :, None] * wd[:, None, :] * (m[:, :, None] - m[:, None, :]).abs()).sum((1, 2)) + (wd * wd * d).sum(1) / 3).mean()
+    ref.backward()
+    w2 = torch.from_numpy(w).requires_grad_(True)
+    got = R.distort_loss(bd, w2)
+    got.backward()
+    assert abs(float(got.detach()) - float(ref.detach())) <= 1e-12 * max(1.0, abs(float(ref.detach())))
+    assert float((w2.grad - wd.grad).abs().max()) <= 1e-12 * max(1.0, float(wd.grad.abs().max()))

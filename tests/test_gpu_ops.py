@@ -438,6 +438,54 @@ def test_distort_loss_kernel(gpu, T_):
     assert float((w3.grad - w2.grad.cpu()).abs().max()) <= 1e-9 * float(w2.grad.abs().max()) + 1e-14
 
 
+def _distort_cases(T_, seed):
+    """Intervals and weights that stress the O(T) kernel: random, zero-width intervals (repeated edges), all mass in one bin, one-hot mass at
+    either end, equal weights on equal intervals, a ray with no mass at all."""
+    rng = np.random.default_rng(seed)
+    N = 64
+    b = np.sort(rng.uniform(0, 1, (N, T_ + 1)), axis=1)
+    w = rng.uniform(0, 1, (N, T_)) ** 4
+    b[1, T_ // 3: 2 * T_ // 3 + 1] = b[1, T_ // 3]                         # a run of zero-width intervals
+    b[2] = np.repeat(b[2, ::2], 2)[:T_ + 1] if T_ > 1 else b[2]              # every other interval has zero width
+    w[3] = 0.0; w[3, T_ // 2] = 1.0                                          # all mass in one bin
+    w[4] = 0.0; w[4, 0] = 1.0
+    w[5] = 0.0; w[5, -1] = 1.0
+    b[6] = np.linspace(0, 1, T_ + 1); w[6] = 1.0 / T_                        # uniform
+    w[7] = 0.0                                                               # nothing hit
+    b[8] = 0.5                                                               # the whole ray collapsed to one point
+    w[9] = 0.0; w[9, 0] = 0.5; w[9, -1] = 0.5                                # two far-apart spikes: the pairwise term at its largest
+    return b.astype(np.float32), w.astype(np.float32)
+
+
+@pytest.mark.parametrize("T_", [32, 64, 128])
+def test_distort_loss_degenerate_intervals_vs_fp64_brute_force(gpu, T_):
+    """The pin of sn_rm_distort_loss (verdict round 5, item 8): the package the reference calls (torch_efficient_distloss, requirements.txt:21,
+    renderer.py:14,25) is not installable here (no network), so the kernel is held to the PUBLISHED definition evaluated by brute force in
+    fp64 -- sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 d_i, mean over rays -- on random AND degenerate rays, value per ray and gradient per
+    element; the torch cumulative-sum statement used for T > 2048 is held to the same."""
+    from sanerf_hq_amd import raymarching as rm
+    from sanerf_hq_amd.nerf import renderer as R
+    b, w = _distort_cases(T_, 100 + T_)
+    N = b.shape[0]
+    w1 = T(w, gpu).requires_grad_(True)
+    l1 = rm.distort_loss(T(b, gpu), w1)
+    l1.backward()
+    bd, wd = T(b, gpu).double(), T(w, gpu).double().requires_grad_(True)
+    d = bd[:, 1:] - bd[:, :-1]
+    m = bd[:, :-1] + d / 2
+    per_ray = (wd[:, :, None] * wd[:, None, :] * (m[:, :, None] - m[:, None, :]).abs()).sum((1, 2)) + (wd * wd * d).sum(1) / 3
+    per_ray.mean().backward()
+    assert abs(float(l1) - float(per_ray.mean())) <= 2e-6 * abs(float(per_ray.mean())) + 1e-10
+    gref = wd.grad
+    assert float((w1.grad.double() - gref).abs().max()) <= 2e-6 * float(gref.abs().max()) + 1e-12
+    assert float(w1.grad[7].abs().max()) <= 2.0 / N and float(gref[8].abs().max()) == 0.0 and float(w1.grad[8].abs().max()) == 0.0
+    w3 = torch.from_numpy(w).double().requires_grad_(True)
+    l3 = R.distort_loss(torch.from_numpy(b).double(), w3)                     # CPU tensors: the cumulative-sum statement
+    l3.backward()
+    assert abs(float(l3) - float(per_ray.mean())) <= 1e-9 * abs(float(per_ray.mean())) + 1e-13
+    assert float((w3.grad - gref.cpu()).abs().max()) <= 1e-9 * float(gref.abs().max()) + 1e-14
+
+
 def test_weights_and_composite(gpu, orc):
     from sanerf_hq_amd import raymarching as rm
     rng = np.random.default_rng(70)
@@ -868,6 +916,61 @@ def test_wide_mlp_fused_backward_matches_autograd(gpu, N, din, n_out, leaky):
     assert float(gxa[5].abs().max()) == 0.0
     for a_, b_ in zip(gwa, gwb):
         assert float((a_ - b_).norm() / b_.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("N,din,n_out", [(20000, 143, 2), (33000, 64, 5)])
+def test_wide_mlp_default_forward_and_sign_bits_backward_per_row(gpu, N, din, n_out):
+    """The DEFAULT training route of the wide MLP (split-fp16 x3 forward with saved outputs + backward from sign bits, advisor round 5): per
+    row against torch autograd in fp64.  A unit whose fp64 pre-activation is within 1e-5 of zero may take the other LeakyReLU branch under a
+    differently rounded forward; rows that contain such a unit are excluded from the per-row bound (and counted: they must be rare)."""
+    from sanerf_hq_amd import ops, synth
+    assert ops.WIDE_MLP_FORWARD_F16X3 and ops.WIDE_MLP_SIGN_BITS and not ops.WIDE_MLP_FORWARD_NATIVE
+    ws = [T(synth.linear_weight(256, din, 710, 2.0), gpu), T(synth.linear_weight(256, 256, 711, 2.0), gpu), T(synth.linear_weight(n_out, 256, 712, 2.0), gpu)]
+    rng = np.random.default_rng(N + 1)
+    x = T(rng.standard_normal((N, din)).astype(np.float32), gpu)
+    gy = T((rng.standard_normal((N, n_out)) * 10.0 ** rng.uniform(-6, -1, (N, 1))).astype(np.float32), gpu)
+    xs = x.clone().requires_grad_(True)
+    wl = [w.clone().requires_grad_(True) for w in ws]
+    y = ops._wide_mlp_train.apply(xs, True, *wl)
+    y.backward(gy)
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    p1 = torch.nn.functional.linear(x64, w64[0])
+    p2 = torch.nn.functional.linear(torch.nn.functional.leaky_relu(p1), w64[1])
+    y64 = torch.nn.functional.linear(torch.nn.functional.leaky_relu(p2), w64[2])
+    y64.backward(gy.double())
+    assert float((y.double() - y64).norm() / y64.norm()) < 2e-6
+    risky = ((p1.abs() < 1e-5).any(dim=1) | (p2.abs() < 1e-5).any(dim=1))
+    assert int(risky.sum()) < max(8, N // 500), int(risky.sum())
+    rn = x64.grad.norm(dim=1)
+    rel = (xs.grad.double() - x64.grad).norm(dim=1) / rn.clamp_min(1e-30)
+    keep = (rn > 0) & ~risky
+    assert float(rel[keep].max()) < 5e-5, float(rel[keep].max())
+    for a_, b_ in zip([w.grad for w in wl], [w.grad for w in w64]):
+        assert float((a_.double() - b_).norm() / b_.norm()) < 1e-4
+
+
+def test_wide_mlp_training_forward_reports_a_left_fp16_range(gpu):
+    """ops.WIDE_MLP_RANGE_CHECK_EVERY (advisor round 5, medium): the split-fp16 training forward has a range contract (|v| < 65504); an input
+    beyond it makes the loss NaN.  The periodic check of the library's sticky flag turns that into a RuntimeError that names the cause."""
+    from sanerf_hq_amd import ops, raymarching as rm, synth
+    ws = [T(synth.linear_weight(256, 143, 720, 2.0), gpu).requires_grad_(True), T(synth.linear_weight(256, 256, 721, 2.0), gpu).requires_grad_(True),
+          T(synth.linear_weight(2, 256, 722, 2.0), gpu).requires_grad_(True)]
+    x = torch.randn(20000, 143, device=gpu)
+    rm.mlp_wide_overflow()                                                # clear the flag
+    old = ops.WIDE_MLP_RANGE_CHECK_EVERY
+    ops.WIDE_MLP_RANGE_CHECK_EVERY = 1
+    try:
+        ops._wide_mlp_train.apply(x, True, *ws)                           # in range: no complaint
+        with pytest.raises(RuntimeError, match="fp16 range"):
+            ops._wide_mlp_train.apply(x * 1e6, True, *ws)
+        ops.WIDE_MLP_FORWARD_F16X3 = False
+        y = ops._wide_mlp_train.apply(x * 1e6, True, *ws)                 # the BLAS forward has no such limit
+        assert bool(torch.isfinite(y).all())
+    finally:
+        ops.WIDE_MLP_RANGE_CHECK_EVERY = old
+        ops.WIDE_MLP_FORWARD_F16X3 = True
+        rm.mlp_wide_overflow()
 
 
 def test_new_entry_points_accept_empty_batches(gpu):

@@ -219,6 +219,30 @@ def _c5_like_step(gpu, seed, capturable):
     return model, step
 
 
+def test_mask_training_step_replayed_as_a_hip_graph_tight_bounds_with_the_blas_forward(gpu):
+    """The same replay-vs-eager comparison with the fp32 BLAS forward (ops.WIDE_MLP_FORWARD_F16X3 = False), under which no hidden unit of this
+    set-up sits within round-off of zero: the bounds of rounds 3-4 hold (1e-3 max-abs, 1e-4 relative norm) -- tight enough to catch a single
+    stale buffer or a kernel missing from the captured graph in a 6-step run (advisor, round 5)."""
+    from sanerf_hq_amd import ops
+    from sanerf_hq_amd.graph import GraphedStep
+    steps = 6
+    ops.WIDE_MLP_FORWARD_F16X3 = False
+    try:
+        m_eager, step_eager = _c5_like_step(gpu, 99, False)
+        losses_e = [float(step_eager()) for _ in range(steps)]
+        m_graph, step_graph = _c5_like_step(gpu, 99, True)
+        g = GraphedStep(step_graph, warmup=2)
+        losses_g = [float(g()) for _ in range(steps - 2)]
+        torch.cuda.synchronize()
+    finally:
+        ops.WIDE_MLP_FORWARD_F16X3 = True
+    assert all(np.isfinite(losses_g)) and abs(losses_g[-1] - losses_e[-1]) <= 1e-5 * max(1.0, abs(losses_e[-1]))
+    for (n1, p1), (n2, p2) in zip(m_eager.named_parameters(), m_graph.named_parameters()):
+        if p1.requires_grad:
+            assert float((p1 - p2).abs().max()) <= 1e-3, n1
+            assert float((p1 - p2).double().norm() / (p1.double().norm() + 1e-12)) <= 1e-4, n1
+
+
 def test_mask_training_step_replayed_as_a_hip_graph(gpu):
     """BASELINE configs[4] as ONE HIP graph (sanerf_hq_amd.graph.GraphedStep): frozen-field render, m_grid, mask MLP, fused NLL, binned grid
     backward, capturable single-pass Adam -- captured once, replayed; after the same number of steps the parameters equal the eager run's
