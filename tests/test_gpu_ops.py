@@ -921,8 +921,9 @@ def test_wide_mlp_fused_backward_matches_autograd(gpu, N, din, n_out, leaky):
 @pytest.mark.parametrize("N,din,n_out", [(20000, 143, 2), (33000, 64, 5)])
 def test_wide_mlp_default_forward_and_sign_bits_backward_per_row(gpu, N, din, n_out):
     """The DEFAULT training route of the wide MLP (split-fp16 x3 forward with saved outputs + backward from sign bits, advisor round 5): per
-    row against torch autograd in fp64.  A unit whose fp64 pre-activation is within 1e-5 of zero may take the other LeakyReLU branch under a
-    differently rounded forward; rows that contain such a unit are excluded from the per-row bound (and counted: they must be rare)."""
+    row against torch autograd in fp64.  A unit whose fp64 pre-activation is within 4e-6 of zero may take the other LeakyReLU branch under a
+    differently rounded forward (pre-activations are O(1-10) here, the forward is good to ~2e-7 relative); rows that contain such a unit are
+    excluded from the per-row bound (and counted: they must be rare)."""
     from sanerf_hq_amd import ops, synth
     assert ops.WIDE_MLP_FORWARD_F16X3 and ops.WIDE_MLP_SIGN_BITS and not ops.WIDE_MLP_FORWARD_NATIVE
     ws = [T(synth.linear_weight(256, din, 710, 2.0), gpu), T(synth.linear_weight(256, 256, 711, 2.0), gpu), T(synth.linear_weight(n_out, 256, 712, 2.0), gpu)]
@@ -940,8 +941,8 @@ def test_wide_mlp_default_forward_and_sign_bits_backward_per_row(gpu, N, din, n_
     y64 = torch.nn.functional.linear(torch.nn.functional.leaky_relu(p2), w64[2])
     y64.backward(gy.double())
     assert float((y.double() - y64).norm() / y64.norm()) < 2e-6
-    risky = ((p1.abs() < 1e-5).any(dim=1) | (p2.abs() < 1e-5).any(dim=1))
-    assert int(risky.sum()) < max(8, N // 500), int(risky.sum())
+    risky = ((p1.abs() < 4e-6).any(dim=1) | (p2.abs() < 4e-6).any(dim=1))
+    assert int(risky.sum()) < max(8, N // 100), int(risky.sum())
     rn = x64.grad.norm(dim=1)
     rel = (xs.grad.double() - x64.grad).norm(dim=1) / rn.clamp_min(1e-30)
     keep = (rn > 0) & ~risky
