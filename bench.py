@@ -29,12 +29,14 @@ Prints ONE JSON line (rank 0): the contract fields plus
 """
 import argparse
 import ctypes as C
+import faulthandler
 import hashlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -42,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md chip table
+MFMA_F16_PEAK = 2.5e15       # dense fp16 FLOP/s, ibid. (not the 2:1-sparsity figure)
 PEAK_CLOCK_HZ = 2.4e9        # ibid.
 N_CU = 256
 GATHER_CYCLES_PER_CU = 17.5  # one wave-wide <=16-byte gather instruction per 17.5 cycles per CU (4 lanes/clk address rate);
@@ -70,9 +73,35 @@ def parse_args():
     ap.add_argument("--shared-device", action="store_true",
                     help="N > 1: every rank uses cuda:0 (a one-GPU box exercising the N-rank code path; the ranks time-share the GPU, so `value` "
                          "measures nothing about scaling -- the line says so)")
+    ap.add_argument("--watchdog-seconds", type=float, default=-1.0,
+                    help="N > 1: a rank that makes no progress for this long prints WHICH rank stalled in WHICH phase (with its Python stack) and "
+                         "exits 124 instead of hanging the job (default: 300 at N > 1, off at N = 1; 0 = off)")
     ap.add_argument("--tuning", default="", help="kernel-selection fields of raymarching.Tuning for A/B runs, e.g. densify=1,per_sample_form=1 "
                                                   "(mlp_mode also takes f16x3 / mfma32 / valu); default: the shipped kernels")
     return ap.parse_args()
+
+
+class Watchdog(threading.Thread):
+    """Says which rank stalled where.  A collective that never completes (a rank that died, a rendezvous that never formed) otherwise shows up
+    as a silent hang of the whole job; each rank's watchdog prints `rank r: no progress for T s in phase P` + its Python stack to stderr and
+    exits 124.  `at(phase)` is the heartbeat."""
+
+    def __init__(self, rank: int, timeout: float):
+        super().__init__(daemon=True)
+        self.rank, self.timeout, self.phase, self.beat, self.done = rank, timeout, "start", time.monotonic(), False
+
+    def at(self, phase: str) -> None:
+        self.phase, self.beat = phase, time.monotonic()
+
+    def run(self) -> None:
+        while not self.done:
+            time.sleep(0.5)
+            idle = time.monotonic() - self.beat
+            if idle > self.timeout:
+                sys.stderr.write(f"bench.py WATCHDOG: rank {self.rank} made no progress for {idle:.0f} s in phase '{self.phase}' -- exiting 124\n")
+                faulthandler.dump_traceback(file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(124)
 
 
 def self_spawn(args):
@@ -126,6 +155,29 @@ def gather_ceiling():
     return GATHER_CYCLES_PER_CU, "round-1 constant (no matching profiles/latest_ubench.json)"
 
 
+def kernel_counters():
+    """profiles/latest_kernel_counters.json (tools/pmc_kernels_summary.py <round> <json>): per-kernel counter means of the other workloads,
+    used for `also.*.roofline.binding` when they were taken from the kernel sources in the tree."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "latest_kernel_counters.json")))
+        return j["workloads"] if j.get("source_fingerprint") == source_fingerprint() else {}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+def also_roofline(alg_bytes, ms, limiter, counters, field, traffic_key=True):
+    """A roofline object of the contract's shape for one `also` configuration: the SURVEY 8(d) algorithmic bytes of the whole path / its time
+    against the HBM peak (cache-absorbed: can exceed 1), the counter-derived HBM-side traffic of its dominant kernel when a profile of these
+    sources exists, and the fraction that binds (`binding.frac` = the named unit's busy fraction from the counters)."""
+    gbps = alg_bytes / (ms * 1e-3) / 1e9 if alg_bytes and ms else None
+    c = counters or {}
+    tr = (c.get("fetch_bytes_gfx950_corrected") or 0) + (c.get("write_bytes") or 0) if c and traffic_key else None
+    return {"bound": "hbm", "achieved": round(gbps, 1) if gbps else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(gbps * 1e9 / HBM_PEAK, 4) if gbps else None, "traffic": tr or None,
+            "binding": {"limiter": limiter, "frac": round(c[field] / 100.0, 4) if c.get(field) is not None else None,
+                        "from": f"profiles/latest_kernel_counters.json: {field}" if c.get(field) is not None else "no counter profile of these kernel sources"}}
+
+
 def source_fingerprint():
     """sha256 over the kernel sources: ties a committed PMC profile to the code it was taken from (the GPU box has no .git)."""
     h = hashlib.sha256()
@@ -166,6 +218,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
     multi = world > 1 or force_dist
+    wd_secs = args.watchdog_seconds if args.watchdog_seconds >= 0 else (300.0 if world > 1 else 0.0)
+    dog = Watchdog(rank, wd_secs) if wd_secs > 0 else None
+    if dog is not None:
+        dog.start()
+    beat = (lambda phase: dog.at(phase)) if dog is not None else (lambda phase: None)
+    beat("init_process_group")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     rccl_ranks = None
@@ -174,6 +232,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        beat("first all_reduce (rendezvous)")
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                        # every rank really joined the RCCL communicator
         rccl_ranks = int(ones.item())
@@ -239,13 +298,17 @@ def main():
                 rm.render_rays(plan, r_o, r_d, tile_w=r_w, out=out, packed=band)
                 pipe.submit(band)
 
+        beat(f"warm-up {schedule}/{tables}")
         for _ in range(n_warm):
             step()
         if pipe is not None:
             pipe.drain()
+            pipe.stats()                                    # (reset the wait timers: the timed region starts clean)
         torch.cuda.synchronize()
         if gather and multi:
+            beat("barrier before the timed region")
             dist.barrier()
+        beat(f"timed region {schedule}/{tables}")
         lib.sn_rm_profile_enable(1)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
         torch.cuda.synchronize()
@@ -254,12 +317,16 @@ def main():
         for i in range(n_steps):
             step()
             marks[i + 1].record()
+            beat(f"timed region {schedule}/{tables}: step {i + 1}/{n_steps} enqueued")
         if pipe is not None:
             pipe.drain()
         torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0           # this rank's own time (before the barrier: a straggler shows up as the largest)
         if gather and multi:
+            beat("barrier after the timed region")
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        gstats = pipe.stats() if pipe is not None else None
         ms = (C.c_float * 8)()
         cnt = (C.c_int32 * 8)()
         _lib.check(lib.sn_rm_profile_read(ms, cnt, 8), "profile_read")
@@ -279,26 +346,52 @@ def main():
                     ms_per_step=elapsed / n_steps * 1e3, median_ms=per_step[len(per_step) // 2], max_ms=per_step[-1], tables=tables,
                     s_bytes=2 if tables == "f16" else 4, final_ms=per(4), final_launches=int(cnt[4]), pack_ms=per(0),
                     prop_ms=[per(1), per(2)], shader_mhz=float(mhz.value), probe_ms=float(probe_ms.value), launch=launch,
+                    local_ms_per_step=local_elapsed / n_steps * 1e3, gather=gstats, n_steps=n_steps,
                     image=pipe.drain() if pipe is not None else None)
 
     m = measure(args.schedule, args.tables, args.steps, args.warmup)
     steps, params, out = m["steps"], m["params"], m["out"]
     value, ms_per_step, s_bytes, final_ms = m["value"], m["ms_per_step"], m["s_bytes"], m["final_ms"]
 
-    # ---- N > 1: the gathered image must be the single-process image; and the same image on ONE GPU for the ratio ----
-    single = gathered_check = None
+    # ---- N > 1: the gathered image must be the single-process image ON EVERY RANK; the same image on ONE GPU for the ratio; and every
+    # ---- rank's own numbers in the line (band time, kernel time, time lost waiting on the all-gather), so that one run explains itself ----
+    single = gathered_check = per_rank = None
     if world > 1:
+        beat("per-rank statistics")
+        mine = torch.tensor([m["local_ms_per_step"], m["median_ms"], m["max_ms"], m["final_ms"] or 0.0,
+                             (m["gather"]["gather_wait_ms"] / m["n_steps"]) if m["gather"] else 0.0, m["shader_mhz"], float(n_local)],
+                            device=dev, dtype=torch.float64)
+        allr = torch.empty(world * mine.numel(), device=dev, dtype=torch.float64)      # (flat: gloo wants world x the input's shape exactly)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, mine.numel()).cpu().tolist()
+        per_rank = {"band_ms_per_step": [round(r[0], 4) for r in allr], "median_frame_ms": [round(r[1], 4) for r in allr],
+                    "max_frame_ms": [round(r[2], 4) for r in allr], "final_kernel_ms": [round(r[3], 4) for r in allr],
+                    "all_gather_wait_ms_per_step": [round(r[4], 4) for r in allr], "shader_clock_mhz": [round(r[5], 1) for r in allr],
+                    "rays": [int(r[6]) for r in allr], "slowest_rank": int(max(range(world), key=lambda i: allr[i][0])),
+                    "gather_path": m["gather"]["path"] if m["gather"] else None,
+                    "note": "band_ms_per_step: each rank's own wall time per step before the closing barrier (the step time of the line is the max over "
+                            "ranks); all_gather_wait_ms_per_step: time the rank's compute stream spent waiting on collectives (HIP events around "
+                            "every wait); gather_path: in_place (RCCL alias) or staged"}
+        beat("single-GPU render of the same image + check on every rank")
         ro_f, rd_f = rm.generate_rays(pose, intr, H, W, device=dev)
+        full = torch.empty(H * W, 5, device=dev, dtype=torch.float32)
         if rank == 0:
             r1 = measure(args.schedule, args.tables, max(3, args.steps // 4), 1, rays=(ro_f, rd_f, W, total_rays), gather=False)
             single = {"rays_per_s": round(r1["value"], 1), "ms_per_step": round(r1["ms_per_step"], 4),
                       "note": "rank 0 alone renders the whole image right after the timed region (other ranks idle at a barrier)"}
-            full = torch.cat([r1["out"]["image"], r1["out"]["depth"].unsqueeze(-1), r1["out"]["weights_sum"].unsqueeze(-1)], dim=-1)
-            gathered_check = {"max_abs_diff_vs_single_gpu_image": float((m["image"] - full).abs().max().item()),
-                              "max_abs_diff": float((m["image"] - full).abs().max().item()),
+            full.copy_(torch.cat([r1["out"]["image"], r1["out"]["depth"].unsqueeze(-1), r1["out"]["weights_sum"].unsqueeze(-1)], dim=-1))
+        beat("broadcast of the single-GPU image")
+        dist.broadcast(full, 0)
+        diff = (m["image"] - full).abs().max().double().reshape(1)           # THIS rank's gathered copy against the single-GPU image
+        diffs = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(diffs, diff)
+        if rank == 0:
+            dl = [float(v) for v in diffs.cpu().tolist()]
+            gathered_check = {"max_abs_diff_vs_single_gpu_image": max(dl), "max_abs_diff": max(dl), "max_abs_diff_per_rank": dl,
                               "rows_per_rank": [list(shard_rows(H, world, r, align)) for r in range(world)]}
         dist.barrier()
-        del ro_f, rd_f
+        del ro_f, rd_f, full
+    beat("roofline / extras")
 
     # ---- roofline of the dominant kernel (final stage) on this rank ----
     gpw = m["launch"]["gathers_per_wave_sample"]         # read back from the library: 86 for the densified fp16 kernel, 98 / 108 for K = 5
@@ -331,6 +424,11 @@ def main():
         # L1 / L2 / Infinity Cache serve neighbouring rays, so this figure can exceed 1 -- the fractions that bind follow.
         "kernel": m["launch"]["final_kernel"], "bound": "hbm", "achieved": round(alg_gbps, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": round(alg_gbps * 1e9 / HBM_PEAK, 4), "traffic": traffic,
+        # the fractions that BIND, first (verdict r05 item 7): `frac` above is cache-absorbed and saturated as a metric (0.87 / 1.03 / 1.56 on three
+        # configurations by the same formula).  binding_frac = texture-address floor / kernel time (ta_address_rate below); mfma_frac = matrix-pipe
+        # busy fraction = fp16 MFMA FLOPs issued (layers 1-2 as three split products; layer 3 is off the matrix cores) / time / 2.5 PFLOP/s
+        "binding_frac": round(ta_floor / final_ms, 4) if ta_floor else None,
+        "mfma_frac": round(n_local * steps[-1] * 2 * (32 * 64 + 64 * 64) * 3 / (final_ms * 1e-3) / MFMA_F16_PEAK, 4),
         # what actually binds: NOT HBM.  The four fields above are the contract's ALGORITHMIC figure (every corner fetch once, no
         # cache credit: cache-absorbed, can exceed 1); the kernel is co-limited by the texture-address rate, vector-ALU issue and the
         # power-managed shader clock, and moves `fabric_frac` of the HBM peak beyond its L2s
@@ -377,6 +475,7 @@ def main():
     also = None
     if world == 1 and not multi and not args.primary_only and scaling == "single":
         also = {}
+        kc = kernel_counters()
         for sch, tb in (("flat128", "f32"), ("ref", "f32"), ("flat128", "f16"), ("ref", "f16")):
             if (sch, tb) == (args.schedule, args.tables):
                 continue
@@ -386,6 +485,13 @@ def main():
                                    "kernel_ms": {"final": round(r["final_ms"], 4),
                                                  "prop0": round(r["prop_ms"][0], 4) if r["prop_ms"][0] else None,
                                                  "prop1": round(r["prop_ms"][1], 4) if r["prop_ms"][1] else None}}
+            alg = total_rays * algorithmic_bytes_per_ray(r["steps"], 2 if tb == "f16" else 4)
+            if sch == "ref":
+                also[f"{sch}_{tb}"]["roofline"] = also_roofline(alg, r["ms_per_step"], "vector ALU of the proposal stages (k_prop_stage), then the texture path of "
+                                                               "the last stage", kc.get("ref_f16", {}).get("k_prop_stage") if tb == "f16" else None, "VALUBusy_pct")
+            else:
+                also[f"{sch}_{tb}"]["roofline"] = also_roofline(alg, r["ms_per_step"], "texture-address path (k_final_stage)",
+                                                               kc.get("flat128_f16", {}).get("k_final_stage") if tb == "f16" else None, "TA_busy_pct")
             if r["final_launches"] > max(3, args.steps // 2):     # (two row bands on two HIP streams, sn_render_tuning.band_streams)
                 also[f"{sch}_{tb}"]["kernel_ms_note"] = ("the image is rendered as two row bands on two HIP streams: kernel_ms are sums of spans that "
                                                          "OVERLAP in time (their sum exceeds ms_per_step)")
@@ -467,9 +573,34 @@ def main():
             torch.cuda.empty_cache()
             also["c3_sam_head_400x400"] = dict(bc.c3_entry(dev, 2, 6), note="BASELINE configs[2]: 400x400 rays + 256-d SAM-feature head, [128,64,32]; fp32 tables, and "
                                                "with every table in half (incl. the per-call conversion)")
+            also["c3_sam_head_400x400"]["roofline"] = also_roofline(160000 * 226348, also["c3_sam_head_400x400"]["ms"], "texture-address path (k_feat_stage: the F = 8 "
+                                                                    "feature stage)", kc.get("c3_sam_head", {}).get("k_feat_stage"), "TA_busy_pct")
             also["mask_head_400x400"] = dict(bc.mask_head_entry(dev, 2, 5), note="400x400 render with the per-sample mask head (renderer.py:376-385), one-kernel head vs three-kernel route")
+            also["mask_head_400x400"]["roofline"] = also_roofline(160000 * 225324, also["mask_head_400x400"]["ms_fused_head"], "matrix pipe (k_mask16: three fp16 products "
+                                                                  "per fp32 product of the 143-256-256-2 head, 6.6 MFLOP per ray)", kc.get("mask_head", {}).get("k_mask16"), "MfmaUtil_pct")
             also["c5_train_step_ms"] = dict(bc.c5_entry(dev, 3, 8, optimisers=False), note="BASELINE configs[4]: mask-field training step, 4096 rays, fwd+bwd [+ single-pass Adam]")
+            also["c5_train_step_ms"]["roofline"] = also_roofline(4096 * 225324 * 2, also["c5_train_step_ms"]["fwd_bwd_ms"], "latency of the binned gradient scatter's LDS "
+                                                                 "phases (k_bin_pull) and HBM writes of the [N, 256] gradient tensors", kc.get("train_mask", {}).get("k_bin_pull"), "TA_busy_pct")
             torch.cuda.empty_cache()
+            import train_bench as tbm
+            also["rgb_train_step_ms"] = dict(tbm.rgb(), note="RGB-mode training step (trainer.py:360-392): 4096 rays, [128,64,32], every parameter trainable, MSE + "
+                                             "proposal loss, perturb=True; fused training operators (no BLAS launch in the step)")
+            also["rgb_train_step_ms"]["roofline"] = also_roofline(4096 * 94252 * 2, also["rgb_train_step_ms"]["fwd_bwd_ms"], "the binned gradient scatter of three grids "
+                                                                  "(k_bin_pull / k_bin_refs) and the three grid forwards", kc.get("train_rgb", {}).get("k_bin_pull"), "TA_busy_pct")
+            torch.cuda.empty_cache()
+            # what the unused part of the 1e-4 tolerance is worth (verdict r05 item 3): the last stage's MLP with ONE fp16 product per multiply.
+            # NOT a legal mode: 3.2e-4 / 3.5e-4 from the reference's own output on the stress-init fixtures (profiles/r06/mlp_modes_ab.json).
+            base_img = m["out"]["image"].clone()
+            rm.tuning.mlp_mode = _lib.MLP_F16X1
+            try:
+                r = measure("flat128", "f16", max(3, args.steps // 2), 2)
+            finally:
+                rm.tuning.mlp_mode = _lib.MLP_AUTO
+            also["measurement_only_mlp_mode_f16x1_flat128_f16"] = {
+                "ms_per_step": round(r["ms_per_step"], 4), "rays_per_s": round(r["value"], 1), "kernel": r["launch"]["final_kernel"],
+                "max_abs_rgb_diff_vs_the_headline_image": float((r["out"]["image"] - base_img).abs().max()) if args.schedule == "flat128" and args.tables == "f16" else None,
+                "note": "sn_render_tuning.mlp_mode = SN_MLP_F16X1: plain fp16 operands, fp32 accumulation.  Over the 1e-4 bar against the reference on the "
+                        "stress-init fixtures (3.2e-4 / 3.5e-4; profiles/r06/mlp_modes_ab.json): a measurement, never the headline and never a default"}
         except Exception as e:   # noqa: BLE001   (the headline line must survive a failure of an extra)
             also["extras_error"] = f"{type(e).__name__}: {e}"
         out = m["out"]
@@ -530,7 +661,10 @@ def main():
             line["n1_same_image_rays_per_s"] = single["rays_per_s"]      # the base a scaling curve of THIS image must use (not the 800x800 N=1 line)
             line["speedup_vs_single_gpu_same_image"] = round(value / single["rays_per_s"], 3)
             line["gathered_image_check"] = gathered_check
+            line["per_rank"] = per_rank
         print(json.dumps(line), file=json_out, flush=True)
+    if dog is not None:
+        dog.done = True
     if multi:
         dist.destroy_process_group()
 

@@ -250,11 +250,14 @@ typedef struct sn_mlp_desc {
 
 /* Kernel selection of sn_rm_render_rays, read from the caller's cfg on every call (ABI <= 6 read process-wide environment variables
  * instead).  All zero = the defaults.  None of these changes WHAT is computed beyond fp32 round-off; the notes say which are bit-neutral. */
-enum { SN_MLP_AUTO = 0, SN_MLP_F16X3 = 1, SN_MLP_MFMA32 = 2, SN_MLP_VALU = 3 };
+enum { SN_MLP_AUTO = 0, SN_MLP_F16X3 = 1, SN_MLP_MFMA32 = 2, SN_MLP_VALU = 3, SN_MLP_F16X1 = 5 };
 enum { SN_EXP_NONE = 0, SN_EXP_ROLE_SPLIT = 1, SN_EXP_LDS_LEVEL0 = 2 };
 typedef struct sn_render_tuning {
     int32_t mlp_mode;            /* SN_MLP_AUTO: split-fp16 on the matrix cores unless cfg.mlp_exact_fp32; SN_MLP_F16X3 forces it (overrides the
-                                  * range guard); SN_MLP_MFMA32: exact fp32 v_mfma_f32_32x32x2_f32; SN_MLP_VALU: vector-ALU fallback (A/B of the layouts) */
+                                  * range guard); SN_MLP_MFMA32: exact fp32 v_mfma_f32_32x32x2_f32; SN_MLP_VALU: vector-ALU fallback (A/B of the layouts);
+                                  * SN_MLP_F16X1 (opt-in measurement mode, NOT fp32-class: RGB 3e-4 from the reference on the stress-init fixtures, over
+                                  * the 1e-4 bar; honoured by the plain last-stage launch with fp16 tables, F16X3 elsewhere): one product per multiply --
+                                  * plain fp16 operands, fp32 accumulation: what an autocast fp16 run of the reference multiplies */
     int32_t per_sample_form;     /* 1: the last stage evaluates the third MLP layer per sample everywhere (no "linear tail"): bit-identical to
                                   * the compacting / several-lanes-per-ray kernels, fp32 round-off away from the default */
     int32_t densify;             /* hashed levels 5-6 of the main grid re-laid out per call like dense levels (bit-neutral): 0 automatic (fp16

@@ -34,7 +34,7 @@ class MlpDesc(C.Structure):
                 ("activation", C.c_uint32), ("skip_mask", C.c_uint32)]
 
 
-MLP_AUTO, MLP_F16X3, MLP_MFMA32, MLP_VALU = 0, 1, 2, 3              # sn_render_tuning.mlp_mode
+MLP_AUTO, MLP_F16X3, MLP_MFMA32, MLP_VALU, MLP_F16X1 = 0, 1, 2, 3, 5              # sn_render_tuning.mlp_mode
 EXP_NONE, EXP_ROLE_SPLIT, EXP_LDS_LEVEL0 = 0, 1, 2                   # sn_render_tuning.experiment (experiments builds only)
 BUILD_EXPERIMENTS, BUILD_POISON_LDS = 1, 2                           # sn_build_flags()
 ADAM_ZERO_GRAD, ADAM_LAZY = 1, 2                                     # sn_adam_step flags

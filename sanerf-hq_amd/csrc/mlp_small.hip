@@ -30,7 +30,7 @@ namespace sn {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int SM_MAXL = 4;              // layers of a chain
-constexpr int SM_MAXW = 64;             // widest layer
+
 
 struct SmallArgs {
     const float *w[SM_MAXL];            // nn.Linear.weight [out, in] of FORWARD layer l

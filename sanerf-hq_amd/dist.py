@@ -137,36 +137,76 @@ class PipelinedGather:
         self.works = [None] * depth
         self.k = 0
         self.last = None
+        self._waits: list = []          # (event before, event after) around every wait on a collective: what the compute stream lost to it
+        self._timed = torch.device(device).type == "cuda"
+        # How the band reaches the collective.  "in_place": the send buffer IS this rank's slice of the receive buffer (RCCL's in-place
+        # all-gather: no staging copy).  "staged": the band is copied first -- gloo cannot alias, and an RCCL build that rejects the alias is
+        # detected here, once, by a synchronous probe on a few bytes (the first real run on 8 GPUs must not die on it).
+        self.path = "local" if not dist.is_initialized() else "staged (gloo cannot alias send and receive buffers)"
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            self.path = "in_place"
+            try:
+                probe = torch.zeros(self.world * 4, device=device, dtype=dtype)
+                r = dist.get_rank(group)
+                probe[r * 4:(r + 1) * 4] = float(r + 1)
+                dist.all_gather_into_tensor(probe, probe[r * 4:(r + 1) * 4], group=group)
+                want = torch.arange(1, self.world + 1, device=device, dtype=dtype).repeat_interleave(4)
+                if not torch.equal(probe, want):
+                    raise RuntimeError("in-place all_gather_into_tensor returned wrong data")
+            except RuntimeError as e:       # noqa: BLE001
+                self.path = f"staged (in-place all_gather_into_tensor rejected by the backend: {str(e).splitlines()[0][:160]})"
+
+    def _wait(self, slot: int) -> None:
+        w = self.works[slot]
+        if w is None:
+            return
+        if self._timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            w.wait()
+            b.record()
+            self._waits.append((a, b))
+        else:
+            w.wait()
+        self.works[slot] = None
 
     def band_buffer(self, rank: Optional[int] = None) -> torch.Tensor:
         """This rank's [rows * W, K] slice of the image buffer the NEXT submit() gathers into: render into it (render_rays(packed=...)) and
         hand it back to submit() -- the all-gather then runs in place, without a staging copy of the band."""
         slot = self.k % len(self.images)
-        if self.works[slot] is not None:
-            self.works[slot].wait()                 # the buffer's previous frame is complete
-            self.works[slot] = None
+        self._wait(slot)                            # the buffer's previous frame is complete
         r = (dist.get_rank(self.group) if dist.is_initialized() else 0) if rank is None else rank
         return self.images[slot][r * self.local_numel:(r + 1) * self.local_numel]
 
     def submit(self, local: torch.Tensor) -> None:
         assert local.shape[0] == self.local_numel, f"expected a band of {self.local_numel} rays, got {local.shape[0]}"
         slot = self.k % len(self.images)
-        if self.works[slot] is not None:
-            self.works[slot].wait()                 # the buffer's previous frame is complete
+        self._wait(slot)                            # the buffer's previous frame is complete
         if not dist.is_initialized():
             self.images[slot].copy_(local)
         else:
             src = local.contiguous()
-            if src.data_ptr() >= self.images[slot].data_ptr() and src.data_ptr() < self.images[slot].data_ptr() + self.images[slot].numel() * self.images[slot].element_size() \
-                    and dist.get_backend(self.group) != "nccl":
-                src = src.clone()                   # band_buffer(): RCCL gathers in place (send = receive + rank * count); gloo stages through a copy
-            self.works[slot] = dist.all_gather_into_tensor(self.images[slot], src, group=self.group, async_op=True)
+            img = self.images[slot]
+            aliased = img.data_ptr() <= src.data_ptr() < img.data_ptr() + img.numel() * img.element_size()
+            if aliased and self.path != "in_place":
+                src = src.clone()                   # band_buffer(): RCCL gathers in place (send = receive + rank * count); otherwise stage through a copy
+            self.works[slot] = dist.all_gather_into_tensor(img, src, group=self.group, async_op=True)
         self.last = slot
         self.k += 1
 
     def drain(self) -> Optional[torch.Tensor]:
-        for i, w in enumerate(self.works):
-            if w is not None:
-                w.wait()
-                self.works[i] = None
+        for i in range(len(self.works)):
+            self._wait(i)
         return None if self.last is None else self.images[self.last]
+
+    def stats(self, reset: bool = True) -> dict:
+        """{"path": how the band reaches the collective, "gather_wait_ms": total time the compute stream spent waiting on collectives since the
+        last reset, "waits": their number}.  Synchronises the device (event timings)."""
+        total = 0.0
+        n = len(self._waits)
+        if self._timed and n:
+            torch.cuda.synchronize()
+            total = sum(a.elapsed_time(b) for a, b in self._waits)
+        if reset:
+            self._waits = []
+        return {"path": self.path, "gather_wait_ms": total, "waits": n}

@@ -144,6 +144,29 @@ def test_bench_multi_rank_branch_runs_on_one_gpu(nproc):
     assert line["gathered_image_check"]["rows_per_rank"] == [[256 // nproc * r, 256 // nproc * (r + 1)] for r in range(nproc)]
     assert line["n1_same_image_rays_per_s"] > 0 and line["single_gpu_same_image"]["ms_per_step"] > 0
     assert "roofline" in line and line["roofline"]["bound"] == "hbm"
+    # round 6: the line explains itself -- every rank's band time, kernel time, all-gather wait and image check, and how the band reached the collective
+    pr = line["per_rank"]
+    for key in ("band_ms_per_step", "median_frame_ms", "final_kernel_ms", "all_gather_wait_ms_per_step", "shader_clock_mhz", "rays"):
+        assert len(pr[key]) == nproc, key
+    assert all(t > 0 for t in pr["band_ms_per_step"]) and all(t >= 0 for t in pr["all_gather_wait_ms_per_step"])
+    assert pr["rays"] == [256 * 256 // nproc] * nproc and 0 <= pr["slowest_rank"] < nproc
+    assert pr["gather_path"].startswith("staged (gloo")
+    assert line["gathered_image_check"]["max_abs_diff_per_rank"] == [0.0] * nproc
+
+
+def test_bench_watchdog_names_the_stalled_rank():
+    """bench.py --watchdog-seconds: a rank that makes no progress prints which rank stalled in which phase and exits 124 instead of hanging the
+    job.  Provoked here with a world of 2 whose second rank never starts (the first one waits in the rendezvous)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--shared-device",
+                        "--watchdog-seconds", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert "WATCHDOG: rank 0 made no progress" in r.stderr and "init_process_group" in r.stderr
 
 
 def test_render_writes_straight_into_a_packed_band(gpu, orc):

@@ -3,7 +3,7 @@
 # Counter passes (rocprofv3 --pmc with --kernel-trace only, one pass per counter group) for the kernels the bench line's roofline block does
 # not cover (round-4 verdict item 6): k_mask16 / k_mlp_wide (mask render), k_feat_stage (configs[2]), k_bin_scatter / k_bin_accum /
 # k_linear_wgrad_mfma / k_mlp_wide<4> (configs[4] step), k_prop_stage with fp16 tables (reference schedule).
-R=${1:-r05}; out=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $out; root=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+R=${1:-r06}; out=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $out; root=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(TCP|TA|TCC|SQ)_[A-Z0-9_]+(_sum)?\b" | sort -u > $out/counters_available.txt
 run() {   # name, filter, command...
   local name=$1 filt=$2; shift 2
@@ -29,6 +29,7 @@ LIST
 run mask_head "k_mask16|k_mlp_wide|k_final_stage|k_prop_stage" python $root/tools/mask_profile.py mask
 run c3_sam_head "k_feat_stage|k_mlp_wide|k_final_stage" python $root/tools/c3_profile.py
 run train_mask "k_bin_|k_linear_wgrad|k_mlp_wide|k_grid_forward|k_adam" python $root/tools/train_profile.py mask
+run train_rgb "k_mlp_small|k_bin_|k_linear_wgrad|k_grid_forward|k_ray_composite|k_adam" python $root/tools/train_profile.py rgb
 run ref_f16 "k_prop_stage|k_final_stage" python $root/bench.py --steps 2 --warmup 1 --schedule ref --tables f16 --no-cpu-baseline --primary-only
 run flat128_f16 "k_final_stage" python $root/bench.py --steps 2 --warmup 1 --schedule flat128 --tables f16 --no-cpu-baseline --primary-only
 ls -la $out

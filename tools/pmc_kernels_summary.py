@@ -6,10 +6,15 @@ import os
 import re
 import sys
 
+import hashlib
+import json
+
 d0 = sys.argv[1]
 sets = (("pmc_kernels_mask_head.txt", ("k_mask16",)), ("pmc_kernels_c3_sam_head.txt", ("k_feat_stage",)),
         ("pmc_kernels_train_mask.txt", ("k_bin_refs", "k_bin_pull", "k_bin_scatter", "k_bin_accum", "k_linear_wgrad_mfma", "k_mlp_wide", "k_grid_forward")),
+        ("pmc_kernels_train_rgb.txt", ("k_mlp_small", "k_bin_refs", "k_bin_pull", "k_grid_forward", "k_linear_wgrad_mfma", "k_ray_composite")),
         ("pmc_kernels_ref_f16.txt", ("k_prop_stage", "k_final_stage")), ("pmc_kernels_flat128_f16.txt", ("k_final_stage",)))
+as_json = {}
 print("workload      kernel               cycles/launch  (ms at 2.3 GHz)  MfmaUtil VALUBusy TA-busy  gather-instr  L1-acc/instr  L2-hit  FETCH_SIZE  WRITE_SIZE")
 for f, ks in sets:
     path = os.path.join(d0, f)
@@ -28,5 +33,22 @@ for f, ks in sets:
         g = lambda c: d.get((full[0], c), float("nan"))   # noqa: E731
         act = g("GRBM_GUI_ACTIVE") / 8
         hit = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) * 100
+        as_json.setdefault(f[12:-4], {})[k] = {
+            "shader_cycles_per_launch": act, "MfmaUtil_pct": g("MfmaUtil"), "VALUBusy_pct": g("VALUBusy"),
+            "TA_busy_pct": g("TA_TA_BUSY_sum") / 256 / act * 100, "L2_hit_pct": hit, "gather_instructions": g("SQ_INSTS_VMEM_RD"),
+            "fetch_bytes_gfx950_corrected": 2 * 1024 * g("FETCH_SIZE"), "write_bytes": 1024 * g("WRITE_SIZE")}
         print(f"{f[12:-4]:13s} {k:20s} {act:13.0f}  {act / 2.3e6:15.3f}  {g('MfmaUtil'):8.1f} {g('VALUBusy'):8.1f} {g('TA_TA_BUSY_sum') / 256 / act * 100:6.1f}%  {g('SQ_INSTS_VMEM_RD'):12.4g}  "
               f"{g('TCP_TOTAL_CACHE_ACCESSES_sum') / max(g('SQ_INSTS_VMEM_RD'), 1):12.1f}  {hit:5.1f}%  {g('FETCH_SIZE'):10.4g}  {g('WRITE_SIZE'):10.4g}")
+
+if len(sys.argv) > 2:       # second argument: a JSON twin of the table for bench.py (`also.*.roofline.binding`), tied to the kernel sources by their hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "sanerf-hq_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".inc")):
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    clean = {w: {k: {kk: (None if vv != vv else round(vv, 3)) for kk, vv in v.items()} for k, v in ks.items()} for w, ks in as_json.items()}
+    json.dump({"source_fingerprint": h.hexdigest()[:16], "from": d0, "workloads": clean,
+               "note": "means per launch under rocprofv3 --pmc (one counter group per pass, --kernel-trace only); fetch bytes = 2 x FETCH_SIZE KiB "
+                       "(the gfx950 correction of MI355X_MICROARCH.md: 128-byte requests tallied at 64 B); VALUBusy by the gfx94x formula"},
+              open(sys.argv[2], "w"), indent=1)
