@@ -362,6 +362,10 @@ typedef struct sn_render_io {
     float       *geo_feat_last;             /* [N,T_last,geo] per-sample geometry features (feeds the mask head) */
     float       *f_image;                   /* [N, geo+sh] composited colour features (feeds the SAM head) */
     float       *f_feat;                    /* [N, L*C of cfg->feat_grid]; required when cfg->with_feat */
+    uint32_t     head_stride;               /* 0: f_image / f_feat are dense arrays.  s > 0: both are COLUMN RANGES of one row-major [N, s] buffer -- the SAM head's
+                                             * MLP input cat([f_sam, f_image, image, depth]) of renderer.py:366 written in place of a concatenation: rows are s floats
+                                             * apart, and rgb | depth of ray n are written once more at f_image + n*s + 31 (4 floats).  The caller points f_feat at
+                                             * column 0 and f_image at column L*C, s = L*C + 31 + 4 (163 for the reference network).  Needs f_image. */
     /* workspace */
     void        *workspace;                 /* device, >= sn_rm_render_workspace_bytes() */
     size_t       workspace_bytes;

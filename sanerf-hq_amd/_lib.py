@@ -68,7 +68,7 @@ class RenderIO(C.Structure):
                 ("image", C.c_void_p), ("depth", C.c_void_p), ("weights_sum", C.c_void_p), ("out_stride", C.c_uint32),
                 ("bins", C.c_void_p * MAX_STAGES), ("weights", C.c_void_p * MAX_STAGES),
                 ("sigmas", C.c_void_p * MAX_STAGES), ("inds", C.c_void_p * MAX_STAGES),
-                ("xyzs_last", C.c_void_p), ("geo_feat_last", C.c_void_p), ("f_image", C.c_void_p), ("f_feat", C.c_void_p),
+                ("xyzs_last", C.c_void_p), ("geo_feat_last", C.c_void_p), ("f_image", C.c_void_p), ("f_feat", C.c_void_p), ("head_stride", C.c_uint32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 

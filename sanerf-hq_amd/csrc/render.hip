@@ -1045,6 +1045,8 @@ struct FinalArgs {
     float *image, *depth, *wsum;
     uint32_t istride, sstride;   // floats between consecutive rays of image / of depth and wsum (3 and 1, or sn_render_io.out_stride for both)
     float *dbg_bins, *dbg_w, *dbg_sigma, *dbg_xyz, *dbg_geo, *dbg_fimg;
+    uint32_t fimg_stride;        // floats between consecutive rays of dbg_fimg (geo + 16, or sn_render_io.head_stride)
+    float *head_rgbd;            // sn_render_io.head_stride: rgb | depth of ray n also go to head_rgbd[n * fimg_stride + 0..3] (the SAM head's MLP input), or NULL
     float *w_out;                // scratch [T][Npad] for the feature stage, or NULL
     float stop_cum;              // > 0: a wave leaves the march once every lane's optical depth exceeds this (-ln eps)
     PairTab pairs;               // dense levels of the main grid as aligned x-pairs (K > 0 instantiations)
@@ -1968,7 +1970,13 @@ __global__ __launch_bounds__(256, MODE == MLP_VALU ? 1 : SN_FINAL_WAVES) void k_
         a.wsum[(size_t)n * a.sstride] = ws;
         if (a.dbg_fimg) {
 #pragma unroll
-            for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
+            for (int c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * a.fimg_stride + c] = fimg[c];
+        }
+        if (a.head_rgbd) {
+            float *q = a.head_rgbd + (size_t)n * a.fimg_stride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = a.image[(size_t)n * a.istride + c];
+            q[3] = dep;
         }
     }
 }
@@ -2161,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_final_stage_any(FinalArgs a, AnyShape s
 #pragma unroll
         for (uint32_t c = 0; c < 16u; ++c) bufA[(GEO + c) * 256u] = sh[c] * ws;
     }
-    if (ok && a.dbg_fimg) for (uint32_t c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = bufA[c * 256u];
+    if (ok && a.dbg_fimg) for (uint32_t c = 0; c < NCOL; ++c) a.dbg_fimg[(size_t)n * a.fimg_stride + c] = bufA[c * 256u];
     float *xin = bufA, *xout = bufB;
     for (uint32_t i = 0; i < s.nv; ++i) {
         dense_any(s.wv[i], s.dv[i], s.dv[i + 1u], i + 1u < s.nv, xin, xout);
@@ -2420,9 +2428,15 @@ __global__ __launch_bounds__(256, 2) void k_final_stage_cmp(FinalArgs a) {
         a.wsum[(size_t)n * a.sstride] = ws;
         if (a.dbg_fimg) {
 #pragma unroll
-            for (int c = 0; c < GEO; ++c) a.dbg_fimg[(size_t)n * NCOL + c] = fimg[c];
+            for (int c = 0; c < GEO; ++c) a.dbg_fimg[(size_t)n * a.fimg_stride + c] = fimg[c];
 #pragma unroll
-            for (int c = 0; c < NSH; ++c) a.dbg_fimg[(size_t)n * NCOL + GEO + c] = sh[c] * ws;
+            for (int c = 0; c < NSH; ++c) a.dbg_fimg[(size_t)n * a.fimg_stride + GEO + c] = sh[c] * ws;
+        }
+        if (a.head_rgbd) {
+            float *q = a.head_rgbd + (size_t)n * a.fimg_stride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = a.image[(size_t)n * a.istride + c];
+            q[3] = dep;
         }
     }
 }
@@ -2603,7 +2617,7 @@ __global__ __launch_bounds__(256, 1) void k_final_stage_sp(FinalArgs a, uint32_t
     __builtin_amdgcn_wave_barrier();          // the ray's lanes live in one wave; LDS serves a wave in order
     const float dep = ray_col[FSP_DEPTH_ROW * 64];
     if (ok && c == 0u && a.dbg_fimg) {
-        for (int k = 0; k < NCOL; ++k) a.dbg_fimg[(size_t)n * NCOL + k] = ray_col[k * 64];
+        for (int k = 0; k < NCOL; ++k) a.dbg_fimg[(size_t)n * a.fimg_stride + k] = ray_col[k * 64];
     }
     __builtin_amdgcn_wave_barrier();
     float rgb[3];
@@ -2624,6 +2638,12 @@ __global__ __launch_bounds__(256, 1) void k_final_stage_sp(FinalArgs a, uint32_t
         }
         a.depth[(size_t)n * a.sstride] = dep;
         a.wsum[(size_t)n * a.sstride] = ws;
+        if (a.head_rgbd) {
+            float *q = a.head_rgbd + (size_t)n * a.fimg_stride;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q[k] = a.image[(size_t)n * a.istride + k];
+            q[3] = dep;
+        }
     }
 }
 
@@ -2642,7 +2662,8 @@ struct FeatArgs {
     const float *bins0_tab;
     uint32_t bins0_stride;
     const float *w_in;           // scratch [T][Npad]
-    float *out;                  // [N, L*C]
+    float *out;                  // [N, L*C], rows out_stride floats apart
+    uint32_t out_stride;         // L*C, or sn_render_io.head_stride
 };
 
 template <typename TT, int C, int LG>
@@ -2714,10 +2735,11 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
         }
     }
     if (!ok) return;
-    float *o = a.out + (size_t)n * a.g.L * C + (size_t)l0 * C;
+    float *o = a.out + (size_t)n * a.out_stride + (size_t)l0 * C;
+    const bool vec_ok = (a.out_stride & 3u) == 0u;          // (a [N, 163] head input: rows are not 16-byte aligned)
 #pragma unroll
     for (int i = 0; i < LG; ++i) {
-        if constexpr (C % 4 == 0) {
+        if (C % 4 == 0 && vec_ok) {
 #pragma unroll
             for (int q = 0; q < C / 4; ++q)
                 reinterpret_cast<float4 *>(o + i * C)[q] = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
@@ -3101,6 +3123,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                                    "render_rays: skip_final needs >= 2 stages, io->bins[last] for the resampled bins, and no feature stage");
     else SN_REQUIRE(io->image && io->depth && io->weights_sum, "render_rays: outputs must be device pointers");
     SN_REQUIRE(io->out_stride == 0u || io->out_stride >= 5u, "render_rays: out_stride %u must be 0 (dense outputs) or at least 5 floats (rgb | depth | weights_sum per row)", io->out_stride);
+    SN_REQUIRE(io->head_stride == 0u || (io->f_image && io->head_stride >= 31u + 4u && !io->skip_final),
+               "render_rays: head_stride %u needs f_image and room for f_image | rgb | depth (>= 35 floats per row)", io->head_stride);
     SN_REQUIRE(cfg->tuning.wave_tile >= 0 && cfg->tuning.wave_tile <= 5, "render_rays: tuning.wave_tile %d outside 0..5", cfg->tuning.wave_tile);
     SN_REQUIRE(!(rs_enabled(cfg) && cfg->tuning.wave_tile != 0 && cfg->tuning.wave_tile != 3), "render_rays: the role-split experiment is built for 8x8 wave tiles (tuning.wave_tile 0 or 3)");
     const uint32_t S = cfg->num_stages;
@@ -3375,7 +3399,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         fa.dbg_sigma = io->sigmas[S - 1] ? io->sigmas[S - 1] + (size_t)first * fa.T : nullptr;
         fa.dbg_xyz = io->xyzs_last ? io->xyzs_last + (size_t)first * fa.T * 3 : nullptr;
         fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * 15 : nullptr;
-        fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * 31 : nullptr;
+        fa.fimg_stride = io->head_stride ? io->head_stride : 31u;
+        fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * fa.fimg_stride : nullptr;
+        fa.head_rgbd = (io->head_stride && io->f_image) ? fa.dbg_fimg + 31 : nullptr;
         fa.pairs = pairs;
         const bool lv_ok = build_final_lv(gl_main, dense_prefix(gl_main), pairs, cfg->grid.embeddings,
                                           2u * (cfg->grid.table_dtype == SN_F16 ? 2u : 4u), fa.lv);
@@ -3398,7 +3424,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             note("k_final_stage_any", nblk, (size_t)(2u * any_shape.rows + (any_shape.dg[any_shape.ng] - 1u)) * 256u * sizeof(float), 0, cfg->grid.L * 8u);
             const uint32_t geo = any_shape.dg[any_shape.ng] - 1u;
             fa.dbg_geo = io->geo_feat_last ? io->geo_feat_last + (size_t)first * fa.T * geo : nullptr;
-            fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * (geo + 16u) : nullptr;
+            fa.fimg_stride = io->head_stride ? io->head_stride : geo + 16u;
+            fa.dbg_fimg = io->f_image ? io->f_image + (size_t)first * fa.fimg_stride : nullptr;
+            fa.head_rgbd = nullptr;
             const size_t lds_bytes = (size_t)(2u * any_shape.rows + geo) * 256u * sizeof(float);
             if (f16) {
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage_any<__half>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -3567,7 +3595,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             ft.bins_in = b_scr[S - 1]; ft.bins0_stride = io->bins0_ray_stride;
             ft.bins0_tab = (S == 1 && io->bins0_table) ? io->bins0_table + (size_t)first * ft.bins0_stride : nullptr;
             ft.w_in = w_scr[S - 1];
-            ft.out = io->f_feat + (size_t)first * gl_feat.L * gl_feat.C;
+            ft.out_stride = io->head_stride ? io->head_stride : gl_feat.L * gl_feat.C;
+            ft.out = io->f_feat + (size_t)first * ft.out_stride;
             const bool h16 = cfg->feat_grid.table_dtype == SN_F16;
             ProfScope ps_feat(st, PK_FEAT);
 #define SN_LAUNCH_FEAT(CC, LGG)                                                                                       \

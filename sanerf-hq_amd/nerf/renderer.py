@@ -270,17 +270,21 @@ class NeRFRenderer(nn.Module):
         return rm.mlp_forward(x.reshape(-1, x.shape[-1]), mlp, ln).reshape(*lead, -1)
 
     def _heads(self, results, weights, xyzs, geo_feat, f_image, image, depth, return_feats, return_mask, H, W,
-               tile_w=0, f_sam=None):
+               tile_w=0, f_sam=None, head_input=None):
         opt = self.opt
         if opt.with_sam:                                    # renderer.py:301-302, 359-374
-            if f_sam is not None:
+            if head_input is not None:
+                pass                                        # cat([f_sam, f_image, image, depth]) was written in place by the fused render
+            elif f_sam is not None:
                 pass                                        # accumulated inside the fused render (feature stage)
             elif torch.is_grad_enabled() and any(t.requires_grad for t in (self.s_grid.embeddings, weights, xyzs)):
                 features = self.s_grid(xyzs, bound=self.bound)
                 f_sam = rm.composite(weights, features)
             else:   # inference: one kernel, no [N*T, 128] intermediate
                 f_sam = rm.grid_composite(weights, xyzs, self.s_grid, self.bound, tile_w=tile_w)
-            if opt.sam_use_view_direction:
+            if head_input is not None:
+                f = head_input
+            elif opt.sam_use_view_direction:
                 f = torch.cat([f_sam, f_image, image, depth.unsqueeze(-1)], dim=-1)
             else:
                 f = torch.cat([f_sam, rm.composite(weights, geo_feat), image, depth.unsqueeze(-1)], dim=-1)
@@ -321,16 +325,20 @@ class NeRFRenderer(nn.Module):
             want.append("geo_feat_last")                    # [N,T,15] per-sample features
         plan = self._get_plan(with_feat=fused_sam)
         bg = float(bg_color) if not torch.is_tensor(bg_color) else 0.0
+        # the SAM head's MLP input [N, 163] = f_sam | f_image | image | depth written in place by the kernels (no torch.cat, renderer.py:366);
+        # a tensor background is blended after the kernel, so the image columns would be stale: that case keeps the concatenation
+        head_in = fused_sam and opt.sam_use_view_direction and not torch.is_tensor(bg_color)
         with torch.no_grad():
             out = rm.render_rays(plan, rays_o, rays_d, cam_near_far=cam_near_far, bg_color=bg, tile_w=tile_w, want=want,
-                                 packed=None if torch.is_tensor(bg_color) else packed)
+                                 packed=None if torch.is_tensor(bg_color) else packed, head_input=head_in)
             image = out["image"]
             if torch.is_tensor(bg_color):                   # per-ray / rgb background (renderer.py:353)
                 image = image + (1 - out["weights_sum"]).unsqueeze(-1) * bg_color
         results = {"weights_sum": out["weights_sum"], "depth": out["depth"], "image": image}
         if need_heads:
             self._heads(results, out.get("weights_last"), out.get("xyzs_last"), out.get("geo_feat_last"), out.get("f_image"),
-                        image, out["depth"], return_feats, return_mask, H, W, tile_w=tile_w or 0, f_sam=out.get("f_feat"))
+                        image, out["depth"], return_feats, return_mask, H, W, tile_w=tile_w or 0, f_sam=out.get("f_feat"),
+                        head_input=out.get("head_input") if head_in else None)
         return results
 
     # ---------------------------------------------------------------------------------------

@@ -743,13 +743,16 @@ class RenderPlan:
 def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: float = 1.0, tile_w: int = 0,
                 want: Sequence[str] = (), u_tables: Optional[Dict[int, torch.Tensor]] = None,
                 bins0_table: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None,
-                skip_final: bool = False, tuning: Optional["Tuning"] = None, packed: Optional[torch.Tensor] = None):
+                skip_final: bool = False, tuning: Optional["Tuning"] = None, packed: Optional[torch.Tensor] = None,
+                head_input: bool = False):
     """Fused render of N rays.  Returns dict(image [N,3], depth [N], weights_sum [N]) plus the
     per-stage tensors named in `want`: 'bins', 'weights', 'sigmas', 'inds' (all stages),
     'weights_last', 'xyzs_last', 'geo_feat_last', 'f_image'; a plan built with `feat_encoder` also
     returns 'f_feat' [N, L*C] = composite(weights_last, feat_encoder(xyzs_last)).
     packed: a contiguous fp32 [N, K >= 5] buffer -- the kernels write rgb | depth | weights_sum into its first five columns (sn_render_io.out_stride)
-    and the returned image / depth / weights_sum are views of it: the payload of the image all-gather without a concatenation (dist.py)."""
+    and the returned image / depth / weights_sum are views of it: the payload of the image all-gather without a concatenation (dist.py).
+    head_input (plans with `feat_encoder`): also return 'head_input' [N, L*C + ncol + 4] = cat([f_feat, f_image, image, depth]) -- the SAM head's
+    MLP input of renderer.py:366 -- written in place by the kernels (sn_render_io.head_stride); 'f_feat' / 'f_image' are then views of it."""
     rays_o, rays_d = _flat3(rays_o), _flat3(rays_d)
     N = rays_o.shape[0]
     device = rays_o.device
@@ -822,10 +825,16 @@ def render_rays(plan: RenderPlan, rays_o, rays_d, cam_near_far=None, bg_color: f
         io.xyzs_last = buf("xyzs_last", (N, Tl, 3)).data_ptr()
     if "geo_feat_last" in want:
         io.geo_feat_last = buf("geo_feat_last", (N, Tl, plan.geo)).data_ptr()
-    if "f_image" in want:
-        io.f_image = buf("f_image", (N, plan.ncol)).data_ptr()
-    if plan.cfg.with_feat and not skip_final:
-        io.f_feat = buf("f_feat", (N, plan.feat_dim)).data_ptr()
+    if head_input and plan.cfg.with_feat and not skip_final:
+        S_head = plan.feat_dim + plan.ncol + 4
+        hb = buf("head_input", (N, S_head))
+        io.f_feat, io.f_image, io.head_stride = hb.data_ptr(), hb.data_ptr() + 4 * plan.feat_dim, S_head
+        res["f_feat"], res["f_image"] = hb[:, :plan.feat_dim], hb[:, plan.feat_dim:plan.feat_dim + plan.ncol]
+    else:
+        if "f_image" in want:
+            io.f_image = buf("f_image", (N, plan.ncol)).data_ptr()
+        if plan.cfg.with_feat and not skip_final:
+            io.f_feat = buf("f_feat", (N, plan.feat_dim)).data_ptr()
     eff = tuning or plan.tuning or globals()["tuning"]           # per call > per plan > process default
     eff.write(plan.cfg.tuning)
     need = int(_lib.lib().sn_rm_render_workspace_bytes(C.byref(plan.cfg), N, int(tile_w)))

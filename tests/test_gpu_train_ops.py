@@ -290,3 +290,26 @@ def test_fused_training_route_with_jitter_runs_and_is_seed_reproducible(gpu):
     torch.manual_seed(124)
     o2 = model.render(ro, rd, staged=False, bg_color=1, perturb=True, update_proposal=True)
     assert not torch.equal(o2["image"], runs[0][0])
+
+
+def test_sam_head_input_written_in_place_equals_the_concatenation(gpu):
+    """sn_render_io.head_stride: the fused render writes f_sam | f_image | rgb | depth straight into the [N, 163] input of samvit_mlp
+    (renderer.py:366 concatenates four tensors).  Bit-equal to the concatenation of the dense outputs, for image-order tiles and for a small
+    linear-order batch (the several-lanes-per-ray kernels), and the SAM feature map is unchanged."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    model = NeRFNetwork(make_opt(with_sam=True))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_params([128, 64, 32], heads=True, seed=1).items()}, strict=False)
+    model = model.to(gpu).eval()
+    for H, W, tile in ((96, 96, True), (40, 50, False)):
+        ro, rd = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+        plan = model._get_plan(with_feat=True)
+        with torch.no_grad():
+            a = rm.render_rays(plan, ro, rd, tile_w=W if tile else 0, want=("f_image",), out={})
+            b = rm.render_rays(plan, ro, rd, tile_w=W if tile else 0, want=("f_image",), out={}, head_input=True)
+            want = torch.cat([a["f_feat"], a["f_image"], a["image"], a["depth"].unsqueeze(-1)], dim=-1)
+            assert b["head_input"].shape == (H * W, 163) and torch.equal(b["head_input"], want)
+            assert torch.equal(b["image"], a["image"]) and torch.equal(b["depth"], a["depth"]) and torch.equal(b["weights_sum"], a["weights_sum"])
+            o1 = model.render(ro, rd, staged=False, bg_color=1, perturb=False, return_feats=1, H=H, W=W, tile_w=W if tile else 0)
+            ref = model._head_mlp(model.samvit_mlp, want).view(H, W, -1)
+            assert torch.equal(o1["samvit"], ref)
