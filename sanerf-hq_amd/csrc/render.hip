@@ -2664,11 +2664,46 @@ struct FeatArgs {
     const float *w_in;           // scratch [T][Npad]
     float *out;                  // [N, L*C], rows out_stride floats apart
     uint32_t out_stride;         // L*C, or sn_render_io.head_stride
+    uint32_t level0;             // first level of this launch (blockIdx.y counts passes of LG levels from here)
 };
 
-template <typename TT, int C, int LG>
+// wave-wide minimum / maximum of a float in six DPP steps (row_shr 1, 2, 4, 8 bring a row's extremum to its lane 15, row_bcast:15 / :31 carry
+// it across the four rows to lane 63), returned wave-uniform.
+template <bool MAXI>
+__device__ __forceinline__ float wave_extremum(float v) {
+    auto step = [&](auto ctrl_tag, auto rmask_tag) {
+        constexpr int ctrl = decltype(ctrl_tag)::value, rmask = decltype(rmask_tag)::value;
+        const float t = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), ctrl, rmask, 0xf, false));
+        v = MAXI ? fmaxf(v, t) : fminf(v, t);
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
+// PATCH (round 6; north_star "LDS staging of per-tile grid voxels"): on a DENSE level the 64 rays of a wave tile at one sample
+// index occupy a handful of cells -- the bounding box of their vertices is 10-17 rows on levels 0-6 of the heads' grid
+// (profiles/r06/gather_lines_per_level.txt) -- yet every lane issues its own 8 corner fetches (16 gather instructions per level with 32-byte
+// rows, each at the texture path's per-instruction floor).  Here the wave fetches the box ONCE (lane v loads vertex v: one or two gather
+// instructions), parks it in LDS and every lane reads its 8 corners from there.  Same rows, same blend: bit-identical.  A box beyond 64 vertices
+// (wave-uniform test) and every hashed level take the ordinary path: on hashed levels a box fetches MORE lines than the direct gathers (same file).
+// MEASURED SLOWER (profiles/r06/feat_patch_ab.json, same box): configs[2] 400x400 2.46 -> 2.64 ms (fp32 tables), 2.08 -> 2.22 (fp16); 800x800 6.81 -> 7.43 /
+// 5.79 -> 6.32; one level per pass: 2.47 -> 2.53.  The dense levels' direct gathers touch 1.3-2.2 lines per instruction -- the texture path's best
+// case -- while the staged form adds a box computation (six wave reductions per sample), an LDS write -> read round trip inside every level's
+// dependent chain and twice the registers (192 vs 92: 2 instead of 5 waves per SIMD).  Third measured negative of LDS voxel staging on this chip
+// (round 2: per-wave vertex cache in the last stage, round 3: LDS-resident level 0).  Opt-in: sn_render_tuning.feat_patch = 1.
+constexpr uint32_t FEAT_PATCH_ROWS = 64;
+
+template <typename TT, int C, int LG, bool PATCH = false>
 __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
     SN_POISON_ALL();
+    __shared__ __attribute__((aligned(16))) TT patch_lds[PATCH ? 4 * LG * FEAT_PATCH_ROWS * C : 1];
     uint32_t n;
     const uint32_t wg = tile_id_x(a.rc, blockIdx.x, gridDim.x);
     const bool ok = ray_of_lane(a.rc, wg, n);
@@ -2683,8 +2718,10 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
         if (a.bins0_tab) return a.bins0_tab[(size_t)n * a.bins0_stride + j];
         return linspace_at(0.0f, 1.0f, b0step, T + 1u, j);
     };
-    const uint32_t l0 = blockIdx.y * LG;
+    const uint32_t l0 = a.level0 + blockIdx.y * LG;
     const TT *table = reinterpret_cast<const TT *>(a.table);
+    const uint32_t lane = threadIdx.x & 63u;
+    TT *my_patch = patch_lds + (PATCH ? (threadIdx.x >> 6) * (LG * FEAT_PATCH_ROWS * C) : 0u);
     float acc[LG][C];
 #pragma unroll
     for (int i = 0; i < LG; ++i)
@@ -2705,20 +2742,17 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) if (x01[d] < 0.0f || x01[d] > 1.0f) oob = true;     // gridencoder.cu:105-130
         const float wz = oob ? 0.0f : w;
-        float pos[LG][3];
-        float cv[LG][8][C];
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        if constexpr (PATCH) {       // bounding box (in table coordinates) of the lanes whose sample counts; wave-uniform
+            const bool act = wz != 0.0f;
 #pragma unroll
-        for (int i = 0; i < LG; ++i) {
-            const uint32_t l = l0 + i;
-            uint32_t cell[3], offs[8];
-            locate_linear(x01, a.g.res[l], pos[i], cell);
-            corner_offsets<-1, (uint32_t)(C * sizeof(TT))>(cell, a.g.res[l], a.g.size[l], a.g.mode[l], offs);
-            const char *tab = reinterpret_cast<const char *>(table + (size_t)a.g.off[l] * C);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) load_row<TT, C>(reinterpret_cast<const TT *>(tab + offs[k]), cv[i][k]);
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = wave_extremum<false>(act ? x01[d] : __builtin_inff());
+                hi[d] = wave_extremum<true>(act ? x01[d] : -__builtin_inff());
+            }
+            if (!(lo[0] <= hi[0])) continue;              // no lane counts: every fmaf(0, feature, acc) would leave acc as it is
         }
-#pragma unroll
-        for (int i = 0; i < LG; ++i) {
+        auto blend = [&](int i, const float (&ps)[3], const float (&cvi)[8][C]) {
             float feat[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) feat[c] = 0.0f;
@@ -2726,12 +2760,104 @@ __global__ __launch_bounds__(256) void k_feat_stage(FeatArgs a) {
             for (uint32_t idx = 0; idx < 8u; ++idx) {       // gridencoder.cu:171-192
                 float cw = 1.0f;
 #pragma unroll
-                for (uint32_t d = 0; d < 3u; ++d) cw *= (idx & (1u << d)) ? pos[i][d] : 1.0f - pos[i][d];
+                for (uint32_t d = 0; d < 3u; ++d) cw *= (idx & (1u << d)) ? ps[d] : 1.0f - ps[d];
 #pragma unroll
-                for (int c = 0; c < C; ++c) feat[c] = __builtin_fmaf(cw, cv[i][idx][c], feat[c]);
+                for (int c = 0; c < C; ++c) feat[c] = __builtin_fmaf(cw, cvi[idx][c], feat[c]);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[i][c] = __builtin_fmaf(wz, feat[c], acc[i][c]);
+        };
+        if constexpr (!PATCH) {
+            float pos[LG][3];
+            float cv[LG][8][C];
+#pragma unroll
+            for (int i = 0; i < LG; ++i) {
+                const uint32_t l = l0 + i;
+                uint32_t cell[3], offs[8];
+                locate_linear(x01, a.g.res[l], pos[i], cell);
+                corner_offsets<-1, (uint32_t)(C * sizeof(TT))>(cell, a.g.res[l], a.g.size[l], a.g.mode[l], offs);
+                const char *tab = reinterpret_cast<const char *>(table + (size_t)a.g.off[l] * C);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) load_row<TT, C>(reinterpret_cast<const TT *>(tab + offs[k]), cv[i][k]);
+            }
+#pragma unroll
+            for (int i = 0; i < LG; ++i) blend(i, pos[i], cv[i]);
+        } else {
+            // the boxes of all LG levels are fetched first (their gathers fly together), then every level is read back and blended
+            uint32_t c0[LG][3], nd[LG][3];
+            bool staged[LG];
+#pragma unroll
+            for (int i = 0; i < LG; ++i) {
+                const uint32_t l = l0 + i;
+                const uint32_t res = a.g.res[l];
+                // vertices of the box: cells of lo .. hi (locate_linear is monotone in x01) plus the +1 corners, clamped like them (gridencoder.cu:182)
+                const float rf = (float)res, top = (float)(res - 1u);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float p0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(lo[d], rf, -0.5f), 0.0f, top);
+                    const float p1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(hi[d], rf, -0.5f), 0.0f, top);
+                    c0[i][d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p0);
+                    const uint32_t c1 = umin((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p1) + 1u, res - 1u);
+                    nd[i][d] = c1 - c0[i][d] + 1u;
+                }
+                const uint32_t nxy = nd[i][0] * nd[i][1], total = nxy * nd[i][2];
+                const uint32_t mode = a.g.mode[l];
+                staged[i] = (mode & 1u) == 0u && ((mode >> 4) & 15u) == 3u && ((mode >> 1) & 3u) == 0u && total <= FEAT_PATCH_ROWS;    // dense level, box fits
+                if (staged[i]) {     // lane v fetches vertex v = ix + nx (iy + ny iz) of the box
+                    TT *pl = my_patch + (uint32_t)i * (FEAT_PATCH_ROWS * C);
+                    const char *tab = reinterpret_cast<const char *>(table + (size_t)a.g.off[l] * C);
+                    const uint32_t iz = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)nxy));
+                    const uint32_t rem = lane - iz * nxy;
+                    const uint32_t iy = (uint32_t)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)nd[i][0]));
+                    const uint32_t ix = rem - iy * nd[i][0];
+                    if (lane < total) {
+                        const uint32_t row = (c0[i][0] + ix) + res * ((c0[i][1] + iy) + res * (c0[i][2] + iz));
+                        const TT *src = reinterpret_cast<const TT *>(tab + (size_t)row * (C * sizeof(TT)));      // the row as it is stored
+                        constexpr int RB = C * (int)sizeof(TT);
+                        if constexpr (RB % 16 == 0) {
+#pragma unroll
+                            for (int q = 0; q < RB / 16; ++q) reinterpret_cast<uint4 *>(pl + lane * C)[q] = reinterpret_cast<const uint4 *>(src)[q];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) pl[lane * C + c] = src[c];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < LG; ++i) {
+                const uint32_t l = l0 + i;
+                const uint32_t res = a.g.res[l];
+                uint32_t cell[3];
+                float ps[3];
+                float cvi[8][C];
+                locate_linear(x01, res, ps, cell);
+                if (staged[i]) {
+                    // this lane's corners inside the box (a lane that does not count may lie outside: any row will do, its weight is 0)
+                    const TT *pl = my_patch + (uint32_t)i * (FEAT_PATCH_ROWS * C);
+                    uint32_t q0[3], q1[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        q0[d] = umin(cell[d] - c0[i][d], nd[i][d] - 1u);
+                        q1[d] = umin(q0[d] + (cell[d] < res - 1u ? 1u : 0u), nd[i][d] - 1u);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; ++k) {
+                        const uint32_t v = ((k & 1u) ? q1[0] : q0[0]) + nd[i][0] * (((k & 2u) ? q1[1] : q0[1]) + nd[i][1] * ((k & 4u) ? q1[2] : q0[2]));
+                        load_row<TT, C>(pl + v * C, cvi[k]);
+                    }
+                    blend(i, ps, cvi);
+                } else {
+                    uint32_t offs[8];
+                    corner_offsets<-1, (uint32_t)(C * sizeof(TT))>(cell, res, a.g.size[l], a.g.mode[l], offs);
+                    const char *tab = reinterpret_cast<const char *>(table + (size_t)a.g.off[l] * C);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) load_row<TT, C>(reinterpret_cast<const TT *>(tab + offs[k]), cvi[k]);
+                    blend(i, ps, cvi);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();      // the next sample's box overwrites the patch: every lane has read its corners
         }
     }
     if (!ok) return;
@@ -3599,11 +3725,25 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             ft.out = io->f_feat + (size_t)first * ft.out_stride;
             const bool h16 = cfg->feat_grid.table_dtype == SN_F16;
             ProfScope ps_feat(st, PK_FEAT);
+            // dense prefix of the feature grid: its passes run the LDS-patch instantiation (k_feat_stage<..., PATCH = true>), the hashed rest the plain one
+            uint32_t n_dense = 0;
+            while (n_dense < gl_feat.L && (gl_feat.mode[n_dense] & 1u) == 0u) ++n_dense;
+            const uint32_t lg_u = (uint32_t)feat_lg;
+            const uint32_t patch_levels = cfg->tuning.feat_patch != 1 ? 0u : ((n_dense + lg_u - 1u) / lg_u) * lg_u > gl_feat.L ? gl_feat.L : ((n_dense + lg_u - 1u) / lg_u) * lg_u;
 #define SN_LAUNCH_FEAT(CC, LGG)                                                                                       \
             do {                                                                                                      \
-                const dim3 fg(nblk, gl_feat.L / LGG);                                                                 \
-                if (h16) hipLaunchKernelGGL((k_feat_stage<__half, CC, LGG>), fg, dim3(256), 0, st, ft);                \
-                else hipLaunchKernelGGL((k_feat_stage<float, CC, LGG>), fg, dim3(256), 0, st, ft);                     \
+                if (patch_levels) {                                                                                   \
+                    ft.level0 = 0;                                                                                    \
+                    const dim3 fg(nblk, patch_levels / LGG);                                                          \
+                    if (h16) hipLaunchKernelGGL((k_feat_stage<__half, CC, LGG, true>), fg, dim3(256), 0, st, ft);      \
+                    else hipLaunchKernelGGL((k_feat_stage<float, CC, LGG, true>), fg, dim3(256), 0, st, ft);           \
+                }                                                                                                     \
+                if (patch_levels < gl_feat.L) {                                                                       \
+                    ft.level0 = patch_levels;                                                                         \
+                    const dim3 fg(nblk, (gl_feat.L - patch_levels) / LGG);                                            \
+                    if (h16) hipLaunchKernelGGL((k_feat_stage<__half, CC, LGG>), fg, dim3(256), 0, st, ft);            \
+                    else hipLaunchKernelGGL((k_feat_stage<float, CC, LGG>), fg, dim3(256), 0, st, ft);                 \
+                }                                                                                                     \
             } while (0)
             if (gl_feat.C == 8) { if (feat_lg == 4) SN_LAUNCH_FEAT(8, 4); else if (feat_lg == 2) SN_LAUNCH_FEAT(8, 2); else SN_LAUNCH_FEAT(8, 1); }
             else if (gl_feat.C == 4) { if (feat_lg == 4) SN_LAUNCH_FEAT(4, 4); else if (feat_lg == 2) SN_LAUNCH_FEAT(4, 2); else SN_LAUNCH_FEAT(4, 1); }

@@ -313,3 +313,21 @@ def test_sam_head_input_written_in_place_equals_the_concatenation(gpu):
             o1 = model.render(ro, rd, staged=False, bg_color=1, perturb=False, return_feats=1, H=H, W=W, tile_w=W if tile else 0)
             ref = model._head_mlp(model.samvit_mlp, want).view(H, W, -1)
             assert torch.equal(o1["samvit"], ref)
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_feature_stage_lds_patch_is_bit_identical(gpu, f16):
+    """sn_render_tuning.feat_patch = 1 (per-wave LDS staging of the dense levels' voxels in k_feat_stage; opt-in because it is
+    slower): f_feat equals the direct-gather kernel's bit for bit, image-order tiles and an odd-sized image, fp32 and fp16 tables."""
+    from sanerf_hq_amd import raymarching as rm, synth
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    model = NeRFNetwork(make_opt(with_sam=True))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_params([128, 64, 32], heads=True, seed=1).items()}, strict=False)
+    model = model.to(gpu).eval()
+    for H, W in ((96, 96), (37, 53)):
+        ro, rd = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+        plan = rm.RenderPlan(model, [128, 64, 32], torch.float16 if f16 else torch.float32, feat_encoder=model.s_grid)
+        a = rm.render_rays(plan, ro, rd, tile_w=W, out={}, tuning=rm.Tuning(feat_patch=0))
+        for lg in (0, 1, 4):
+            b = rm.render_rays(plan, ro, rd, tile_w=W, out={}, tuning=rm.Tuning(feat_patch=1, feat_levels=lg))
+            assert torch.equal(a["f_feat"], b["f_feat"]), (H, W, lg)

@@ -82,6 +82,7 @@ def main():
             print(f"{'lvl':>3} {'res':>5} {'hash':>4} | 8x8 pixels x 1 level, lines per corner instruction: {'fp16 rows':>9} {'fp32 rows':>9} | cells of a wave: bbox <= 2^3  <= 4^3  <= 8^3 | patch rows (bbox, mean)")
         else:
             print(f"{'lvl':>3} {'res':>5} {'hash':>4} | lines per corner instruction: {'8x8 px (k_feat_stage)':>22} {'32 rays (k_mlp_wide_j<3>)':>26} {'16 rays (k_mask16, per level)':>30} | bbox(8x8) <= 2^3  <= 4^3  <= 8^3 | patch rows")
+        per_lvl = []
         for l in range(L):
             r = int(res[l]); size = int(offs[l + 1] - offs[l])
             rows88, pg88, dense = rows_of(x88, r, size, int(offs[l]))
@@ -101,6 +102,22 @@ def main():
             patch = float(ext.prod(axis=-1).mean())
             print(f"{l:>3} {r:>5} {'n' if dense else 'y':>4} | " + " ".join(f"{c:>{w}.1f}" for c, w in zip(cols, (9, 9) if key == "grid" else (22, 26, 30)))
                   + f" | {fit[0]:10.2f} {fit[1]:6.2f} {fit[2]:6.2f} | {patch:10.0f}")
+            if key != "grid":
+                # round 6 (row g1): line visits of one wave-sample of k_feat_stage at this level, three ways.  direct = the 8 corner instructions as
+                # they are (lines merge inside an instruction only); unique = distinct lines over all 512 corner requests (what a perfect
+                # de-duplicating stage could reach); patch = the wave's bounding box of vertices loaded row by row (what a per-wave LDS patch fetches:
+                # on a hashed level every vertex is its own line)
+                ln_all = (rows88 // 4).reshape(n_w, 64, T, 8).transpose(0, 2, 1, 3).reshape(-1, 512)
+                per_lvl.append((l, r, dense, cols[0] * 8, distinct(ln_all), patch if not dense else patch / 4.0))
+        if key != "grid":
+            print("\nrow g1 (north_star: LDS staging of per-tile grid voxels), k_feat_stage, fp32 rows (32 B; fp16 rows: halve `patch` on dense levels only):")
+            print(f"{'lvl':>3} {'res':>5} {'hash':>4} | line visits per wave-sample: {'direct (8 instr)':>16} {'unique lines':>13} {'bbox patch':>11} | patch / direct")
+            for l, r, dense, d8, uq, pt in per_lvl:
+                print(f"{l:>3} {r:>5} {'n' if dense else 'y':>4} | {'':29s}{d8:16.1f} {uq:13.1f} {pt:11.1f} | {pt / d8:8.2f}")
+            tot = [sum(v[i] for v in per_lvl) for i in (3, 4, 5)]
+            print(f"all {len(per_lvl)} levels: direct {tot[0]:.0f}, unique {tot[1]:.0f}, bbox patch {tot[2]:.0f} line visits per wave-sample.  A bounding-box patch fetches MORE lines than the "
+                  f"direct gathers from level {next((v[0] for v in per_lvl if v[5] > v[3]), -1)} up: the samples of an 8x8-pixel tile at one depth index lie on a thin slanted sheet, "
+                  "its box is mostly empty.")
 
 
 if __name__ == "__main__":
