@@ -1680,7 +1680,7 @@ extern "C" int sn_mlp_wide_forward(const sn_mlp_desc *mlp, const float *ln_weigh
 // The training forward on the inference kernel (k_mlp_wide_j: split-fp16 x3 products, fp32 accumulation, ~2^-22 per product) with every
 // hidden layer's post-activation output saved as its tiles leave the accumulators.  Measured against the reference's gradients
 // (tests/golden/train_c5.npz) the three forwards -- BLAS fp32, fp32 MFMA, this -- give the SAME errors to three digits (7.8e-4 / 1.6e-4 /
-// 8.9e-4 relative L2 for the first two weight matrices and the table rows: tools/r5/fwd_modes_err.py): the error against the fixture comes
+// 8.9e-4 relative L2 for the first two weight matrices and the table rows: tools/train_fwd_modes_err.py): the error against the fixture comes
 // from elsewhere (the frozen field's 1e-5), not from how the mask MLP's pre-activations are rounded.
 extern "C" int sn_mlp_wide_forward_train_f16x3(const sn_mlp_desc *mlp, const float *x, uint32_t N, float *const *hidden, uint32_t *const *sign_bits,
                                                float *out, void *workspace, size_t workspace_bytes, sn_stream_t stream) {

@@ -710,7 +710,7 @@ WIDE_MLP_BACKWARD_FUSED = True      # False: the wide training MLP differentiate
 WIDE_MLP_FORWARD_F16X3 = True       # the wide training MLP's forward as ONE kernel on the inference path's matrix-core kernel (split-fp16 x3 products, ~2^-22 per
                                     # product, fp32 accumulation; sn_mlp_wide_forward_train_f16x3) with the hidden outputs saved: 0.38 -> 0.2 ms for the mask head.
                                     # Against the reference's gradients (train_c5.npz) it gives the same errors as the BLAS forward to three digits
-                                    # (tools/r5/fwd_modes_err.py).  Activations must stay inside the fp16 range (raymarching.mlp_wide_overflow()).  False: BLAS fp32
+                                    # (tools/train_fwd_modes_err.py).  Activations must stay inside the fp16 range (raymarching.mlp_wide_overflow()).  False: BLAS fp32
 WIDE_MLP_RANGE_CHECK_EVERY = 64    # with the split-fp16 forward: every this many training forwards the library's sticky overflow flag is read (one device
                                     # synchronisation; skipped while a HIP graph is being captured) and a RuntimeError names the cause -- an activation or
                                     # input at or beyond 65504 makes the logits, the loss and every gradient non-finite.  0: never check

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GridEncoder.forward_cat (k_grid_forward_rows, C = 8 fp32) at the training step's and the 400x400 mask render's sizes."""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sanerf_hq_amd.gridencoder import GridEncoder
 gpu = torch.device("cuda:0")

@@ -3,7 +3,7 @@
 BLAS fp32, the fp32-MFMA kernel, split-fp16 x3 products (emulated layer by layer through sn_mlp_wide_forward)."""
 import ctypes as C, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
 from helpers import golden, params_from_spec, spec_of, make_opt
 from sanerf_hq_amd import _lib, ops

@@ -2,7 +2,7 @@
 """sn_mlp_wide_backward_bits on k_mlp_wide_j<.., 2> vs k_mlp_wide<5> (experiments build: sn_debug_set("wide_bwd_j", v)) and the fp32-mask form k_mlp_wide<4>."""
 import ctypes as C, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sanerf_hq_amd import _lib, ops, synth
 gpu = torch.device("cuda:0")
