@@ -3,7 +3,7 @@
 # Regenerates every profile artefact of the round from the code as it is: rocprofv3 --kernel-trace --stats summaries of the
 # bench line(s) and of the other configurations, the --pmc passes of the dominant kernel (separate passes, kernel-trace only),
 # the HBM-side traffic json bench.py reads, the micro-benchmarks and the un-profiled bench lines.
-R=${1:-r01}; out=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+R=${1:-r06}; out=$GRAFT_REPO_ROOT/gpurun_out/$R; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT
 stats() {   # name, command...
   local name=$1; shift
@@ -61,5 +61,8 @@ python $root/tools/fuzz_parity.py any 150 5 2>&1 | grep -v amdgpu.ids | grep -E 
 # un-profiled numbers
 cd $root
 python tools/bench_configs.py 2>/dev/null | tail -1 > $out/bench_configs.json
+python tools/train_bench.py both 2>/dev/null | tail -1 > $out/train_bench.json
+python tools/mlp_modes_ab.py 2>/dev/null | tail -1 > $out/mlp_modes_ab_final.json
+python tools/feat_patch_ab.py 2>/dev/null | tail -1 > $out/feat_patch_ab_final.json
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 ls -la $out
