@@ -97,6 +97,13 @@ int sn_grid_encode_backward(const float *grad, const float *inputs, const void *
  * grad_embeddings zero-initialised by the caller, rows without contribution are not written.  offsets_host = the L+1 level offsets
  * (host memory).  No host synchronisation, static grids (graph-capturable).  Sums are order-nondeterministic in the last bits, like the
  * reference's atomicAdd.  Several times faster than the atomic path at the sizes of the training steps. */
+/* sn_grid_encode_backward_binned on a gradient whose rows are grad_row_stride floats apart ([B, L*C] layout only; 0 = L*C): the gradient of a
+ * wider tensor that carries the grid features in its first L*C columns -- the mask head's MLP input cat([m_grid(x), geo_feat]) of
+ * renderer.py:380 -- is read in place, without the slice copy.  Rows need only 4-byte alignment. */
+int sn_grid_encode_backward_binned_rows(const float *grad, uint32_t grad_row_stride, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
+                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                                        float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                        int layout, void *workspace, size_t workspace_bytes, sn_stream_t stream);
 size_t sn_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, const int32_t *offsets_host);
 int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
@@ -251,7 +258,7 @@ typedef struct sn_mlp_desc {
 /* Kernel selection of sn_rm_render_rays, read from the caller's cfg on every call (ABI <= 6 read process-wide environment variables
  * instead).  All zero = the defaults.  None of these changes WHAT is computed beyond fp32 round-off; the notes say which are bit-neutral. */
 enum { SN_MLP_AUTO = 0, SN_MLP_F16X3 = 1, SN_MLP_MFMA32 = 2, SN_MLP_VALU = 3, SN_MLP_F16X1 = 5 };
-enum { SN_EXP_NONE = 0, SN_EXP_ROLE_SPLIT = 1, SN_EXP_LDS_LEVEL0 = 2 };
+enum { SN_EXP_NONE = 0, SN_EXP_ROLE_SPLIT = 1, SN_EXP_LDS_LEVEL0 = 2, SN_EXP_FINAL_ONE_WG = 3 };
 typedef struct sn_render_tuning {
     int32_t mlp_mode;            /* SN_MLP_AUTO: split-fp16 on the matrix cores unless cfg.mlp_exact_fp32; SN_MLP_F16X3 forces it (overrides the
                                   * range guard); SN_MLP_MFMA32: exact fp32 v_mfma_f32_32x32x2_f32; SN_MLP_VALU: vector-ALU fallback (A/B of the layouts);

@@ -35,7 +35,7 @@ class MlpDesc(C.Structure):
 
 
 MLP_AUTO, MLP_F16X3, MLP_MFMA32, MLP_VALU, MLP_F16X1 = 0, 1, 2, 3, 5              # sn_render_tuning.mlp_mode
-EXP_NONE, EXP_ROLE_SPLIT, EXP_LDS_LEVEL0 = 0, 1, 2                   # sn_render_tuning.experiment (experiments builds only)
+EXP_NONE, EXP_ROLE_SPLIT, EXP_LDS_LEVEL0, EXP_FINAL_ONE_WG = 0, 1, 2, 3                   # sn_render_tuning.experiment (experiments builds only)
 BUILD_EXPERIMENTS, BUILD_POISON_LDS = 1, 2                           # sn_build_flags()
 ADAM_ZERO_GRAD, ADAM_LAZY = 1, 2                                     # sn_adam_step flags
 
@@ -86,6 +86,7 @@ _SIGNATURES = {
     "sn_grid_encode_backward": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _int, _u32, _int, _vp]),
     "sn_grid_backward_binned_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32, _u32, _u32, _vp]),
     "sn_grid_encode_backward_binned": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp, C.c_size_t, _vp]),
+    "sn_grid_encode_backward_binned_rows": (_int, [_vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp, C.c_size_t, _vp]),
     "sn_grad_total_variation": (_int, [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp]),
     "sn_grad_weight_decay": (_int, [_vp, _vp, _vp, _f32, _u32, _u32, _u32, _vp]),
     "sn_sh_encode_forward": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_bin_plan_emit(const uint32_t *
 
 template <uint32_t D, uint32_t C, bool FAST>
 __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ inputs, const float *__restrict__ grad, uint32_t B,
-                                                     GridLevels g, BinGeom bg, int layout, uint32_t *__restrict__ cursor,
+                                                     GridLevels g, BinGeom bg, int layout, uint32_t gstride, uint32_t *__restrict__ cursor,
                                                      const uint32_t *__restrict__ blkbase, uint32_t total_bins,
                                                      uint16_t *__restrict__ ekey, float *__restrict__ econtrib) {
     SN_POISON_ALL();
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const float *__restrict__ i
     for (uint32_t s = 0; s < SPT; ++s) {
         const uint32_t b = blockIdx.x * (256u * SPT) + s * 256u + threadIdx.x;
         float gs[C];
-        if (live[s]) load_row<float, (int)C>(layout == SN_LAYOUT_LBC ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * g.L + level) * C, gs);
+        if (live[s]) load_row<float, (int)C>(layout == SN_LAYOUT_LBC ? grad + ((size_t)level * B + b) * C : grad + (size_t)b * gstride + (size_t)level * C, gs);
         else {
 #pragma unroll
             for (uint32_t c = 0; c < C; ++c) gs[c] = 0.0f;
@@ -528,7 +528,7 @@ __device__ __forceinline__ void store_row(float *dst, const float (&v)[C]) {
 //      row (coarse levels: a bin of 4 rows holds ~1000 entries) folded with wave shuffles and, beyond 64 threads per row, one LDS hop.
 // The phases are device functions shared by the two kernels that feed them: k_bin_accum (entries = products, one item per workgroup) and
 // k_bin_pull (entries = references, persistent workgroups that fetch the next item's operands under the current item's phases).
-struct BinPull { const float *grad; const uint2 *eref; uint32_t B; int layout; };
+struct BinPull { const float *grad; const uint2 *eref; uint32_t B; int layout; uint32_t gstride; };      // gstride: floats between samples' rows ([B, L*C] layout)
 
 __device__ __forceinline__ BinItem bin_item_of(uint32_t i, const BinHdr &h, const BinItem *__restrict__ items, const BinShared *__restrict__ shared_bins, const BinGeom &bg) {
     if (i >= h.n_shared_items) return items[i];
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, SN_BIN_WGS) void k_bin_pull(const BinHdr *__re
         const bool in = ref[j].x != 0xffffffffu;
         const uint32_t b = in ? ref[j].x & ((1u << REF_KEY_SHIFT) - 1u) : 0u;
         key[j] = in ? ref[j].x >> REF_KEY_SHIFT : 0xffffffffu;
-        if (in) load_row<float, (int)C>(pull.layout == SN_LAYOUT_LBC ? pull.grad + ((size_t)level * pull.B + b) * C : pull.grad + ((size_t)b * g.L + level) * C, val[j]);
+        if (in) load_row<float, (int)C>(pull.layout == SN_LAYOUT_LBC ? pull.grad + ((size_t)level * pull.B + b) * C : pull.grad + (size_t)b * pull.gstride + (size_t)level * C, val[j]);
     }
     bin_count_scan<EPT>(end, brows, key, wsum, blockIdx.x, h.n_items);
 #pragma unroll
@@ -864,7 +864,17 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
                                    float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                    int layout, void *workspace, size_t workspace_bytes, sn_stream_t stream) {
+    return sn_grid_encode_backward_binned_rows(grad, 0u, inputs, offsets_host, grad_embeddings, B, D, C, L, max_level, S, H, gridtype, align_corners, interp,
+                                               layout, workspace, workspace_bytes, stream);
+}
+
+int sn_grid_encode_backward_binned_rows(const float *grad, uint32_t grad_row_stride, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
+                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level,
+                                        float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                        int layout, void *workspace, size_t workspace_bytes, sn_stream_t stream) {
     if (B == 0 || max_level == 0) return SN_OK;
+    SN_REQUIRE(grad_row_stride == 0u || (layout == SN_LAYOUT_BLC && grad_row_stride >= L * C), "grid_encode_backward_binned: grad_row_stride %u needs the [B, L*C] layout and >= L*C = %u floats", grad_row_stride, L * C);
+    const uint32_t gstride = grad_row_stride ? grad_row_stride : L * C;
     SN_REQUIRE(grad && inputs && grad_embeddings && workspace, "grid_encode_backward_binned: NULL device pointer");
     SN_REQUIRE(layout == SN_LAYOUT_LBC || layout == SN_LAYOUT_BLC, "grid_encode_backward_binned: bad layout %d", layout);
     if (D != 3 && D != 2) { set_error("grid_encode_backward_binned: D=%u not instantiated (use sn_grid_encode_backward)", D); return SN_ERR_UNSUPPORTED; }
@@ -914,7 +924,7 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
     // a reference holds the sample index in 22 bits
     const bool pull = (g_bin_pull < 0 ? true : g_bin_pull != 0) && C >= 2u && B < (1u << REF_KEY_SHIFT);     // (strictly below: sample 2^22 - 1 in row 1023 of a bin would encode the 'no entry' key 0xffffffff)   // (C >= 2: the references live in the products' region)
     uint2 *eref = reinterpret_cast<uint2 *>(econtrib);
-    const BinPull bp{grad, eref, B, layout};
+    const BinPull bp{grad, eref, B, layout, gstride};
     constexpr size_t refs_lds = (size_t)REF_WINDOW * 2 * sizeof(uint32_t);
     const dim3 blk_refs(REF_THREADS);
 #define SN_BIN_ACC(CC)                                                                                                           \
@@ -934,8 +944,8 @@ int sn_grid_encode_backward_binned(const float *grad, const float *inputs, const
             SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pull<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((k_bin_pull<CC>), ga, blk, lds, st, hdr, items, shared_bins, g, bg, bp, slabs, grad_embeddings);  \
         } else {                                                                                                                 \
-            if (DD == 3 && fast) hipLaunchKernelGGL((k_bin_scatter<DD, CC, DD == 3>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, blkcnt, lay.total_bins, ekey, econtrib); \
-            else hipLaunchKernelGGL((k_bin_scatter<DD, CC, false>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, cursor, blkcnt, lay.total_bins, ekey, econtrib); \
+            if (DD == 3 && fast) hipLaunchKernelGGL((k_bin_scatter<DD, CC, DD == 3>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, gstride, cursor, blkcnt, lay.total_bins, ekey, econtrib); \
+            else hipLaunchKernelGGL((k_bin_scatter<DD, CC, false>), gs, blk, 0, st, inputs, grad, B, g, bg, layout, gstride, cursor, blkcnt, lay.total_bins, ekey, econtrib); \
             SN_BIN_ACC(CC);                                                                                                      \
         }                                                                                                                        \
         hipLaunchKernelGGL((k_bin_merge<CC>), gm, blk, 0, st, hdr, shared_bins, g, bg, slabs, grad_embeddings);                  \

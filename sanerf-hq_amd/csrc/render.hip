@@ -3589,6 +3589,14 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         // (1.953 vs 1.952 ms -- the proposal stages' own early-out, always on, is what takes that render from 3.19 to 1.95 ms) while it costs a
         // semi-transparent scene 0.2-0.3 %; a single-stage schedule gains (6.07 -> 4.43 ms) but its kernel is the bench line's (0.5-1 % cost).
         const bool eo = cfg->tuning.exact_early_out == 2;
+#ifdef SN_EXPERIMENTS
+        // SN_EXP_FINAL_ONE_WG (round 6): the last stage asks for 84 KiB of LDS, so only ONE of its workgroups fits a CU and half of every SIMD's
+        // registers stay free for the proposal-stage workgroups of the OTHER row band (tuning.band_streams): vector-ALU-bound waves beside
+        // texture-bound ones on the same SIMD instead of on different CUs
+        const size_t lds_pad_exp = cfg->tuning.experiment == SN_EXP_FINAL_ONE_WG ? (size_t)(84 * 1024) - (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float) : 0u;
+#else
+        const size_t lds_pad_exp = 0u;
+#endif
         constexpr int VIEW_W = 32 * 32 + 32 * 32 + 3 * 32;     // padded view_mlp rows
         static_assert(VIEW_W <= PACK_FLOATS, "view weights overlay the packed MLP weights");
         const int Kmain = !lv_ok ? -1 : dense_prefix(gl_main);   // the K = 5 instantiations read FinalLv
@@ -3641,7 +3649,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
             // linear tail: layer 3 off the matrix cores (per-sample geometry features are not available in this form)
 #define SN_LAUNCH_FINAL_LT_E(TT_, AUX_, EO_)                                                                                  \
             do {                                                                                                             \
-                const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float);                   \
+                const size_t lds_bytes = (size_t)(PACK_FLOATS + 4 * 2 * 64 * SLAB_STRIDE) * sizeof(float) + lds_pad_exp;     \
                 SN_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, false, EO_>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                  \
                 hipLaunchKernelGGL((k_final_stage<TT_, 16, 2, 64, 64, 16, 32, MLP_F16X3, 5, AUX_, true, false, EO_>), dim3(nblk), dim3(256), lds_bytes, st, fa); \

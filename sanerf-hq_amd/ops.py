@@ -194,10 +194,18 @@ class _grid_encode_cat(Function):
     def backward(ctx, grad):
         inputs, table = ctx.saved_tensors
         offs, B, D, Cc, L, S, H, gridtype, interpolation, align_corners, emb_dtype = ctx.meta
-        g = grad[:, :L * Cc].contiguous().float()
         grad_embeddings = _zeros_f32(table.shape, table.device)                                # grid.py:83
         lib = _lib.lib()
         need = _binned_workspace_bytes(B, D, Cc, L, L, offs, None)
+        if need and grad.is_contiguous() and grad.dtype == torch.float32 and grad.data_ptr() % 16 == 0:
+            # the binned scatter reads the first L*C columns of the [B, L*C + E] gradient in place (no slice copy)
+            ws = _binned_workspace(need, table.device)
+            _lib.check(lib.sn_grid_encode_backward_binned_rows(
+                _lib.dev(grad, "grad"), grad.shape[1], _lib.dev(inputs, "inputs"), _lib.host_i32(offs), _lib.dev(grad_embeddings, "grad_embeddings"),
+                B, D, Cc, L, L, S, H, gridtype, int(align_corners), interpolation, _lib.LAYOUT_BLC,
+                ws.data_ptr(), ws.numel(), _lib.stream()), "grid_encode_backward_binned_rows")
+            return None, grad_embeddings.to(emb_dtype), None, None, None, None, None, None, None
+        g = grad[:, :L * Cc].contiguous().float()
         if need:
             ws = _binned_workspace(need, table.device)
             _lib.check(lib.sn_grid_encode_backward_binned(
