@@ -29,7 +29,7 @@ LIST
 run mask_head "k_mask16|k_mlp_wide|k_final_stage|k_prop_stage" python $root/tools/mask_profile.py mask
 run c3_sam_head "k_feat_stage|k_mlp_wide|k_final_stage" python $root/tools/c3_profile.py
 run train_mask "k_bin_|k_linear_wgrad|k_mlp_wide|k_grid_forward|k_adam" python $root/tools/train_profile.py mask
-run train_rgb "k_mlp_small|k_bin_|k_linear_wgrad|k_grid_forward|k_ray_composite|k_adam" python $root/tools/train_profile.py rgb
+run train_rgb "k_mlp_small|k_bin_|k_linear_wgrad|k_grid_forward|k_ray_composite|k_weights|k_proposal_loss|k_adam" python $root/tools/train_profile.py rgb
 run ref_f16 "k_prop_stage|k_final_stage" python $root/bench.py --steps 2 --warmup 1 --schedule ref --tables f16 --no-cpu-baseline --primary-only
 run flat128_f16 "k_final_stage" python $root/bench.py --steps 2 --warmup 1 --schedule flat128 --tables f16 --no-cpu-baseline --primary-only
 python $root/tools/pmc_kernels_summary.py $out $out/latest_kernel_counters.json > $out/pmc_kernels_summary.txt 2>&1

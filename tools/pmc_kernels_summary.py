@@ -12,17 +12,18 @@ import json
 d0 = sys.argv[1]
 sets = (("pmc_kernels_mask_head.txt", ("k_mask16",)), ("pmc_kernels_c3_sam_head.txt", ("k_feat_stage",)),
         ("pmc_kernels_train_mask.txt", ("k_bin_refs", "k_bin_pull", "k_bin_scatter", "k_bin_accum", "k_linear_wgrad_mfma", "k_mlp_wide", "k_grid_forward")),
-        ("pmc_kernels_train_rgb.txt", ("k_mlp_small", "k_bin_refs", "k_bin_pull", "k_grid_forward", "k_linear_wgrad_mfma", "k_ray_composite")),
+        ("pmc_kernels_train_rgb.txt", ("k_mlp_small<fwd 32-64-64-16>", "k_mlp_small<bwd 16-64-64-32>", "k_mlp_small<fwd 10-16-1>", "k_mlp_small<bwd 1-16-10>",
+                                       "k_bin_refs", "k_bin_pull", "k_grid_forward", "k_linear_wgrad_mfma")),
         ("pmc_kernels_ref_f16.txt", ("k_prop_stage", "k_final_stage")), ("pmc_kernels_flat128_f16.txt", ("k_final_stage",)))
 as_json = {}
-print("workload      kernel               cycles/launch  (ms at 2.3 GHz)  MfmaUtil VALUBusy TA-busy  gather-instr  L1-acc/instr  L2-hit  FETCH_SIZE  WRITE_SIZE")
+print("workload      kernel                       cycles/launch  (ms at 2.3 GHz)  MfmaUtil VALUBusy TA-busy  gather-instr  L1-acc/instr  L2-hit  FETCH_SIZE  WRITE_SIZE")
 for f, ks in sets:
     path = os.path.join(d0, f)
     if not os.path.exists(path):
         continue
     d = {}
     for ln in open(path):
-        m = re.match(r"(.*?)\s+(\S+)\s+dispatches=\s*(\d+) mean=(\S+)", ln)
+        m = re.match(r"(.*?)\s+([A-Za-z_][A-Za-z0-9_]*)\s+dispatches=\s*(\d+) mean=(\S+)", ln)
         if m:
             d[(m.group(1).strip(), m.group(2))] = float(m.group(4))
     names = sorted({n for n, _ in d})
@@ -37,7 +38,7 @@ for f, ks in sets:
             "shader_cycles_per_launch": act, "MfmaUtil_pct": g("MfmaUtil"), "VALUBusy_pct": g("VALUBusy"),
             "TA_busy_pct": g("TA_TA_BUSY_sum") / 256 / act * 100, "L2_hit_pct": hit, "gather_instructions": g("SQ_INSTS_VMEM_RD"),
             "fetch_bytes_gfx950_corrected": 2 * 1024 * g("FETCH_SIZE"), "write_bytes": 1024 * g("WRITE_SIZE")}
-        print(f"{f[12:-4]:13s} {k:20s} {act:13.0f}  {act / 2.3e6:15.3f}  {g('MfmaUtil'):8.1f} {g('VALUBusy'):8.1f} {g('TA_TA_BUSY_sum') / 256 / act * 100:6.1f}%  {g('SQ_INSTS_VMEM_RD'):12.4g}  "
+        print(f"{f[12:-4]:13s} {k:28s} {act:13.0f}  {act / 2.3e6:15.3f}  {g('MfmaUtil'):8.1f} {g('VALUBusy'):8.1f} {g('TA_TA_BUSY_sum') / 256 / act * 100:6.1f}%  {g('SQ_INSTS_VMEM_RD'):12.4g}  "
               f"{g('TCP_TOTAL_CACHE_ACCESSES_sum') / max(g('SQ_INSTS_VMEM_RD'), 1):12.1f}  {hit:5.1f}%  {g('FETCH_SIZE'):10.4g}  {g('WRITE_SIZE'):10.4g}")
 
 if len(sys.argv) > 2:       # second argument: a JSON twin of the table for bench.py (`also.*.roofline.binding`), tied to the kernel sources by their hash

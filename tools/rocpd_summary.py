@@ -11,6 +11,10 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     import re
+    m = re.search(r"k_mlp_small<sn::Chain<(true|false), (\d), ([\d, ]+)>", name)
+    if m:       # the small training perceptrons: direction and the chain's widths (backward chains list the widths reversed)
+        dims = [d.strip() for d in m.group(3).split(",")][: int(m.group(2)) + 1]
+        return f"k_mlp_small<{'bwd' if m.group(1) == 'true' else 'fwd'} {'-'.join(dims)}>"
     for key in ("k_mask16", "k_bin_scatter", "k_bin_accum", "k_bin_count", "k_bin_merge", "k_final_stage_sp", "k_prop_stage_sp", "k_final_stage", "k_prop_stage", "k_feat_stage", "k_linear_wgrad_mfma", "k_linear_wgrad_sum4", "k_pack_grid_mlp_f16", "k_pack_grid_mlp", "k_pack_mlp_wide", "k_mlp_wide",
                 "k_grid_composite", "k_grid_forward", "k_grid_backward", "k_bwd_reduce", "k_bwd_keys",
                 "k_composite", "k_generate_rays", "k_sample_pdf", "k_weights"):
@@ -61,7 +65,8 @@ def pmc(db):
     for r in rows:
         agg[short(r[ki])][r[ci]].append(r[vi])
     for k, cs in agg.items():
-        if not any(t in k for t in ("k_final", "k_prop", "k_pack", "k_mlp_wide", "k_feat", "k_mask16", "k_bin_", "k_linear_wgrad", "k_grid_", "k_adam")):
+        if not any(t in k for t in ("k_final", "k_prop", "k_pack", "k_mlp_wide", "k_feat", "k_mask16", "k_bin_", "k_linear_wgrad", "k_grid_", "k_adam", "k_mlp_small",
+                                    "k_ray_composite", "k_weights", "k_sample", "k_proposal_loss", "k_jitter", "k_zero16")):
             continue
         for c, v in sorted(cs.items()):
             print(f"{k:30s} {c:28s} dispatches={len(v):4d} mean={sum(v) / len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
