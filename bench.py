@@ -356,7 +356,7 @@ def main():
     # ---- N > 1: the gathered image must be the single-process image ON EVERY RANK; the same image on ONE GPU for the ratio; and every
     # ---- rank's own numbers in the line (band time, kernel time, time lost waiting on the all-gather), so that one run explains itself ----
     single = gathered_check = per_rank = None
-    if world > 1:
+    if multi:           # (world > 1, or --force-dist on one GPU: the same code through RCCL at world size 1)
         beat("per-rank statistics")
         mine = torch.tensor([m["local_ms_per_step"], m["median_ms"], m["max_ms"], m["final_ms"] or 0.0,
                              (m["gather"]["gather_wait_ms"] / m["n_steps"]) if m["gather"] else 0.0, m["shader_mhz"], float(n_local)],

@@ -114,3 +114,19 @@ def test_bench_watchdog_names_the_stalled_rank():
                         "--watchdog-seconds", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
     assert "WATCHDOG: rank 0 made no progress" in r.stderr and "init_process_group" in r.stderr
+
+
+def test_bench_force_dist_runs_the_multi_rank_code_through_rccl_at_world_size_one():
+    """bench.py --gpus 1 --force-dist --scaling strong: the N > 1 branch's own code -- RCCL init, the in-place all-gather pipeline (probe included),
+    per-rank statistics, broadcast of the single-GPU image, the check on every rank -- on the one GPU a box has, through the nccl (= RCCL) backend."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--scaling", "strong", "--hw", "512", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--primary-only"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    import json
+    line = json.loads(lines[0])
+    assert line["dist_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["per_rank"]["gather_path"] == "in_place", line["per_rank"]["gather_path"]
+    assert len(line["per_rank"]["band_ms_per_step"]) == 1 and line["per_rank"]["all_gather_wait_ms_per_step"][0] >= 0
+    assert line["gathered_image_check"]["max_abs_diff_per_rank"] == [0.0]
