@@ -390,6 +390,7 @@ int sn_mlp_small_forward_train(const sn_mlp_desc *mlp, const float *x, uint32_t 
                                const float *aux_in, float bg, float *aux_out, sn_stream_t stream) {
     using namespace sn;
     if (int rc = small_check(mlp, "mlp_small_forward_train")) return rc;
+    if (N == 0) return SN_OK;                      // empty batch: nothing to launch, pointers may be NULL
     SN_REQUIRE(x && out, "mlp_small_forward_train: NULL pointer");
     SN_REQUIRE(act >= SN_SMALL_ACT_NONE && act <= SN_SMALL_ACT_SIGMOID_BG, "mlp_small_forward_train: unknown output activation %d", act);
     SN_REQUIRE(act == SN_SMALL_ACT_NONE || aux_out, "mlp_small_forward_train: the activated output needs a destination");
@@ -417,6 +418,7 @@ int sn_mlp_small_backward(const sn_mlp_desc *mlp, const float *grad_out, const f
                           sn_stream_t stream) {
     using namespace sn;
     if (int rc = small_check(mlp, "mlp_small_backward")) return rc;
+    if (N == 0) return SN_OK;
     SN_REQUIRE(act >= SN_SMALL_ACT_NONE && act <= SN_SMALL_ACT_SIGMOID_BG, "mlp_small_backward: unknown output activation %d", act);
     SN_REQUIRE(grad_out || grad_aux, "mlp_small_backward: no incoming gradient");
     SN_REQUIRE(!grad_aux || (act != SN_SMALL_ACT_NONE && out_raw), "mlp_small_backward: grad_aux needs the activation and the forward's raw output");

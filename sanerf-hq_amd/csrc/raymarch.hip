@@ -771,6 +771,7 @@ int sn_rm_sample_positions(const float *rays_o, const float *rays_d, const float
 }
 
 int sn_rm_jitter(const float *uniform, uint32_t N, uint32_t T, int kind, float *out, sn_stream_t stream) {
+    if (N == 0) return SN_OK;
     SN_REQUIRE(out, "jitter: NULL pointer");
     SN_REQUIRE(kind == 0 || kind == 1, "jitter: kind 0 (stage-0 bins) or 1 (sample_pdf u), got %d", kind);
     SN_REQUIRE(T >= 1, "jitter: T >= 1");
@@ -782,8 +783,8 @@ int sn_rm_jitter(const float *uniform, uint32_t N, uint32_t T, int kind, float *
 
 int sn_rm_ray_composite(const float *weights, const float *rays_t, const float *raw, const float *rays_d, uint32_t N, uint32_t T,
                         float *weights_sum, float *depth, float *f_image, sn_stream_t stream) {
-    SN_REQUIRE(weights && rays_t && raw && rays_d && weights_sum && depth && f_image, "ray_composite: NULL pointer");
     if (N == 0) return SN_OK;
+    SN_REQUIRE(weights && rays_t && raw && rays_d && weights_sum && depth && f_image, "ray_composite: NULL pointer");
     hipLaunchKernelGGL(k_ray_composite, dim3(div_up((uint64_t)N * 16u, 256)), dim3(256), 0, (hipStream_t)stream, weights, rays_t, raw, rays_d, N, T,
                        weights_sum, depth, f_image);
     SN_LAUNCH_CHECK("k_ray_composite");
@@ -793,6 +794,7 @@ int sn_rm_ray_composite(const float *weights, const float *rays_t, const float *
 int sn_rm_ray_composite_backward(const float *weights, const float *rays_t, const float *raw, const float *rays_d, const float *grad_weights_sum,
                                  const float *grad_depth, const float *grad_f_image, uint32_t N, uint32_t T, float *grad_weights, float *grad_raw,
                                  sn_stream_t stream) {
+    if (N == 0 || T == 0) return SN_OK;
     SN_REQUIRE(weights && rays_t && raw && rays_d && grad_weights && grad_raw, "ray_composite_backward: NULL pointer");
     SN_REQUIRE(table_aligned(raw) && table_aligned(grad_raw), "ray_composite_backward: raw / grad_raw must be 16-byte aligned");
     if (N == 0 || T == 0) return SN_OK;

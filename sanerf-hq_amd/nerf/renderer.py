@@ -481,9 +481,12 @@ class NeRFRenderer(nn.Module):
             if k == first_stage and first_stage > 0:
                 pass                                            # bins of the last stage came from the fused proposal stages
             elif k == 0:
-                bins = torch.linspace(0, 1, T + 1, device=device).unsqueeze(0).expand(N, -1)
-                if perturb:
-                    bins = (bins + (torch.rand_like(bins) - 0.5) / T).clamp(0, 1)
+                # (the same stage-0 edges as the fused kernels and the fused training route: aten's scalar linspace recipe, sn_rm_jitter)
+                bins = rm.jitter(torch.rand(N, T + 1, device=device) if perturb else None, N, T + 1, 0, device=device) if rays_o.is_cuda else None
+                if bins is None:
+                    bins = torch.linspace(0, 1, T + 1, device=device).unsqueeze(0).expand(N, -1)
+                    if perturb:
+                        bins = (bins + (torch.rand_like(bins) - 0.5) / T).clamp(0, 1)
             else:
                 bins = rm.sample_pdf(bins, weights, T + 1, perturb)
             # bins -> distances, mid-points, (contracted) positions: nothing on this chain is differentiated

@@ -53,11 +53,13 @@ def test_round6_entry_points_validate_their_arguments():
     assert l.sn_mlp_small_forward_train(ctypes.byref(d), dummy, 4, hid, dummy, 1, None, 0.0, None, None) == -1      # activated output without destination
     assert l.sn_mlp_small_forward_train(ctypes.byref(d), dummy, 4, hid, dummy, 7, None, 0.0, dummy, None) == -1
     assert b"unknown output activation" in l.sn_last_error()
+    assert l.sn_mlp_small_forward_train(ctypes.byref(d), None, 0, hid, None, 0, None, 0.0, None, None) == 0           # an empty batch launches nothing
     assert l.sn_mlp_small_backward(ctypes.byref(d), None, None, 0, None, 0.0, hid, 4, None, hid, dummy, None, None) == -1
     assert b"no incoming gradient" in l.sn_last_error()
     d.bias[0] = 16
     assert l.sn_mlp_small_supported(ctypes.byref(d)) == 0
     assert l.sn_rm_jitter(None, 4, 8, 2, dummy, None) == -1 and b"kind" in l.sn_last_error()
+    assert l.sn_rm_jitter(None, 0, 8, 0, None, None) == 0 and l.sn_rm_ray_composite(None, None, None, None, 0, 8, None, None, None, None) == 0
     assert l.sn_zero(ctypes.c_void_p(8), 16, None) == -1
     assert l.sn_rm_sample_positions_ex(dummy, dummy, dummy, dummy, dummy, 4, 8, 1, -1.0, dummy, dummy, dummy, None) == -1
     assert l.sn_rm_ray_composite(None, dummy, dummy, dummy, 4, 8, dummy, dummy, dummy, None) == -1

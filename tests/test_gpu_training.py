@@ -739,3 +739,58 @@ def test_wide_mlp_backward_from_sign_bits_is_bit_identical(gpu, N, din, n_out, l
     assert torch.equal(ya, yb) and torch.equal(gxa, gxb)
     for a_, b_ in zip(gwa, gwb):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("steps", [[64, 32], [32], [48, 24, 16], [128, 64, 32]])
+@pytest.mark.parametrize("N", [1, 77, 1500])
+def test_fused_training_route_other_schedules_and_ray_counts(gpu, steps, N):
+    """The fused training route on other schedules than the reference's default (one, two, three stages; sample counts that are not powers
+    of two) and ray counts that fill neither a wave nor a 64-row matrix tile: image, proposal loss and every gradient against the operator chain.
+    Bounds: two correct fp32 implementations of a RESAMPLING render differ by more than round-off -- a 1e-7 change of a proposal weight moves the
+    next stage's sample positions, and the hash field turns that into ~1e-5 on the weights (measured: single stage 1e-7, [128,64,32] 4e-6,
+    [48,24,16] 9e-6; image 3e-5) -- so the image is held to the north star's 1e-4; and in a batch of a few thousand samples ONE ReLU unit that takes
+    the other branch under a differently ordered sum moves a gradient tensor by ~1e-3 relative (77 rays x 32 samples: 1.1e-3 on the table), so
+    small batches get 5e-3.  A wrong layout or a missing term shows as O(1)."""
+    from sanerf_hq_amd import ops, raymarching as rm, synth
+    from sanerf_hq_amd.nerf import NeRFNetwork
+    opt = make_opt()
+    opt.num_steps = list(steps)
+    opt.lambda_proposal, opt.lambda_distort = 1.0, 0.0
+    H = W = 64
+    roF, rdF = rm.generate_rays(synth.orbit_pose(1.1, 25.0, 60.0), synth.pinhole_intrinsics(H, W), H, W, device=gpu)
+    pix = torch.from_numpy((synth.hash_u01(N, 5) * (H * W)).astype(np.int64)).to(gpu)
+    ro, rd = roF[pix].contiguous(), rdF[pix].contiguous()
+    res = {}
+    for fused in (True, False):
+        model = NeRFNetwork(opt)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_params([128, 64, 32], seed=1).items()}, strict=False)
+        model = model.to(gpu).train()
+        model.fused_training_ops = fused
+        ops.SMALL_MLP_FUSED = fused
+        try:
+            o = model.render(ro, rd, staged=False, bg_color=0.5, perturb=False, update_proposal=True)
+            loss = o["image"].square().mean() + o["proposal_loss"]
+            loss.backward()
+        finally:
+            ops.SMALL_MLP_FUSED = True
+        res[fused] = (o, float(loss), {n: p.grad for n, p in model.named_parameters() if p.grad is not None})
+    (o1, l1, g1), (o0, l0, g0) = res[True], res[False]
+    assert float((o1["image"] - o0["image"]).abs().max()) < 1e-4
+    assert abs(l1 - l0) < 2e-5 * max(1.0, abs(l0))
+    assert set(g1) == set(g0)
+    for n in g0:
+        assert rel(g1[n], g0[n]) < (5e-3 if N < 1000 else 1e-3) or float((g1[n] - g0[n]).abs().max()) < 1e-9, (n, rel(g1[n], g0[n]))
+
+
+def test_training_operators_accept_empty_batches(gpu):
+    """N = 0 through the round-6 entry points: nothing is launched, shapes are right."""
+    from sanerf_hq_amd import ops, raymarching as rm
+    layers = _layers((32, 64, 64, 16), gpu, 1)
+    x = torch.zeros(0, 32, device=gpu, requires_grad=True)
+    raw, sig = ops.small_mlp_train(x, layers, ops.SMALL_ACT_TRUNC_EXP0)
+    assert raw.shape == (0, 16) and sig.shape == (0,)
+    (raw.sum() + sig.sum()).backward()
+    assert x.grad.shape == (0, 32)
+    ws, depth, f = rm.ray_composite(torch.zeros(0, 32, device=gpu), torch.zeros(0, 32, device=gpu), torch.zeros(0, 32, 16, device=gpu), torch.zeros(0, 3, device=gpu))
+    assert ws.shape == (0,) and f.shape == (0, 31)
+    assert rm.jitter(None, 0, 33, 0, device=gpu).shape == (0, 33)
