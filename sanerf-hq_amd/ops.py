@@ -598,6 +598,9 @@ def _wgrad_into(x2, gy2, gw, cache=_small_ws):
     """gw[N,K] = gy2[M,N]^T x2[M,K] through sn_linear_wgrad (fixed summation order)."""
     lib = _lib.lib()
     M, K, N = x2.shape[0], x2.shape[1], gy2.shape[1]
+    if M == 0:                      # an empty batch: the sum over no rows
+        gw.zero_()
+        return
     need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
     if need == 0:
         raise RuntimeError("sn_linear_wgrad: " + lib.sn_last_error().decode())
@@ -660,7 +663,7 @@ class _small_mlp_train(Function):
         rows, dev = x2.shape[0], x2.device
         dout = ws[-1].shape[0]
         go = g_out.reshape(rows, dout).contiguous().float() if g_out is not None else None
-        ga = g_aux.reshape(rows, -1).contiguous().float() if g_aux is not None else None
+        ga = g_aux.reshape(rows, 1 if act == SMALL_ACT_TRUNC_EXP0 else dout).contiguous().float() if g_aux is not None else None
         desc = _small_desc(ws)
         need_x = ctx.needs_input_grad[0]
         gx = torch.empty(rows, x2.shape[1], device=dev, dtype=torch.float32) if need_x else None
