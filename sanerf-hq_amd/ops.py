@@ -781,10 +781,12 @@ class _wide_mlp_train(Function):
                     and not torch.cuda.is_current_stream_capturing()):
                 flag = C.c_int32(0)
                 _lib.check(lib.sn_mlp_wide_overflow(C.byref(flag)), "sn_mlp_wide_overflow")
-                if flag.value:
+                # the flag is process-wide and sticky: an inference call of the head kernels may have raised it since the last read.  It only
+                # counts here when THIS call's own output is not finite (a training run that left the range stays outside it)
+                if flag.value and not bool(torch.isfinite(h).all()):
                     raise RuntimeError(
                         "wide MLP training forward: an activation or input left the fp16 range (|v| >= 65504) of the split-fp16 matrix-core "
-                        "forward during the last %d calls; logits, loss and gradients of those steps are not finite.  Set "
+                        "forward (checked every %d calls); logits, loss and gradients of this step are not finite.  Set "
                         "sanerf_hq_amd.ops.WIDE_MLP_FORWARD_F16X3 = False (fp32 BLAS forward, no range limit) or rescale the inputs."
                         % WIDE_MLP_RANGE_CHECK_EVERY)
         elif WIDE_MLP_FORWARD_NATIVE and x.shape[-1] <= 256 and weights[-1].shape[0] <= 256:

@@ -963,6 +963,11 @@ def test_wide_mlp_training_forward_reports_a_left_fp16_range(gpu):
     ops.WIDE_MLP_RANGE_CHECK_EVERY = 1
     try:
         ops._wide_mlp_train.apply(x, True, *ws)                           # in range: no complaint
+        # a STALE flag (raised by some other call of the head kernels, e.g. an inference render) must not fail an in-range training forward
+        from sanerf_hq_amd.nerf.network import SkipConnMLP
+        with torch.no_grad():
+            rm.mlp_forward(x * 1e6, SkipConnMLP(143, 2, 256, 3, skip_layers=[], bias=False).to(gpu), check_range=False)
+        ops._wide_mlp_train.apply(x, True, *ws)
         with pytest.raises(RuntimeError, match="fp16 range"):
             ops._wide_mlp_train.apply(x * 1e6, True, *ws)
         ops.WIDE_MLP_FORWARD_F16X3 = False
