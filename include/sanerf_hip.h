@@ -287,6 +287,8 @@ typedef struct sn_render_tuning {
                                   * The proposal stages always do (their remaining weights are written as 0 without evaluating the density). */
     int32_t wave_tile;           /* image mode: the 64 lanes of a wave cover 2^w x 2^(6-w) pixels: 0 default (8x8), 1..5 = w (2x32 ... 32x2); bit-neutral
                                   * (A/B of the lines a gather instruction touches: profiles/r05/tile_shape_ab.txt) */
+    int32_t prop_sp_lanes;       /* small linear-order batches, proposal stages: lanes that share a ray: 0 automatic (32: the fastest from 1024 to
+                                  * 32768 rays, profiles/r06/prop_sp_lanes_ab.json), or 8 / 16 / 32 (bit-neutral) */
     int32_t feat_patch;          /* feature stage, dense levels: 1 = a wave fetches the bounding box of its rays' vertices once into LDS and the lanes read their
                                   * corners there (north_star "LDS staging of per-tile grid voxels"; bit-neutral).  0 default = off: measured 3-9 % SLOWER than
                                   * the direct gathers (profiles/r06/feat_patch_ab.json) */

@@ -42,7 +42,7 @@ ADAM_ZERO_GRAD, ADAM_LAZY = 1, 2                                     # sn_adam_s
 
 class RenderTuning(C.Structure):
     _fields_ = [("mlp_mode", C.c_int32), ("per_sample_form", C.c_int32), ("densify", C.c_int32), ("linear_tile_order", C.c_int32),
-                ("prop_sp_max_rays", C.c_int32), ("final_sp_max_rays", C.c_int32), ("feat_levels", C.c_int32), ("band_streams", C.c_int32), ("exact_early_out", C.c_int32), ("wave_tile", C.c_int32), ("feat_patch", C.c_int32), ("experiment", C.c_int32)]
+                ("prop_sp_max_rays", C.c_int32), ("final_sp_max_rays", C.c_int32), ("feat_levels", C.c_int32), ("band_streams", C.c_int32), ("exact_early_out", C.c_int32), ("wave_tile", C.c_int32), ("prop_sp_lanes", C.c_int32), ("feat_patch", C.c_int32), ("experiment", C.c_int32)]
 
 
 class LaunchInfo(C.Structure):

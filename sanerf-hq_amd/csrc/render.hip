@@ -908,23 +908,28 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
 // values parked in LDS (a few adds per sample), and the T_next + 1 resampled bins are found by a binary search
 // per output, 8 outputs at a time.  Same arithmetic, same order where order matters: bit-identical results.
 // Linear ray order only (scratch column = ray index), T <= SP_MAX_T.
-constexpr uint32_t SP_LPR = 8;            // lanes per ray
-constexpr uint32_t SP_MAX_T = 128;        // 3 arrays x 32 rays x (T+4) floats = 50 KiB of static LDS
+// Round 6: the lanes per ray are a template parameter (8, 16 or 32: 32, 16 or 8 rays per workgroup).  With 8 lanes a 4096-ray training batch is
+// 128 workgroups on 256 CUs and every lane walks T/8 = 16 samples one after the other; the launcher now picks the smallest count that gives
+// >= 512 workgroups (4096 rays: 32 lanes, 4 samples per lane).  The serial parts (prefix, cdf) and every sample's arithmetic are unchanged and
+// the fp64 sum of the weights is exact in any order: bit-identical for every choice (sn_render_tuning.prop_sp_lanes forces one).
+constexpr uint32_t SP_MAX_T = 128;        // 3 arrays x (256 / LPR) rays x (T+4) floats: 50 KiB of static LDS at 8 lanes per ray
 constexpr uint32_t SP_STRIDE = SP_MAX_T + 4;   // floats per ray per LDS array
 
-template <typename TT, int L, int C, int HID, int K>
+template <typename TT, int L, int C, int HID, int K, uint32_t SP_LPR = 8>
 __global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
     SN_POISON_ALL();
+    static_assert(SP_LPR == 8 || SP_LPR == 16 || SP_LPR == 32, "a ray's lanes live in one wave");
+    constexpr uint32_t RPB = 256u / SP_LPR;      // rays per workgroup
     constexpr int IN = L * C;
     __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];
     __shared__ __attribute__((aligned(16))) float lds_w1[PadIn<HID>::value];
-    __shared__ float l_bins[32][SP_STRIDE];     // stage bins b_0..b_T of the 32 rays of this workgroup
-    __shared__ float l_ds[32][SP_STRIDE];       // delta*sigma, then reused for the weights
-    __shared__ float l_cum[32][SP_STRIDE];      // (float) of the fp64 exclusive prefix of delta*sigma, then the cdf
+    __shared__ float l_bins[RPB][SP_STRIDE];    // stage bins b_0..b_T of the rays of this workgroup
+    __shared__ float l_ds[RPB][SP_STRIDE];      // delta*sigma, then reused for the weights
+    __shared__ float l_cum[RPB][SP_STRIDE];     // (float) of the fp64 exclusive prefix of delta*sigma, then the cdf
     stage_weights_t<IN, HID>(lds_w0, a.w0);
     stage_weights<HID, 1>(lds_w1, a.w1);
-    const uint32_t tid = threadIdx.x, c = tid & (SP_LPR - 1u), rl = tid >> 3;          // chunk index, local ray
-    const uint32_t n_raw = blockIdx.x * 32u + rl;
+    const uint32_t tid = threadIdx.x, c = tid & (SP_LPR - 1u), rl = tid / SP_LPR;      // chunk index, local ray
+    const uint32_t n_raw = blockIdx.x * RPB + rl;
     const bool ok = n_raw < a.rc.N;
     const uint32_t n = ok ? n_raw : 0u, r = n_raw;                                     // scratch column = ray index (linear order)
     const uint32_t Npad = a.rc.Npad, T = a.T;
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(256, 3) void k_prop_stage_sp(PropArgs a) {
     __syncthreads();                                                                   // weights + bins in LDS
     if (ok && a.dbg_bins) for (uint32_t j = c; j <= T; j += SP_LPR) a.dbg_bins[(size_t)n * (T + 1) + j] = l_bins[rl][j];
 
-    // ---- per-sample work, T/8 consecutive samples per lane ----
+    // ---- per-sample work, T / SP_LPR consecutive samples per lane ----
     const uint32_t spl = (T + SP_LPR - 1u) / SP_LPR;
     const TT *table = reinterpret_cast<const TT *>(a.table);
     for (uint32_t i = 0; i < spl; ++i) {
@@ -3495,17 +3500,27 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 const bool h16 = cfg->prop_grid[k].table_dtype != SN_F32;
                 // few rays in linear order (training batches): 8 lanes per ray instead of one (k_prop_stage_sp)
                 const bool sp = W == 0 && n <= prop_sp_max_rays(cfg) && pa.T <= SP_MAX_T;
-                const uint32_t nblk_sp = Npad / 32u;            // every scratch column, like the one-lane-per-ray launch
+                // lanes per ray of the small-batch kernel: the fewest that still give >= 512 workgroups (tuning.prop_sp_lanes forces 8 / 16 / 32)
+                uint32_t lpr = 32u;      // (measured, profiles/r06/prop_sp_lanes_ab.json: 32 lanes are the fastest from 1024 to 32768 rays)
+                if (cfg->tuning.prop_sp_lanes == 8 || cfg->tuning.prop_sp_lanes == 16 || cfg->tuning.prop_sp_lanes == 32) lpr = (uint32_t)cfg->tuning.prop_sp_lanes;
+                const uint32_t nblk_sp = Npad / (256u / lpr);   // every scratch column, like the one-lane-per-ray launch
+#define SN_LAUNCH_PROP_SP(TT_, KK)                                                                                     \
+                do {                                                                                               \
+                    if (lpr == 8u) hipLaunchKernelGGL((k_prop_stage_sp<TT_, 5, 2, 16, KK, 8>), dim3(nblk_sp), dim3(256), 0, st, pa);        \
+                    else if (lpr == 16u) hipLaunchKernelGGL((k_prop_stage_sp<TT_, 5, 2, 16, KK, 16>), dim3(nblk_sp), dim3(256), 0, st, pa); \
+                    else hipLaunchKernelGGL((k_prop_stage_sp<TT_, 5, 2, 16, KK, 32>), dim3(nblk_sp), dim3(256), 0, st, pa);                 \
+                } while (0)
 #define SN_LAUNCH_PROP(KK)                                                                                         \
                 do {                                                                                               \
-                    if (sp && h16) hipLaunchKernelGGL((k_prop_stage_sp<__half, 5, 2, 16, KK>), dim3(nblk_sp), dim3(256), 0, st, pa); \
-                    else if (sp) hipLaunchKernelGGL((k_prop_stage_sp<float, 5, 2, 16, KK>), dim3(nblk_sp), dim3(256), 0, st, pa);  \
+                    if (sp && h16) SN_LAUNCH_PROP_SP(__half, KK);                                                  \
+                    else if (sp) SN_LAUNCH_PROP_SP(float, KK);                                                     \
                     else if (h16) hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa); \
                     else hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa);     \
                 } while (0)
                 if (K == 3) SN_LAUNCH_PROP(3);          // prop0: res 16, 27, 46 dense (network.py:135)
                 else if (K == 2) SN_LAUNCH_PROP(2);     // prop1: res 16, 32 dense (network.py:140)
                 else SN_LAUNCH_PROP(-1);
+#undef SN_LAUNCH_PROP_SP
 #undef SN_LAUNCH_PROP
             }
             SN_LAUNCH_CHECK("k_prop_stage");
