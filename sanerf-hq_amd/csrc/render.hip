@@ -1572,6 +1572,10 @@ enum { MLP_VALU = 0, MLP_F32 = 1, MLP_F16X3 = 2 };
 #define SN_RS_SPANS_H 6      // role-split producers, fp16 tables: 6 spans like fp32 tables, or 4 spans of 4 levels
 #endif
 #ifndef SN_FINAL_WAVES
+#ifndef SN_FINAL_SP_MIN_BLOCKS
+#define SN_FINAL_SP_MIN_BLOCKS 256u    // the several-lanes-per-ray last stage takes fewer samples per lane until the launch has this many workgroups
+                                       // (round 6, same box: 512 / 1024 are 3-8 % slower from 4096 to 16 384 rays -- one workgroup per CU is this kernel's optimum)
+#endif
 #define SN_FINAL_WAVES 2     // waves per SIMD k_final_stage is compiled for (register budget); experiments only
 #endif
 
@@ -3621,7 +3625,7 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
         if (final_sp) {
             auto lpr_log2_of = [&](uint32_t sl) { const uint32_t need = div_up(fa.T, 1u << sl); uint32_t l2 = 0; while ((1u << l2) < need) ++l2; return l2; };
             uint32_t spl_log2 = 2;
-            while (spl_log2 > 0 && div_up(fa.T, 1u << (spl_log2 - 1)) <= 64u && (((size_t)Npad << lpr_log2_of(spl_log2)) >> 8) < 256u) --spl_log2;
+            while (spl_log2 > 0 && div_up(fa.T, 1u << (spl_log2 - 1)) <= 64u && (((size_t)Npad << lpr_log2_of(spl_log2)) >> 8) < SN_FINAL_SP_MIN_BLOCKS) --spl_log2;
             const uint32_t lpr_log2 = lpr_log2_of(spl_log2);
             const uint32_t blocks = (uint32_t)(((size_t)Npad << lpr_log2) >> 8);
             const size_t lds_bytes = final_sp_lds_floats(1u << spl_log2) * sizeof(float);
