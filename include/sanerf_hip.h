@@ -30,7 +30,7 @@ extern "C" {
 #define SN_MAX_LEVELS 32
 #define SN_MAX_LAYERS 8
 #define SN_MAX_STAGES 4
-#define SN_ABI_VERSION 11
+#define SN_ABI_VERSION 12
 
 typedef void *sn_stream_t; /* hipStream_t */
 
@@ -292,6 +292,8 @@ typedef struct sn_render_tuning {
     int32_t feat_patch;          /* feature stage, dense levels: 1 = a wave fetches the bounding box of its rays' vertices once into LDS and the lanes read their
                                   * corners there (north_star "LDS staging of per-tile grid voxels"; bit-neutral).  0 default = off: measured 3-9 % SLOWER than
                                   * the direct gathers (profiles/r06/feat_patch_ab.json) */
+    int32_t prop_pair;           /* proposal stages (one lane per ray): a lane evaluates TWO consecutive samples at once -- their gathers and MLP chains interleave
+                                  * (k_prop_stage<..., UN = 2>, 3 waves per SIMD instead of 5; bit-neutral): 0 automatic, 1 never, 2 always */
     int32_t experiment;          /* SN_EXP_*: variants that were built, verified bit-identical and measured SLOWER; honoured only by
                                   * a library built with -DSN_EXPERIMENTS (sn_build_flags), SN_ERR_UNSUPPORTED otherwise */
 } sn_render_tuning;

@@ -42,7 +42,7 @@ ADAM_ZERO_GRAD, ADAM_LAZY = 1, 2                                     # sn_adam_s
 
 class RenderTuning(C.Structure):
     _fields_ = [("mlp_mode", C.c_int32), ("per_sample_form", C.c_int32), ("densify", C.c_int32), ("linear_tile_order", C.c_int32),
-                ("prop_sp_max_rays", C.c_int32), ("final_sp_max_rays", C.c_int32), ("feat_levels", C.c_int32), ("band_streams", C.c_int32), ("exact_early_out", C.c_int32), ("wave_tile", C.c_int32), ("prop_sp_lanes", C.c_int32), ("feat_patch", C.c_int32), ("experiment", C.c_int32)]
+                ("prop_sp_max_rays", C.c_int32), ("final_sp_max_rays", C.c_int32), ("feat_levels", C.c_int32), ("band_streams", C.c_int32), ("exact_early_out", C.c_int32), ("wave_tile", C.c_int32), ("prop_sp_lanes", C.c_int32), ("feat_patch", C.c_int32), ("prop_pair", C.c_int32), ("experiment", C.c_int32)]
 
 
 class LaunchInfo(C.Structure):
@@ -73,7 +73,7 @@ class RenderIO(C.Structure):
 
 
 _u32, _f32, _i32, _vp, _int = C.c_uint32, C.c_float, C.c_int32, C.c_void_p, C.c_int
-ABI_VERSION = 11  # include/sanerf_hip.h: SN_ABI_VERSION
+ABI_VERSION = 12  # include/sanerf_hip.h: SN_ABI_VERSION
 
 _SIGNATURES = {
     "sn_abi_version": (_int, []),

@@ -585,6 +585,49 @@ __device__ __forceinline__ void encode_levels(const T *__restrict__ table, const
     for (int i = 0; i < L * C; ++i) feat[i] = oob ? 0.0f : feat[i];
 }
 
+// U positions of one lane through the same grid at once: every level group issues the gathers of all U positions before the
+// first blend, so a wave carries U independent gather -> blend chains (the proposal stage is bound by the length of that chain,
+// not by an execution unit).  Values identical to U calls of encode_levels.
+template <typename T, int L, int C, int K, bool PAIRX, int GROUP, int U>
+__device__ __forceinline__ void encode_levels_multi(const T *__restrict__ table, const GridLevels &g, const float (&x01)[U][3],
+                                                    float (&feat)[U][L * C], const PairTab *pt = nullptr) {
+    constexpr int G = GROUP >= L ? L : GROUP;
+    static_for<0, (L + G - 1) / G>([&](auto grp) {
+        constexpr int l0 = decltype(grp)::value * G;
+        constexpr int GN = (L - l0) < G ? (L - l0) : G;
+        float pos[U][GN][3];
+        Corner<T, C> cv[U][GN][8];
+        static_for<0, U>([&](auto uu) {
+            constexpr int u = decltype(uu)::value;
+            static_for<0, GN>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                constexpr int KIND = K < 0 ? -1 : ((l0 + k) < K ? 0 : 1);
+                issue_level<T, C, KIND, (PAIRX && K > 0 && K <= 8)>(table, g, l0 + k, x01[u], pos[u][k], cv[u][k], pt);
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < GN; ++k) {
+                float acc[C];
+                blend_level<T, C>(pos[u][k], cv[u][k], acc);
+#pragma unroll
+                for (int c = 0; c < C; ++c) feat[u][(l0 + k) * C + c] = acc[c];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) oob |= (x01[u][d] < 0.0f || x01[u][d] > 1.0f);
+#pragma unroll
+        for (int i = 0; i < L * C; ++i) feat[u][i] = oob ? 0.0f : feat[u][i];
+    }
+}
+
 // y = act(W x), W [OUT][IN] row-major at a wave-uniform address (SGPR / scalar-cache loads);
 // each output is one k-ascending fmaf chain (the oracle's order).
 template <int IN, int OUT, int ACT>
@@ -627,21 +670,38 @@ __device__ __forceinline__ void stage_weights_t(float *__restrict__ dst, const f
 // y = act(W x), W k-major in LDS at a wave-uniform address (broadcast ds_read_b128 of 4 adjacent outputs);
 // every output is still ONE k-ascending fmaf chain starting from 0 (the oracle's order), the chains of
 // adjacent outputs just advance together, which lets the compiler use packed fp32 FMAs without shuffles.
-template <int IN, int OUT, int ACT>
+// PIN: the weights of input k+1 are fetched under the FMAs of input k and never earlier -- their address carries a fake dependence on the
+// accumulators of step k-1 (an empty asm).  In a register-hungry caller the scheduler otherwise fetches all IN * OUT weights ahead (160 registers).
+template <int IN, int OUT, int ACT, bool PIN = false>
 __device__ __forceinline__ void dense_ldsw_t(const float *__restrict__ Wl, const float (&x)[IN], float (&y)[OUT]) {
     constexpr int OUTP = PadIn<OUT>::value;
     float acc[OUTP];
 #pragma unroll
     for (int o = 0; o < OUTP; ++o) acc[o] = 0.0f;
+    uint32_t z = 0;
+    float4 w[2][OUTP / 4];
+    if (PIN) {
+#pragma unroll
+        for (int o4 = 0; o4 < OUTP / 4; ++o4) w[0][o4] = *reinterpret_cast<const float4 *>(Wl + 4 * o4);
+    }
 #pragma unroll
     for (int k = 0; k < IN; ++k) {
 #pragma unroll
         for (int o4 = 0; o4 < OUTP / 4; ++o4) {
-            const float4 w = *reinterpret_cast<const float4 *>(Wl + k * OUTP + 4 * o4);
-            acc[4 * o4 + 0] = __builtin_fmaf(w.x, x[k], acc[4 * o4 + 0]);
-            acc[4 * o4 + 1] = __builtin_fmaf(w.y, x[k], acc[4 * o4 + 1]);
-            acc[4 * o4 + 2] = __builtin_fmaf(w.z, x[k], acc[4 * o4 + 2]);
-            acc[4 * o4 + 3] = __builtin_fmaf(w.w, x[k], acc[4 * o4 + 3]);
+            const float4 wk = PIN ? w[k & 1][o4] : *reinterpret_cast<const float4 *>(Wl + k * OUTP + 4 * o4);
+            if (PIN && o4 == 0 && k + 1 < IN) {
+                static_assert(!PIN || OUTP == 16, "the fake dependence lists 16 accumulators");
+                // (all accumulators as they stand after step k-1: the fetch of step k+1 cannot start before step k-1 is complete)
+                asm volatile("" : "+v"(z) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]),
+                                            "v"(acc[8 % OUTP]), "v"(acc[9 % OUTP]), "v"(acc[10 % OUTP]), "v"(acc[11 % OUTP]), "v"(acc[12 % OUTP]), "v"(acc[13 % OUTP]),
+                                            "v"(acc[14 % OUTP]), "v"(acc[15 % OUTP]));
+#pragma unroll
+                for (int q = 0; q < OUTP / 4; ++q) w[(k + 1) & 1][q] = *reinterpret_cast<const float4 *>(Wl + z + (k + 1) * OUTP + 4 * q);
+            }
+            acc[4 * o4 + 0] = __builtin_fmaf(wk.x, x[k], acc[4 * o4 + 0]);
+            acc[4 * o4 + 1] = __builtin_fmaf(wk.y, x[k], acc[4 * o4 + 1]);
+            acc[4 * o4 + 2] = __builtin_fmaf(wk.z, x[k], acc[4 * o4 + 2]);
+            acc[4 * o4 + 3] = __builtin_fmaf(wk.w, x[k], acc[4 * o4 + 3]);
         }
     }
 #pragma unroll
@@ -754,8 +814,16 @@ __device__ __forceinline__ bool ray_misses(const RayCommon &rc, const RaySetup &
 #define SN_PROP_WAVES 5      // waves per SIMD the proposal stage is compiled for (register budget 512 / N in steps of 8: 96 VGPRs); the
                              // stage is bound by each wave's dependent chain, so a fifth wave buys 3-4 % (profiles/r02/ab_round2_experiments.txt)
 #endif
-template <typename TT, int L, int C, int HID, int K>
-__global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
+#ifndef SN_PROP_GROUP_U2
+#define SN_PROP_GROUP_U2 1   // levels per gather group of the two-samples-at-once instantiation (x 2 positions)
+#endif
+#ifndef SN_PROP_WAVES_U2
+#define SN_PROP_WAVES_U2 3   // the two-samples-at-once instantiation (UN = 2): 168 VGPRs
+#endif
+// UN: samples of a ray evaluated together in pass 1 (their gathers and their MLP chains interleave: two dependent chains per wave instead of
+// one).  Every sample goes through the same arithmetic and the weights / the normaliser are formed in the same order: bit-identical to UN = 1.
+template <typename TT, int L, int C, int HID, int K, int UN = 1>
+__global__ __launch_bounds__(256, (UN == 1 ? SN_PROP_WAVES : SN_PROP_WAVES_U2)) void k_prop_stage(PropArgs a) {
     SN_POISON_ALL();
     constexpr int IN = L * C;
     __shared__ __attribute__((aligned(16))) float lds_w0[IN * PadIn<HID>::value];   // k-major [IN][HID]
@@ -788,47 +856,70 @@ __global__ __launch_bounds__(256, SN_PROP_WAVES) void k_prop_stage(PropArgs a) {
     if (ok && a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1)] = bprev;
     double cum = 0.0, wacc = 0.0;
     const TT *table = reinterpret_cast<const TT *>(a.table);
-    for (uint32_t j = 0; j < T; ++j) {
-        const float bnext = bin_at(j + 1);
-        const float rb_next = real_bin(rs, bnext);
-        const float tmid = (rb_next + rb_prev) / 2.0f;
-        float p[3], x01[3];
-        sample_x01(a.rc, rs, tmid, p, x01);
-        float feat[L * C];
-        encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : SN_PROP_GROUP_H)>(table, a.g, x01, feat, &a.pairs);
-        float raw[1];
-        {
-            float h[HID];
+    const bool early_out = !a.dbg_bins && !a.dbg_sigma && !a.dbg_w;
+    // samples j .. j+U-1; returns true once the transmittance of all 64 rays of the wave has underflowed to exactly 0
+    auto march = [&](auto un_tag, uint32_t j) -> bool {
+        constexpr int U = decltype(un_tag)::value;
+        float bnext[U], rb_next[U], x01[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bnext[u] = bin_at(j + (uint32_t)u + 1u);
+            rb_next[u] = real_bin(rs, bnext[u]);
+            const float tmid = (rb_next[u] + (u ? rb_next[u ? u - 1 : 0] : rb_prev)) / 2.0f;
+            float p[3];
+            sample_x01(a.rc, rs, tmid, p, x01[u]);
+        }
+        float feat[U][L * C], raw[U];
+        if constexpr (U == 1) encode_levels<TT, L, C, K, true, (sizeof(TT) == 4 ? SN_PROP_GROUP : SN_PROP_GROUP_H)>(table, a.g, x01[0], feat[0], &a.pairs);
+        else encode_levels_multi<TT, L, C, K, true, SN_PROP_GROUP_U2, U>(table, a.g, x01, feat, &a.pairs);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float h[HID], r1[1];
             const uint32_t oz = opaque_zero();
-            dense_ldsw_t<IN, HID, 1>(lds_w0 + oz, feat, h);
-            dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, raw);
+            dense_ldsw_t<IN, HID, 1, (U > 1)>(lds_w0 + oz, feat[u], h);
+            dense_ldsw<HID, 1, 0>(lds_w1 + oz, h, r1);
+            raw[u] = r1[0];
         }
-        const float sigma = expf_det(raw[0]);                // trunc_exp forward (activation.py:9)
-        const float delta = rb_next - rb_prev;
-        float ds = delta * sigma;
-        if (a.rc.last_opaque && j == T - 1u) ds = __builtin_inff();
-        const float alpha = 1.0f - expf_det(-ds);
-        const float tr = expf_det(-(float)cum);
-        float w = alpha * tr;
-        if (w != w) w = 0.0f;
-        a.w_scr[(size_t)j * Npad + r] = w;
-        cum += (double)ds;
-        wacc += (double)(w + 0.01f);
-        if (ok) {
-            if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + j + 1] = bnext;
-            if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + j] = sigma;
-            if (a.dbg_w) a.dbg_w[(size_t)n * T + j] = w;
-        }
-        rb_prev = rb_next;
-        // EXACT early-out (round 4): once the transmittance of all 64 rays of the wave has underflowed to exactly 0 it stays 0 (the optical
-        // depth never decreases), so every later weight is alpha * 0 = 0 whatever the density: the remaining samples are not evaluated, their
-        // weights are written as 0 and the pdf normaliser keeps taking its (0 + 0.01) terms in the same order.  Opaque scenes only; bit-identical.
-        if (!a.dbg_bins && !a.dbg_sigma && !a.dbg_w && __all(tr == 0.0f)) {
-            for (uint32_t jj = j + 1u; jj < T; ++jj) {
-                a.w_scr[(size_t)jj * Npad + r] = 0.0f;
-                wacc += (double)(0.0f + 0.01f);
+        bool dark = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t ju = j + (uint32_t)u;
+            const float rbp = u ? rb_next[u ? u - 1 : 0] : rb_prev;
+            const float sigma = expf_det(raw[u]);                // trunc_exp forward (activation.py:9)
+            const float delta = rb_next[u] - rbp;
+            float ds = delta * sigma;
+            if (a.rc.last_opaque && ju == T - 1u) ds = __builtin_inff();
+            const float alpha = 1.0f - expf_det(-ds);
+            const float tr = expf_det(-(float)cum);
+            float w = alpha * tr;
+            if (w != w) w = 0.0f;
+            a.w_scr[(size_t)ju * Npad + r] = w;
+            cum += (double)ds;
+            wacc += (double)(w + 0.01f);
+            if (ok) {
+                if (a.dbg_bins) a.dbg_bins[(size_t)n * (T + 1) + ju + 1] = bnext[u];
+                if (a.dbg_sigma) a.dbg_sigma[(size_t)n * T + ju] = sigma;
+                if (a.dbg_w) a.dbg_w[(size_t)n * T + ju] = w;
             }
-            break;
+            // EXACT early-out (round 4): once the transmittance of all 64 rays of the wave has underflowed to exactly 0 it stays 0 (the optical
+            // depth never decreases), so every later weight is alpha * 0 = 0 whatever the density: the remaining samples are not evaluated, their
+            // weights are written as 0 and the pdf normaliser keeps taking its (0 + 0.01) terms in the same order.  Opaque scenes only; bit-identical.
+            // (with U > 1 the samples of the group that follow the underflow are still evaluated: their weights come out as the same zeros)
+            if (u == U - 1) dark = early_out && __all(tr == 0.0f);
+        }
+        rb_prev = rb_next[U - 1];
+        return dark;
+    };
+    {
+        uint32_t j = 0;
+        bool dark = false;
+        if constexpr (UN > 1) {
+            for (; j + (uint32_t)UN <= T && !dark; j += (uint32_t)UN) dark = march(std::integral_constant<int, UN>{}, j);
+        }
+        for (; j < T && !dark; ++j) dark = march(std::integral_constant<int, 1>{}, j);
+        for (; j < T; ++j) {                                   // (only after an early-out)
+            a.w_scr[(size_t)j * Npad + r] = 0.0f;
+            wacc += (double)(0.0f + 0.01f);
         }
     }
 
@@ -3009,6 +3100,12 @@ static uint32_t prop_sp_max_rays(const sn_render_cfg *cfg) {
     return v == 0 ? 32768u : v < 0 ? 0u : (uint32_t)v;        // tools/prop_sp_ab.py: faster up to 32k rays, slower from 64k
 }
 
+// Two samples per lane at once in the proposal stages (bit-neutral): pays where the launch leaves the SIMDs short of waves.
+// Measured (profiles/r06/prop_pair_ab.json, [128,64,32], proposal stages only): a wave alone on its SIMD issues one vector instruction per
+// ~7 cycles whatever its instruction-level parallelism, so the gain is what the interleaved gathers hide -- 64-256 workgroups -11 %,
+// 361 -7 %, 484 -4 %, 625 +-1 %, 1406 and more +5 ... +17 % (3 waves per SIMD instead of 5).
+static bool prop_pair_auto(uint32_t workgroups_in_flight) { return workgroups_in_flight <= 512u; }
+
 static uint32_t final_sp_max_rays(const sn_render_cfg *cfg) {
     const int32_t v = cfg->tuning.final_sp_max_rays;
     return v == 0 ? 16384u : v < 0 ? 0u : (uint32_t)v;
@@ -3508,6 +3605,9 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 uint32_t lpr = 32u;      // (measured, profiles/r06/prop_sp_lanes_ab.json: 32 lanes are the fastest from 1024 to 32768 rays)
                 if (cfg->tuning.prop_sp_lanes == 8 || cfg->tuning.prop_sp_lanes == 16 || cfg->tuning.prop_sp_lanes == 32) lpr = (uint32_t)cfg->tuning.prop_sp_lanes;
                 const uint32_t nblk_sp = Npad / (256u / lpr);   // every scratch column, like the one-lane-per-ray launch
+                // two samples of a ray at once (k_prop_stage<..., UN = 2>): tuning.prop_pair 2 = always, 1 = never, 0 = automatic
+                const bool pair = cfg->tuning.prop_pair == 2 ||
+                                  (cfg->tuning.prop_pair == 0 && prop_pair_auto(fork.side ? blocks_for(io->N, W, tile_log2w(cfg)) : nblk));   // (two bands run side by side)
 #define SN_LAUNCH_PROP_SP(TT_, KK)                                                                                     \
                 do {                                                                                               \
                     if (lpr == 8u) hipLaunchKernelGGL((k_prop_stage_sp<TT_, 5, 2, 16, KK, 8>), dim3(nblk_sp), dim3(256), 0, st, pa);        \
@@ -3518,6 +3618,8 @@ int sn_rm_render_rays(const sn_render_cfg *cfg, const sn_render_io *io, sn_strea
                 do {                                                                                               \
                     if (sp && h16) SN_LAUNCH_PROP_SP(__half, KK);                                                  \
                     else if (sp) SN_LAUNCH_PROP_SP(float, KK);                                                     \
+                    else if (h16 && pair) hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16, KK, 2>), dim3(nblk), dim3(256), 0, st, pa); \
+                    else if (pair) hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16, KK, 2>), dim3(nblk), dim3(256), 0, st, pa); \
                     else if (h16) hipLaunchKernelGGL((k_prop_stage<__half, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa); \
                     else hipLaunchKernelGGL((k_prop_stage<float, 5, 2, 16, KK>), dim3(nblk), dim3(256), 0, st, pa);     \
                 } while (0)

@@ -44,8 +44,9 @@ class Tuning:
         wave_tile          image mode: a wave covers 2^w x 2^(6-w) pixels (0 default = 8x8; 1..5)
         prop_sp_lanes      small linear-order batches: lanes sharing a ray in the proposal stages (0 automatic; 8 / 16 / 32; bit-neutral)
         feat_patch         feature stage: 1 = per-wave LDS patch of the dense levels (bit-neutral; measured 3-9 % slower, so 0 = off is the default)
+        prop_pair          proposal stages: a lane evaluates two consecutive samples at once (bit-neutral): 0 automatic, 1 never, 2 always
         experiment         _lib.EXP_*: measured-and-rejected variants, experiments builds only (SN_LIB=.../libsanerf_hip_exp.so)"""
-    FIELDS = ("mlp_mode", "per_sample_form", "densify", "linear_tile_order", "prop_sp_max_rays", "final_sp_max_rays", "feat_levels", "band_streams", "exact_early_out", "wave_tile", "prop_sp_lanes", "feat_patch", "experiment")
+    FIELDS = ("mlp_mode", "per_sample_form", "densify", "linear_tile_order", "prop_sp_max_rays", "final_sp_max_rays", "feat_levels", "band_streams", "exact_early_out", "wave_tile", "prop_sp_lanes", "feat_patch", "prop_pair", "experiment")
 
     def __init__(self, **kw):
         for f in self.FIELDS:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sanerf_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names, "ctypes signature table out of sync with the header"
-    assert lib.sn_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.sn_abi_version() == _lib.ABI_VERSION == 12
     assert lib.sn_build_flags() == 0, "the product library carries neither the experiment kernels nor the LDS poisoning"
 
 

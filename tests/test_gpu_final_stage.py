@@ -443,6 +443,38 @@ def test_opaque_field_vs_oracle_with_early_outs(gpu, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("steps,f16,gain", [([128, 64, 32], False, 4.0), ([128, 64, 32], True, 4.0), ([33, 17, 8], False, 4.0), ([64, 32], True, 40.0),
+                                            ([127, 64, 32], False, 40.0)])
+def test_two_samples_per_lane_in_the_proposal_stages_are_bit_identical(gpu, orc, steps, f16, gain):
+    """tuning.prop_pair = 2 (k_prop_stage<..., UN = 2>: a lane evaluates two consecutive samples at once, their gathers and MLP chains interleave)
+    against prop_pair = 1: every per-stage tensor (bins, weights, densities, resampled indices) and the image bit for bit -- on even and odd
+    sample counts (the odd one's last sample goes through the one-sample body), on a semi-transparent and on an opaque field (gain 40: the
+    exact early-out leaves in the middle of a pair), with and without the per-stage tensors (which switch the early-out off), in image
+    order and in linear order beyond the small-batch kernels' range; and the indices still equal the oracle's."""
+    from sanerf_hq_amd import raymarching as rm
+    params = synthetic_params(steps, seed=5, gain=gain)
+    model = product_model(params, steps, False, gpu)
+    H, W = 40, 72
+    _, _, ro, rd = camera_rays(orc, H, W, radius=1.0, elev=20.0, azim=30.0)
+    plan = rm.RenderPlan(model, steps, torch.float16 if f16 else torch.float32)
+    want = ("bins", "weights", "sigmas", "inds")
+    for tile_w, kw in ((W, {}), (0, {"tuning_extra": {"prop_sp_max_rays": -1}})):
+        extra = kw.get("tuning_extra", {})
+        one = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=tile_w, want=want, tuning=rm.Tuning(prop_pair=1, **extra), out={}).items()}
+        two = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=tile_w, want=want, tuning=rm.Tuning(prop_pair=2, **extra), out={})
+        assert set(one) == set(two)
+        for k in one:
+            assert torch.equal(one[k], two[k]), (k, tile_w)
+        plain1 = {k: v.clone() for k, v in rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=tile_w, tuning=rm.Tuning(prop_pair=1, **extra), out={}).items()}
+        plain2 = rm.render_rays(plan, T(ro, gpu), T(rd, gpu), tile_w=tile_w, tuning=rm.Tuning(prop_pair=2, **extra), out={})
+        for k in plain1:
+            assert torch.equal(plain1[k], plain2[k]), (k, tile_w, "early-out active")
+    ref = orc.render(oracle_cfg(orc, params, steps, table_f16=f16), ro, rd, debug=True)
+    for k in range(1, len(steps)):
+        assert np.array_equal(two[f"inds{k}"].cpu().numpy(), ref[f"inds{k}"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bands", [3, 4, 7])
 def test_more_than_two_row_bands_are_bit_identical(gpu, bands):
     """tuning.band_streams = K > 2: K row bands dealt alternately to the two HIP streams (measured slower than two bands, kept as an A/B switch):
