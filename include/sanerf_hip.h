@@ -277,7 +277,7 @@ typedef struct sn_render_tuning {
     int32_t band_streams;        /* image mode, schedules with proposal stages: the image is rendered as two row bands whose kernels go to TWO HIP streams
                                   * (the caller's and a library-owned one, forked and joined with events inside the call: capturable), so that
                                   * the vector-ALU-bound proposal stages of one band overlap the texture-path-bound last stage of the other
-                                  * (bit-neutral): 0 automatic (>= 2048 workgroups: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 fp16;
+                                  * (bit-neutral): 0 automatic (>= 768 workgroups: 800x800 [128,64,32] 4.36 -> 4.07 ms fp32, 3.85 -> 3.71 fp16; 448x448 2.10 -> 2.00, 1.88 -> 1.74;
                                   * >= 512 with the feature stage: 400x400 + SAM head 3.00 -> 2.82 ms), 1 never, 2 whenever the image has two bands
                                   * of whole tile rows, K > 2: K bands dealt alternately to the two streams (measured, profiles/r05/band_count_ab.txt: two bands
                                   * are the optimum at 400 / 800 / 1600 pixels -- 800x800 fp16: 3.84 none, 3.59 two, 4.18 four; 1600x1600: 13.36, 12.71, 12.70) */

@@ -3158,9 +3158,11 @@ static BandPlan band_plan(const sn_render_cfg *cfg, uint32_t N, uint32_t W) {
     p.slots = 1;
     const int mode = cfg ? cfg->tuning.band_streams : 1;
     if (mode == 1 || W == 0 || !cfg || cfg->num_stages < 2 || N % W != 0) return p;
-    // automatic: from 2048 workgroups (800x800); with the in-render feature stage -- a fourth kernel, bound by the texture path alone -- from 512
-    // (400x400 + SAM-feature head, BASELINE configs[2]: 3.00 -> 2.82 ms, 2.58 -> 2.41 with fp16 tables; without it 400x400 gains nothing)
-    if (mode == 0 && blocks_for(N, W, tile_log2w(cfg)) < (cfg->with_feat ? 512u : 2048u)) return p;
+    // automatic: from 768 workgroups; with the in-render feature stage -- a fourth kernel, bound by the texture path alone -- from 512
+    // (400x400 + SAM-feature head, BASELINE configs[2]: 3.00 -> 2.82 ms, 2.58 -> 2.41 with fp16 tables).  Without it (profiles/r06/band_small_ab.json,
+    // fp32 / fp16 tables): 361 workgroups -2 / -4 %, 484 -0 / -3 %, 625 (400x400) +0.5 / -2 %, 784 -5 / -8 %, 1024 -6 / -9 %, 1444 -4 / -7 %, 2500 -7 / -4 %:
+    // the last stage holds 512 workgroups at a time, and a band's share of a partly filled last round overlaps the other band's proposal stages.
+    if (mode == 0 && blocks_for(N, W, tile_log2w(cfg)) < (cfg->with_feat ? 512u : 768u)) return p;
     const uint32_t rows = N / W;
     const uint32_t nbands = mode > 2 ? (uint32_t)mode : 2u;              // band_streams = K > 2: K bands, dealt alternately to the two streams (A/B; measured: see DESIGN section 7)
     const uint32_t half_rows = (((rows + nbands - 1u) / nbands + 15u) / 16u) * 16u;   // whole 16-row tile rows; the first bands take the odd ones
