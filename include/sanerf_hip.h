@@ -166,7 +166,8 @@ int sn_rm_sample_pdf(const float *bins, const float *weights, uint32_t N, uint32
 int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32_t N, uint32_t T,
                              int last_sample_opaque, float *weights, sn_stream_t stream);
 /* Backward of sn_rm_weights_from_sigma w.r.t. sigmas (what autograd derives from renderer.py:308-325; the bin edges
- * carry no gradient on this path).  grad_weights [N,T] -> grad_sigmas [N,T]; T <= 256. */
+ * carry no gradient on this path).  grad_weights [N,T] -> grad_sigmas [N,T]; any T <= 131072 (T <= 256: one pass in registers; longer rays keep
+ * the fp64 prefix of every 64-sample segment and evaluate the terms again on the way back -- the same bits). */
 int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigmas, const float *grad_weights, uint32_t N, uint32_t T,
                                       int last_sample_opaque, float *grad_sigmas, sn_stream_t stream);
 
@@ -223,6 +224,14 @@ int sn_rm_ray_composite_backward(const float *weights, const float *rays_t, cons
  * incoming (device-resident) gradient scalar without extra elementwise passes. */
 int sn_rm_proposal_loss_scaled(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
                                uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, sn_stream_t stream);
+
+/* The same for ANY number of samples per ray (T, Tr <= 512 run exactly sn_rm_proposal_loss_scaled's launch and need no workspace; longer rays keep
+ * their prefix sums and search tables in `workspace` -- 8-byte aligned, sn_rm_proposal_loss_workspace_bytes(N, T, Tr, backward) bytes, at most
+ * 64 MiB -- and a wave walks several rays: the same operations in the same order, the same bits). */
+size_t sn_rm_proposal_loss_workspace_bytes(uint32_t N, uint32_t T, uint32_t Tr, int backward);
+int sn_rm_proposal_loss_long(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                             uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, void *workspace,
+                             size_t workspace_bytes, sn_stream_t stream);
 
 /* Clears `bytes` bytes at `ptr` (both multiples of 16) with a kernel on `stream` -- capturable in a HIP graph, unlike a memset node whose
  * replays faulted once the allocator had reused the memory (round 4); the zeros_like of gridencoder/grid.py:83. */

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "sn_rm_ray_composite": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "sn_rm_ray_composite_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_proposal_loss_scaled": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp]),
+    "sn_rm_proposal_loss_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32, _int]),
+    "sn_rm_proposal_loss_long": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_zero": (_int, [_vp, C.c_size_t, _vp]),
     "sn_mlp_small_supported": (_int, [C.POINTER(MlpDesc)]),
     "sn_mlp_small_forward_train": (_int, [C.POINTER(MlpDesc), _vp, _u32, _vp, _vp, _i32, _vp, _f32, _vp, _vp]),

@@ -282,26 +282,25 @@ __global__ __launch_bounds__(256) void k_sample_pdf_wave(const float *__restrict
 // the opaque last sample (ds = inf) is a constant (torch: cat([ds[:-1], inf])), NaN weights pass no gradient
 // (nan_to_num).  One wave per ray: lane l owns samples l, l+64, ...; the prefix of ds (fp64) and the suffix of g*w are
 // wave scans carried from one 64-sample segment to the next.
+// T <= 256 (LONG = false): the per-lane terms of all four segments stay in registers between the sweeps.  LONG: any T -- the forward sweep keeps only
+// the fp64 prefix at the start of every segment (LDS, one double per segment and wave), the backward sweep evaluates a segment's terms again
+// from it: the same operations on the same values, so both instantiations give the same bits.
+template <bool LONG>
 __global__ __launch_bounds__(256) void k_weights_backward(const float *__restrict__ real_bins, const float *__restrict__ sigmas,
                                                           const float *__restrict__ grad_w, uint32_t N, uint32_t T, int last_opaque,
                                                           float *__restrict__ grad_sigmas) {
     SN_POISON_ALL();
+    extern __shared__ __attribute__((aligned(8))) double wb_lds[];      // LONG: [4 waves][segments] prefix of ds at the segment's start
     const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (n >= N) return;
+    if (n >= N) return;                                                 // (no workgroup barrier below)
     const float *rb = real_bins + (size_t)n * (T + 1);
     const float *sg = sigmas + (size_t)n * T;
     const float *gw = grad_w + (size_t)n * T;
     float *gs = grad_sigmas + (size_t)n * T;
-    constexpr uint32_t MAXSEG = 4;                      // T <= 256; loops fully unrolled so the per-lane arrays stay in registers
+    constexpr uint32_t MAXSEG = 4;                      // !LONG: T <= 256; loops fully unrolled so the per-lane arrays stay in registers
     const uint32_t nseg = (T + 63u) / 64u;
-    float gwv[MAXSEG];                                  // g_j * w_j of this lane's samples
-    float dterm[MAXSEG], delta[MAXSEG];
-    // ---- forward sweep: prefix of ds -> T_j, w_j ----
-    double carry = 0.0;
-#pragma unroll
-    for (uint32_t s = 0; s < MAXSEG; ++s) {
-        gwv[s] = dterm[s] = delta[s] = 0.0f;
-        if (s >= nseg) continue;
+    // terms of segment s given the prefix of ds before it; returns the segment's sum of ds (the scan's last lane)
+    auto segment = [&](uint32_t s, double carry, float &gwv, float &dterm, float &delta) -> double {
         const uint32_t j = s * 64u + lane;
         const bool live = j < T;
         const float d = live ? rb[j + 1] - rb[j] : 0.0f;
@@ -311,29 +310,58 @@ __global__ __launch_bounds__(256) void k_weights_backward(const float *__restric
 #pragma unroll
         for (uint32_t k = 1; k < 64u; k <<= 1) { const double v = __shfl_up(incl, k); if (lane >= k) incl += v; }
         const double excl = carry + incl - ((live && !opaque) ? (double)ds : 0.0);
-        carry += __shfl(incl, 63);
+        const double total = __shfl(incl, 63);
         if (opaque) ds = __builtin_inff();
         const float tr = expf_det(-(float)excl);
         const float e = expf_det(-ds);
         const float w = (1.0f - e) * tr;
         const bool bad = w != w;
         const float g = live ? gw[j] : 0.0f;
-        gwv[s] = (live && !bad) ? g * w : 0.0f;
-        dterm[s] = (live && !bad && !opaque) ? g * e * tr : 0.0f;
-        delta[s] = (live && !opaque) ? d : 0.0f;
-    }
-    // ---- backward sweep: suffix of g*w ----
-    float tail = 0.0f;                                  // sum over later segments
-#pragma unroll
-    for (int s = (int)MAXSEG - 1; s >= 0; --s) {
-        if ((uint32_t)s >= nseg) continue;
-        float incl = gwv[s];
+        gwv = (live && !bad) ? g * w : 0.0f;
+        dterm = (live && !bad && !opaque) ? g * e * tr : 0.0f;
+        delta = (live && !opaque) ? d : 0.0f;
+        return total;
+    };
+    // suffix of g*w inside a segment + the later segments' sum; writes the segment's gradients
+    auto finish = [&](uint32_t s, float gwv, float dterm, float delta, float &tail) {
+        float incl = gwv;
 #pragma unroll
         for (uint32_t k = 1; k < 64u; k <<= 1) { const float v = __shfl_down(incl, k); if (lane + k < 64u) incl += v; }
-        const float after = tail + incl - gwv[s];       // strictly later samples
+        const float after = tail + incl - gwv;          // strictly later samples
         tail += __shfl(incl, 0);
-        const uint32_t j = (uint32_t)s * 64u + lane;
-        if (j < T) gs[j] = delta[s] * (dterm[s] - after);
+        const uint32_t j = s * 64u + lane;
+        if (j < T) gs[j] = delta * (dterm - after);
+    };
+    if constexpr (!LONG) {
+        float gwv[MAXSEG], dterm[MAXSEG], delta[MAXSEG];
+        double carry = 0.0;
+#pragma unroll
+        for (uint32_t s = 0; s < MAXSEG; ++s) {
+            gwv[s] = dterm[s] = delta[s] = 0.0f;
+            if (s >= nseg) continue;
+            carry += segment(s, carry, gwv[s], dterm[s], delta[s]);
+        }
+        float tail = 0.0f;                              // sum over later segments
+#pragma unroll
+        for (int s = (int)MAXSEG - 1; s >= 0; --s) {
+            if ((uint32_t)s >= nseg) continue;
+            finish((uint32_t)s, gwv[s], dterm[s], delta[s], tail);
+        }
+    } else {
+        double *pre = wb_lds + (size_t)(threadIdx.x >> 6) * nseg;
+        double carry = 0.0;
+        for (uint32_t s = 0; s < nseg; ++s) {
+            float a, b, c;
+            if (lane == 0u) pre[s] = carry;
+            carry += segment(s, carry, a, b, c);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float tail = 0.0f;
+        for (uint32_t s = nseg; s-- > 0u;) {
+            float gwv, dterm, delta;
+            segment(s, pre[s], gwv, dterm, delta);
+            finish(s, gwv, dterm, delta, tail);
+        }
     }
 }
 
@@ -490,22 +518,26 @@ __global__ __launch_bounds__(256) void k_zero16(uint4 *__restrict__ p, size_t n1
 // contain a given i form one contiguous range [ja, jb]:  dL/dw_i = G[jb+1] - G[ja] with G the prefix sum of
 // g_j = -2 max(rw_j - bound_j, 0) / (rw_j + 1e-8)  -- two binary searches per i, no atomics (deterministic).
 // The reference's own proposal bins/weights of the final stage (rb, rw) are detached there too.
-template <bool BACKWARD>
+// LONG (T or Tr beyond what four waves' LDS holds): the per-wave arrays live in a workspace in memory and a wave walks rays n, n + waves, ...;
+// the same operations in the same order, so both instantiations give the same bits.
+template <bool BACKWARD, bool LONG>
 __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__ bins, const float *__restrict__ weights,
                                                        const float *__restrict__ ref_bins, const float *__restrict__ ref_w,
                                                        uint32_t N, uint32_t T, uint32_t Tr, float scale, const float *__restrict__ scale_dev,
-                                                       float *__restrict__ out) {
+                                                       float *__restrict__ out, double *__restrict__ workspace) {
     SN_POISON_ALL();
     extern __shared__ __attribute__((aligned(8))) double pl_lds[];
     const float sc = scale_dev ? scale * scale_dev[0] : scale;      // (scale 1 and no device factor: the plain value / gradient, exact)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t n_raw = blockIdx.x * 4u + wave;
+    // lanes of a wave exchange values through the arrays: LDS operations of a wave execute in order; in memory (LONG) the writes are fenced first
+    auto wsync = [&]() { if constexpr (LONG) __threadfence_block(); __builtin_amdgcn_wave_barrier(); };
+  for (uint32_t n_raw = blockIdx.x * 4u + wave; LONG ? n_raw < N : true; n_raw += gridDim.x * 4u) {
     const uint32_t n = n_raw < N ? n_raw : N - 1u;           // spare waves redo the last ray and store nothing
     // per wave: cum[T+1] (fp64: bound = cum[hi+1] - cum[lo] cancels), G[Tr+1] (fp64, backward), then the fp32 / int arrays
     const uint32_t nd = (T + 1u) + (BACKWARD ? Tr + 1u : 0u);
     const uint32_t nf = (T + 1u) + (BACKWARD ? 3u * Tr : 0u);
     const uint32_t per_wave_d = nd + (nf + 1u) / 2u;         // in doubles
-    double *cum = pl_lds + (size_t)wave * per_wave_d, *G = cum + (T + 1u);
+    double *cum = (LONG ? workspace + (size_t)blockIdx.x * 4u * per_wave_d : pl_lds) + (size_t)wave * per_wave_d, *G = cum + (T + 1u);
     float *b = reinterpret_cast<float *>(cum + nd);
     float *g = b + (T + 1u);
     int32_t *lo_s = reinterpret_cast<int32_t *>(g + Tr), *hi_s = lo_s + Tr;
@@ -514,7 +546,7 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
     const float *rw = ref_w + (size_t)n * Tr;
     for (uint32_t i = lane; i <= T; i += 64u) b[i] = bins[(size_t)n * (T + 1) + i];
     for (uint32_t i = lane; i < T; i += 64u) cum[i + 1u] = (double)w[i];
-    __builtin_amdgcn_wave_barrier();
+    wsync();
     {
         double acc = 0.0;
         for (uint32_t i = 0; i < T; ++i) {                   // every lane, same order; lane 0 writes the prefixes back
@@ -524,7 +556,7 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
         }
         if (lane == 0u) cum[0] = 0.0;
     }
-    __builtin_amdgcn_wave_barrier();
+    wsync();
     auto upper = [&](const float *a, uint32_t len, float v) {   // number of a[0..len) <= v
         uint32_t lo = 0u, hi = len;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1u; else hi = mid; }
@@ -548,14 +580,14 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
         for (int k = 32; k >= 1; k >>= 1) part += __shfl_xor(part, k);
         if (lane == 0u && n_raw < N) out[n] = part * sc;
     } else {
-        __builtin_amdgcn_wave_barrier();
+        wsync();
         double acc = 0.0;
         for (uint32_t j = 0; j < Tr; ++j) {
             if (lane == 0u) G[j] = acc;
             acc += (double)g[j];
         }
         if (lane == 0u) G[Tr] = acc;
-        __builtin_amdgcn_wave_barrier();
+        wsync();
         if (n_raw >= N) return;
         for (uint32_t i = lane; i < T; i += 64u) {
             uint32_t a0 = 0u, a1 = Tr;                       // ja = first j with hi_j >= i
@@ -565,6 +597,9 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
             out[(size_t)n * T + i] = (c0 > a0 ? (float)(G[c0] - G[a0]) : 0.0f) * sc;
         }
     }
+    if constexpr (!LONG) break;
+    wsync();                                                 // LONG: the next ray reuses the arrays
+  }
 }
 
 // Distortion loss of Mip-NeRF 360 on the final stage's normalised bins (nerf/renderer.py:17-27; the reference calls the
@@ -573,26 +608,43 @@ __global__ __launch_bounds__(256) void k_proposal_loss(const float *__restrict__
 // i.e. sum_ij w_i w_j |m_i - m_j| for sorted bins).  One wave per ray, lane k owns samples k, k+64, ...: the inner sum
 // S_k = sum_j w_j |m_k - m_j| is evaluated directly (T terms per sample, no prefix-sum cancellation), which gives the
 // value and the gradient at once:  loss_ray = (1/3) sum_k w_k^2 d_k + sum_k w_k S_k,  dloss_ray/dw_k = (2/3) w_k d_k + 2 S_k.
+// LONG (T beyond what four waves' LDS holds): weights and mid-points come from memory in the inner loop (wave-uniform addresses) -- the same
+// arithmetic in the same order, so both instantiations give the same bits.
+template <bool LONG>
 __global__ __launch_bounds__(256) void k_distort_loss(const float *__restrict__ bins, const float *__restrict__ weights, uint32_t N,
                                                       uint32_t T, float *__restrict__ loss_per_ray, float *__restrict__ grad_w) {
     SN_POISON_ALL();
-    extern __shared__ float dl_lds[];                    // per wave: w[T] | m[T]
+    extern __shared__ float dl_lds[];                    // per wave: w[T] | m[T]   (LONG: unused)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_raw = blockIdx.x * 4u + wave;
     const uint32_t n = n_raw < N ? n_raw : N - 1u;
     float *w = dl_lds + (size_t)wave * 2u * T, *m = w + T;
     const float *b = bins + (size_t)n * (T + 1);
-    for (uint32_t i = lane; i < T; i += 64u) {
-        const float b0 = b[i], d = b[i + 1u] - b0;
-        w[i] = weights[(size_t)n * T + i];
-        m[i] = b0 + d / 2.0f;
+    const float *wg = weights + (size_t)n * T;
+    if constexpr (!LONG) {
+        for (uint32_t i = lane; i < T; i += 64u) {
+            const float b0 = b[i], d = b[i + 1u] - b0;
+            w[i] = wg[i];
+            m[i] = b0 + d / 2.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
     float part = 0.0f;
     for (uint32_t k = lane; k < T; k += 64u) {
-        const float mk = m[k], wk = w[k], dk = b[k + 1u] - b[k];
+        const float dk = b[k + 1u] - b[k];
+        const float mk = LONG ? b[k] + dk / 2.0f : m[k], wk = LONG ? wg[k] : w[k];
         float S = 0.0f;
-        for (uint32_t j = 0; j < T; ++j) S = __builtin_fmaf(w[j], fabsf(mk - m[j]), S);
+        if constexpr (LONG) {
+            float bj = b[0];
+            for (uint32_t j = 0; j < T; ++j) {
+                const float bn = b[j + 1u];
+                const float mj = bj + (bn - bj) / 2.0f;
+                S = __builtin_fmaf(wg[j], fabsf(mk - mj), S);
+                bj = bn;
+            }
+        } else {
+            for (uint32_t j = 0; j < T; ++j) S = __builtin_fmaf(w[j], fabsf(mk - m[j]), S);
+        }
         part += wk * wk * dk / 3.0f + wk * S;
         if (n_raw < N) grad_w[(size_t)n * T + k] = 2.0f * wk * dk / 3.0f + 2.0f * S;
     }
@@ -746,10 +798,14 @@ int sn_rm_weights_from_sigma(const float *real_bins, const float *sigmas, uint32
 int sn_rm_weights_from_sigma_backward(const float *real_bins, const float *sigmas, const float *grad_weights, uint32_t N, uint32_t T,
                                       int last_sample_opaque, float *grad_sigmas, sn_stream_t stream) {
     SN_REQUIRE(real_bins && sigmas && grad_weights && grad_sigmas, "weights_from_sigma_backward: NULL pointer");
-    SN_REQUIRE(T <= 256, "weights_from_sigma_backward: at most 256 samples per ray (got %u)", T);
     if (N == 0 || T == 0) return SN_OK;
-    hipLaunchKernelGGL(k_weights_backward, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, grad_weights, N, T,
-                       last_sample_opaque, grad_sigmas);
+    SN_REQUIRE(T <= 131072u, "weights_from_sigma_backward: at most 131072 samples per ray (got %u)", T);
+    if (T <= 256u)           // the per-lane terms of the four segments in registers
+        hipLaunchKernelGGL(k_weights_backward<false>, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, real_bins, sigmas, grad_weights, N, T,
+                           last_sample_opaque, grad_sigmas);
+    else                     // any length: segment prefixes in LDS, the terms evaluated again on the way back (same bits)
+        hipLaunchKernelGGL(k_weights_backward<true>, dim3(div_up(N, 4)), dim3(256), (size_t)4 * div_up(T, 64) * sizeof(double), (hipStream_t)stream,
+                           real_bins, sigmas, grad_weights, N, T, last_sample_opaque, grad_sigmas);
     SN_LAUNCH_CHECK("k_weights_backward");
     return SN_OK;
 }
@@ -816,26 +872,55 @@ int sn_zero(void *ptr, size_t bytes, sn_stream_t stream) {
     return SN_OK;
 }
 
-int sn_rm_proposal_loss_scaled(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
-                               uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, sn_stream_t stream) {
+// bytes one wave's arrays take (mirrors the carve-up in k_proposal_loss)
+static size_t proposal_wave_bytes(uint32_t T, uint32_t Tr, bool backward) {
+    const size_t nd = (size_t)(T + 1) + (backward ? (size_t)Tr + 1 : 0), nf = (size_t)(T + 1) + (backward ? 3 * (size_t)Tr : 0);
+    return (nd + (nf + 1) / 2) * sizeof(double);
+}
+// workgroups of the long-ray launch: every wave of it owns a set of arrays in the workspace; at most 64 MiB of it, at least one workgroup
+static uint32_t proposal_long_blocks(uint32_t N, uint32_t T, uint32_t Tr, bool backward) {
+    const size_t per_block = 4 * proposal_wave_bytes(T, Tr, backward);
+    size_t blocks = ((size_t)64 << 20) / per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    const uint32_t need = div_up(N, 4);
+    return need < blocks ? need : (uint32_t)blocks;
+}
+
+size_t sn_rm_proposal_loss_workspace_bytes(uint32_t N, uint32_t T, uint32_t Tr, int backward) {
+    if (N == 0 || (T <= 512u && Tr <= 512u)) return 0;
+    return (size_t)proposal_long_blocks(N, T, Tr, backward != 0) * 4 * proposal_wave_bytes(T, Tr, backward != 0);
+}
+
+int sn_rm_proposal_loss_long(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                             uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, void *workspace,
+                             size_t workspace_bytes, sn_stream_t stream) {
     SN_REQUIRE(bins && weights && ref_bins && ref_weights, "proposal_loss: NULL pointer");
     SN_REQUIRE((loss_per_ray != nullptr) != (grad_weights != nullptr), "proposal_loss: pass exactly one of loss_per_ray (forward) / grad_weights (backward)");
-    SN_REQUIRE(T >= 1 && Tr >= 1 && T <= 512 && Tr <= 512, "proposal_loss: 1..512 samples per ray (got %u, %u)", T, Tr);
+    SN_REQUIRE(T >= 1 && Tr >= 1 && T <= (1u << 24) && Tr <= (1u << 24), "proposal_loss: 1..2^24 samples per ray (got %u, %u)", T, Tr);
     if (N == 0) return SN_OK;
     hipStream_t st = (hipStream_t)stream;
-    auto lds_bytes = [&](bool backward) {        // mirrors the carve-up in k_proposal_loss
-        const size_t nd = (T + 1) + (backward ? Tr + 1 : 0), nf = (T + 1) + (backward ? 3 * (size_t)Tr : 0);
-        return (size_t)4 * (nd + (nf + 1) / 2) * sizeof(double);
-    };
-    if (loss_per_ray) {
-        const size_t lds = lds_bytes(false);
-        hipLaunchKernelGGL(k_proposal_loss<false>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, loss_per_ray);
-    } else {
-        const size_t lds = lds_bytes(true);
-        hipLaunchKernelGGL(k_proposal_loss<true>, dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, grad_weights);
+    const bool backward = grad_weights != nullptr;
+    if (T <= 512u && Tr <= 512u) {               // a ray's arrays in LDS, four rays per workgroup
+        const size_t lds = 4 * proposal_wave_bytes(T, Tr, backward);
+        if (!backward) hipLaunchKernelGGL((k_proposal_loss<false, false>), dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, loss_per_ray, (double *)nullptr);
+        else hipLaunchKernelGGL((k_proposal_loss<true, false>), dim3(div_up(N, 4)), dim3(256), lds, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, grad_weights, (double *)nullptr);
+    } else {                                     // any length: the arrays in the caller's workspace, waves walk the rays
+        const size_t need = sn_rm_proposal_loss_workspace_bytes(N, T, Tr, backward);
+        SN_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 7u) == 0,
+                   "proposal_loss: %u / %u samples per ray need an 8-byte aligned workspace of %zu bytes (sn_rm_proposal_loss_workspace_bytes), got %zu", T, Tr, need, workspace_bytes);
+        const uint32_t blocks = proposal_long_blocks(N, T, Tr, backward);
+        if (!backward) hipLaunchKernelGGL((k_proposal_loss<false, true>), dim3(blocks), dim3(256), 0, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, loss_per_ray, (double *)workspace);
+        else hipLaunchKernelGGL((k_proposal_loss<true, true>), dim3(blocks), dim3(256), 0, st, bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, grad_weights, (double *)workspace);
     }
     SN_LAUNCH_CHECK("k_proposal_loss");
     return SN_OK;
+}
+
+int sn_rm_proposal_loss_scaled(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
+                               uint32_t Tr, float scale, const float *scale_dev, float *loss_per_ray, float *grad_weights, sn_stream_t stream) {
+    SN_REQUIRE(T <= 512 && Tr <= 512, "proposal_loss: more than 512 samples per ray (got %u, %u) take a workspace: sn_rm_proposal_loss_long", T, Tr);
+    return sn_rm_proposal_loss_long(bins, weights, ref_bins, ref_weights, N, T, Tr, scale, scale_dev, loss_per_ray, grad_weights, nullptr, 0, stream);
 }
 
 int sn_rm_proposal_loss(const float *bins, const float *weights, const float *ref_bins, const float *ref_weights, uint32_t N, uint32_t T,
@@ -846,10 +931,13 @@ int sn_rm_proposal_loss(const float *bins, const float *weights, const float *re
 int sn_rm_distort_loss(const float *bins, const float *weights, uint32_t N, uint32_t T, float *loss_per_ray, float *grad_weights,
                        sn_stream_t stream) {
     SN_REQUIRE(bins && weights && loss_per_ray && grad_weights, "distort_loss: NULL pointer");
-    SN_REQUIRE(T >= 1 && T <= 2048, "distort_loss: 1..2048 samples per ray (got %u)", T);
+    SN_REQUIRE(T >= 1, "distort_loss: at least one sample per ray (got %u)", T);
     if (N == 0) return SN_OK;
-    hipLaunchKernelGGL(k_distort_loss, dim3(div_up(N, 4)), dim3(256), (size_t)4 * 2 * T * sizeof(float), (hipStream_t)stream, bins, weights, N, T,
-                       loss_per_ray, grad_weights);
+    if (T <= 2048u)          // a ray's weights and mid-points in LDS (four waves: 64 KiB at T = 2048)
+        hipLaunchKernelGGL(k_distort_loss<false>, dim3(div_up(N, 4)), dim3(256), (size_t)4 * 2 * T * sizeof(float), (hipStream_t)stream, bins, weights, N, T,
+                           loss_per_ray, grad_weights);
+    else                     // any length: the inner loop reads them from memory (same arithmetic, same bits)
+        hipLaunchKernelGGL(k_distort_loss<true>, dim3(div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, bins, weights, N, T, loss_per_ray, grad_weights);
     SN_LAUNCH_CHECK("k_distort_loss");
     return SN_OK;
 }

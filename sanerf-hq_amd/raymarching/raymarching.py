@@ -197,13 +197,14 @@ class _weights_from_sigma(Function):
         return None, gs, None
 
 
-WEIGHTS_BACKWARD_MAX_T = 256      # sn_rm_weights_from_sigma_backward keeps a ray's samples in one wave's registers
+WEIGHTS_BACKWARD_MAX_T = 131072   # sn_rm_weights_from_sigma_backward: any ray the product meets (up to 256 samples in one wave's registers, beyond that the
+                                  # segment prefixes in LDS); the torch statement below is what the tests compare the kernel with (they lower this constant)
 
 
 def weights_from_sigma(real_bins, sigmas, last_sample_opaque: bool = True):
-    """real_bins [N,T+1], sigmas [N,T] -> weights [N,T]; under autograd the gradient reaches `sigmas` (T <= 256)."""
+    """real_bins [N,T+1], sigmas [N,T] -> weights [N,T]; under autograd the gradient reaches `sigmas`."""
     if torch.is_grad_enabled() and sigmas.requires_grad:
-        if sigmas.shape[-1] > WEIGHTS_BACKWARD_MAX_T:       # longer rays than the backward kernel holds: torch's own chain
+        if sigmas.shape[-1] > WEIGHTS_BACKWARD_MAX_T:       # (renderer.py:308-325 as torch states it: the tests' comparison route)
             ds = (real_bins[..., 1:] - real_bins[..., :-1]).detach() * sigmas
             if last_sample_opaque:
                 ds = torch.cat([ds[..., :-1], torch.full_like(ds[..., -1:], torch.inf)], dim=-1)
@@ -295,6 +296,20 @@ def ray_composite(weights, rays_t, raw, rays_d):
     return _ray_composite.apply(weights, rays_t, raw, rays_d)
 
 
+def _proposal_loss_launch(bins, w, ref_bins, ref_w, scale, scale_dev, per_ray_ptr, grad_ptr, what):
+    """One stage, one direction (sn_rm_proposal_loss_long): up to 512 samples per ray the arrays of a ray sit in LDS; longer rays get a
+    workspace (at most 64 MiB) -- the same kernel arithmetic either way, nothing falls back to torch."""
+    N, T, Tr = w.shape[0], w.shape[1], ref_w.shape[1]
+    lib = _lib.lib()
+    nbytes = int(lib.sn_rm_proposal_loss_workspace_bytes(N, T, Tr, 0 if grad_ptr is None else 1))
+    ws = torch.empty((nbytes + 7) // 8, device=w.device, dtype=torch.float64) if nbytes else None
+    _lib.check(lib.sn_rm_proposal_loss_long(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), _lib.dev(ref_bins, "ref_bins"), _lib.dev(ref_w, "ref_weights"),
+                                            N, T, Tr, float(scale), scale_dev, per_ray_ptr, grad_ptr, ws.data_ptr() if ws is not None else None,
+                                            nbytes, _lib.stream()), what)
+    if ws is not None:
+        ws.record_stream(torch.cuda.current_stream(w.device))
+
+
 class _proposal_loss_all(Function):
     """The whole inter-level proposal loss (nerf/renderer.py:30-57) as one autograd node: one kernel per proposal stage forward and backward,
     the mean's 1 / (N Tr) and the incoming gradient scalar applied inside the kernels (sn_rm_proposal_loss_scaled)."""
@@ -309,9 +324,7 @@ class _proposal_loss_all(Function):
         per_ray = torch.empty(S, N, device=ref_w.device, dtype=torch.float32)
         scale = 1.0 / float(N * Tr)
         for k in range(S):
-            _lib.check(_lib.lib().sn_rm_proposal_loss_scaled(_lib.dev(bins[k], "bins"), _lib.dev(ws[k], "weights"), _lib.dev(ref_bins, "ref_bins"),
-                                                             _lib.dev(ref_w, "ref_weights"), N, ws[k].shape[1], Tr, scale, None,
-                                                             per_ray[k].data_ptr(), None, _lib.stream()), "proposal_loss")
+            _proposal_loss_launch(bins[k], ws[k], ref_bins, ref_w, scale, None, per_ray[k].data_ptr(), None, "proposal_loss")
         ctx.save_for_backward(ref_bins, ref_w, *bins, *ws)
         ctx.S = S
         return per_ray.sum()
@@ -328,9 +341,7 @@ class _proposal_loss_all(Function):
         out = []
         for k in range(S):
             gw = torch.empty_like(ws[k])
-            _lib.check(_lib.lib().sn_rm_proposal_loss_scaled(_lib.dev(bins[k], "bins"), _lib.dev(ws[k], "weights"), _lib.dev(ref_bins, "ref_bins"),
-                                                             _lib.dev(ref_w, "ref_weights"), N, ws[k].shape[1], Tr, scale, _lib.dev(g, "grad_out"),
-                                                             None, _lib.dev(gw, "grad_weights"), _lib.stream()), "proposal_loss_backward")
+            _proposal_loss_launch(bins[k], ws[k], ref_bins, ref_w, scale, _lib.dev(g, "grad_out"), None, _lib.dev(gw, "grad_weights"), "proposal_loss_backward")
             out.append(gw)
         return (None, None) + (None,) * S + tuple(out)
 
@@ -363,9 +374,7 @@ class _proposal_loss_stage(Function):
         N, T = w.shape
         Tr = ref_w.shape[1]
         per_ray = torch.empty(N, device=w.device, dtype=torch.float32)
-        _lib.check(_lib.lib().sn_rm_proposal_loss(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), _lib.dev(ref_bins, "ref_bins"),
-                                                  _lib.dev(ref_w, "ref_weights"), N, T, Tr, _lib.dev(per_ray, "loss_per_ray"), None,
-                                                  _lib.stream()), "proposal_loss")
+        _proposal_loss_launch(bins, w, ref_bins, ref_w, 1.0, None, _lib.dev(per_ray, "loss_per_ray"), None, "proposal_loss")
         ctx.save_for_backward(bins, w, ref_bins, ref_w)
         return per_ray.sum() / float(N * Tr)
 
@@ -375,13 +384,12 @@ class _proposal_loss_stage(Function):
         N, T = w.shape
         Tr = ref_w.shape[1]
         gw = torch.empty_like(w)
-        _lib.check(_lib.lib().sn_rm_proposal_loss(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), _lib.dev(ref_bins, "ref_bins"),
-                                                  _lib.dev(ref_w, "ref_weights"), N, T, Tr, None, _lib.dev(gw, "grad_weights"),
-                                                  _lib.stream()), "proposal_loss_backward")
+        _proposal_loss_launch(bins, w, ref_bins, ref_w, 1.0, None, None, _lib.dev(gw, "grad_weights"), "proposal_loss_backward")
         return None, gw * (grad_out / float(N * Tr)), None, None      # no host sync: the scale stays a device scalar
 
 
-PROPOSAL_LOSS_MAX_T = 512
+PROPOSAL_LOSS_MAX_T = 1 << 24       # the kernels take any ray (up to 512 samples in LDS, beyond that in a workspace); nerf/renderer.py keeps the torch statement
+                                    # for CPU tensors and the tests' comparison (they lower this constant)
 
 
 def proposal_loss_stage(bins, weights, ref_bins, ref_weights):
@@ -413,7 +421,7 @@ class _distort_loss(Function):
         return None, gw * (grad_out / float(ctx.n))
 
 
-DISTORT_LOSS_MAX_T = 2048
+DISTORT_LOSS_MAX_T = 1 << 24        # any ray (up to 2048 samples in LDS, beyond that read in place); as above
 
 
 def distort_loss(bins, weights):

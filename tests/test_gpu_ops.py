@@ -275,13 +275,15 @@ def test_sample_pdf_large_random(gpu, orc):
     assert np.array_equal(got_i.cpu().numpy(), want_i) and np.array_equal(got_b.cpu().numpy(), want_b)
 
 
-@pytest.mark.parametrize("T_,opaque", [(1, True), (33, True), (64, False), (128, True), (200, False), (256, True), (300, True)])
+@pytest.mark.parametrize("T_,opaque", [(1, True), (33, True), (64, False), (128, True), (200, False), (256, True), (257, False), (300, True), (1000, True),
+                                       (4097, False)])
 def test_weights_from_sigma_autograd(gpu, orc, T_, opaque):
     """The autograd form of weights_from_sigma against torch's own derivative of renderer.py:308-325 evaluated in fp64
-    (delta*sigma -> alpha, exclusive cumsum -> transmittance, product, nan_to_num)."""
+    (delta*sigma -> alpha, exclusive cumsum -> transmittance, product, nan_to_num).  Rays of more than 256 samples take the backward kernel's
+    long-ray instantiation (segment prefixes in LDS, terms evaluated again on the way back): no torch route at any length."""
     from sanerf_hq_amd import raymarching as rm
     rng = np.random.default_rng(7 + T_)
-    N = 777
+    N = 777 if T_ <= 1000 else 131
     rb = np.sort(rng.uniform(0.2, 30, (N, T_ + 1)), axis=1).astype(np.float32)
     sg = np.exp(rng.uniform(-6, 3, (N, T_))).astype(np.float32)
     go = rng.standard_normal((N, T_)).astype(np.float32)
@@ -356,13 +358,14 @@ def test_wave_per_ray_and_lane_per_ray_operators_agree(gpu, orc):
                                rm.weights_from_sigma(T(rb[:small], gpu), T(sg[:small], gpu), opaque))
 
 
-@pytest.mark.parametrize("T_,Tr", [(128, 32), (64, 32), (33, 17), (1, 5), (200, 300)])
+@pytest.mark.parametrize("T_,Tr", [(128, 32), (64, 32), (33, 17), (1, 5), (200, 300), (512, 512), (600, 700), (1500, 64), (100, 1300), (5000, 3000)])
 def test_proposal_loss_kernel_matches_the_torch_expression(gpu, T_, Tr):
     """sn_rm_proposal_loss (forward value and gradient w.r.t. the proposal weights) against the torch statement of
-    nerf/renderer.py:30-57 in fp64, on sorted random bins that do and do not line up between the two stages."""
+    nerf/renderer.py:30-57 in fp64, on sorted random bins that do and do not line up between the two stages.  More than 512 samples per ray
+    (either stage) take the long-ray instantiation: the ray's arrays in a workspace instead of LDS, a wave walking several rays."""
     from sanerf_hq_amd import raymarching as rm
     rng = np.random.default_rng(T_ * 1000 + Tr)
-    N = 513
+    N = 513 if max(T_, Tr) <= 1500 else 4099            # (the long launch holds at most 64 MiB of arrays: 4099 rays of 5000 samples share them)
     b = np.sort(rng.uniform(0, 1, (N, T_ + 1)), axis=1).astype(np.float32)
     rb = np.sort(rng.uniform(0, 1, (N, Tr + 1)), axis=1).astype(np.float32)
     rb[: N // 4, ::3] = b[: N // 4, : rb[:, ::3].shape[1]] if T_ + 1 >= rb[:, ::3].shape[1] else rb[: N // 4, ::3]   # shared edges
@@ -410,14 +413,14 @@ def test_grid_forward_cat_equals_encode_then_cat(gpu, C_, E, B):
     assert got3.shape == (B, 1, 16 * C_ + E) and torch.equal(got3.view(B, -1), want)
 
 
-@pytest.mark.parametrize("T_", [1, 32, 64, 100, 200])
+@pytest.mark.parametrize("T_", [1, 32, 64, 100, 200, 2048, 2500])
 def test_distort_loss_kernel(gpu, T_):
     """sn_rm_distort_loss against the O(T^2) definition sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 d_i in fp64 (value and
     autograd gradient), and against the cumulative-sum form the CPU path uses (what eff_distloss computes)."""
     from sanerf_hq_amd import raymarching as rm
     from sanerf_hq_amd.nerf import renderer as R
     rng = np.random.default_rng(T_)
-    N = 301
+    N = 301 if T_ <= 200 else 9                         # (the fp64 definition below is O(N T^2) memory; beyond 2048 samples the kernel reads in place)
     b = np.sort(rng.uniform(0, 1, (N, T_ + 1)), axis=1).astype(np.float32)
     w = (rng.uniform(0, 1, (N, T_)) ** 4).astype(np.float32)
     w1 = T(w, gpu).requires_grad_(True)
