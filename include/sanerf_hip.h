@@ -497,6 +497,15 @@ int sn_mlp_small_backward(const sn_mlp_desc *mlp, const float *grad_out, const f
                           const float *const *hidden, uint32_t N, float *grad_in, float *const *grad_hidden, float *grad_last, float *grad_aux_in,
                           sn_stream_t stream);
 
+/* General fp32 matrix product on the matrix cores in true fp32 (v_mfma_f32_32x32x2_f32: exact products, one k-ascending chain per output element,
+ * deterministic) -- the route of every layer shape the specialised kernels do not instantiate; replaces torch.nn.functional.linear / `@`
+ * (nerf/network.py:9-66 with widths other than the reference's):
+ *   c[i * c_row + j] = act(sum_k a[i * a_row + k * a_col] * b[k * b_row + j * b_col] + bias[j]),  i < M, j < N, k < K
+ * One stride of a and one of b must be 1.  nn.Linear forward: a = x (K, 1), b = weight [N,K] (1, K), bias or NULL; input gradient: a = dy (N, 1),
+ * b = weight (K, 1) with K and N swapped; weight gradient: a = dy (1, N) transposed, b = x (K, 1).  act: 0 none, 1 ReLU, 2 leaky ReLU (0.01). */
+int sn_gemm_f32(const float *a, int64_t a_row, int64_t a_col, const float *b, int64_t b_row, int64_t b_col, const float *bias, int32_t act,
+                uint32_t M, uint32_t N, uint32_t K, float *c, int64_t c_row, sn_stream_t stream);
+
 /* Weight gradient of an nn.Linear over a training batch: dw[N,K] = dy[M,N]^T x[M,K], fp32, summed in a fixed order
  * (deterministic).  K, N <= 64 (the radiance / proposal MLPs, nerf/network.py:9-29): register-tiled VALU kernel.
  * Otherwise N <= 256, any K (the per-sample mask head and the SAM head, network.py:31-66): v_mfma_f32_32x32x2_f32 over

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "sn_rm_ray_composite": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "sn_rm_ray_composite_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "sn_rm_proposal_loss_scaled": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp]),
+    "sn_gemm_f32": (_int, [_vp, C.c_int64, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, C.c_int32, _u32, _u32, _u32, _vp, C.c_int64, _vp]),
     "sn_rm_proposal_loss_workspace_bytes": (C.c_size_t, [_u32, _u32, _u32, _int]),
     "sn_rm_proposal_loss_long": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_zero": (_int, [_vp, C.c_size_t, _vp]),

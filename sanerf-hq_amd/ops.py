@@ -536,16 +536,64 @@ def _run_beside_backward(params, tensors, launch) -> bool:
     return True
 
 
+COLD_GEMM_NATIVE = True            # nn.Linear layers the specialised kernels do not cover: True = the library's own fp32 matrix product (sn_gemm_f32: true fp32 on
+                                   # the matrix cores, one k-ascending chain per output, deterministic); False = torch.nn.functional.linear / `@` (rocBLAS: faster on
+                                   # large shapes, summation order its own) -- a plain library GEMM, for A/B and for users who prefer it
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _gemm(a, a_row, a_col, b, b_row, b_col, bias, act, M, N, K, out):
+    _lib.check(_lib.lib().sn_gemm_f32(_lib.dev(a, "a"), int(a_row), int(a_col), _lib.dev(b, "b"), int(b_row), int(b_col),
+                                      _lib.dev(bias, "bias") if bias is not None else None, int(act), int(M), int(N), int(K),
+                                      _lib.dev(out, "out"), int(N), _lib.stream()), "sn_gemm_f32")          # (outputs are contiguous [M, N])
+    return out
+
+
+def gemm_ok(x: torch.Tensor, weight: torch.Tensor, bias=None) -> bool:
+    """Can sn_gemm_f32 take this nn.Linear?  fp32 CUDA tensors, no autocast."""
+    return (COLD_GEMM_NATIVE and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_cuda
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_cuda)) and not torch.is_autocast_enabled() and weight.dim() == 2)
+
+
+def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias=None, act: int = ACT_NONE) -> torch.Tensor:
+    """act(x W^T + b) through sn_gemm_f32 (no autograd): x [..., K], weight [N, K] -> [..., N]."""
+    K, N = weight.shape[1], weight.shape[0]
+    rows = 1
+    for d in x.shape[:-1]:
+        rows *= int(d)
+    x2 = x.detach().reshape(rows, K).contiguous()
+    w = weight.detach().contiguous()
+    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)          # (returned as it is: not a view, callers apply in-place activations)
+    _gemm(x2, K, 1, w, 1, K, bias.detach().contiguous() if bias is not None else None, act, rows, N, K, out.view(rows, N))
+    return out
+
+
+def linear_backward_input(gy2: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """dx [M, K] = dy [M, N] W [N, K] through sn_gemm_f32."""
+    M, N = gy2.shape
+    K = weight.shape[1]
+    out = torch.empty(M, K, device=gy2.device, dtype=torch.float32)
+    return _gemm(gy2, N, 1, weight.detach().contiguous(), K, 1, None, ACT_NONE, M, K, N, out)
+
+
+def linear_wgrad_general(x2: torch.Tensor, gy2: torch.Tensor, gw: torch.Tensor) -> torch.Tensor:
+    """dw [N, K] = dy [M, N]^T x [M, K] through sn_gemm_f32 (layers wider than sn_linear_wgrad takes: one workgroup per 64 x 64 tile walks all M rows)."""
+    M, K, N = x2.shape[0], x2.shape[1], gy2.shape[1]
+    return _gemm(gy2, 1, N, x2, K, 1, None, ACT_NONE, N, K, M, gw)
+
+
 class _small_linear(Function):
-    """y = x W^T (+ b) for a layer of at most 256 outputs applied to many rows (the radiance / proposal MLPs of
-    nerf/network.py:9-29 and the per-sample mask head of network.py:31-66 during training).  Forward and input
-    gradient are the usual GEMMs; the weight gradient -- a small result of a 1e5-long reduction, for which BLAS
-    heuristics pick slow kernels -- is one call of sn_linear_wgrad (deterministic summation order)."""
+    """y = x W^T (+ b) for a layer applied to many rows, any width (the layers of nerf/network.py:9-66 that the fused kernels of this file do not
+    cover).  Forward and input gradient: sn_gemm_f32 (COLD_GEMM_NATIVE; else torch / rocBLAS); the weight gradient -- a small result of a
+    1e5-long reduction, for which BLAS heuristics pick slow kernels -- is one call of sn_linear_wgrad (deterministic summation order), or of
+    sn_gemm_f32 for more than 256 outputs."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if gemm_ok(x, weight, bias):
+            return linear_forward(x, weight, bias)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -554,20 +602,26 @@ class _small_linear(Function):
         gx = gw = gb = None
         gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         if ctx.needs_input_grad[0]:
-            gx = (gy2 @ weight).reshape(x.shape)
+            gy2f = gy2 if gy2.dtype == torch.float32 else gy2.float()
+            gx = (linear_backward_input(gy2f, weight) if gemm_ok(gy2f, weight) else gy2 @ weight).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1]).contiguous()
             M, K, N = x2.shape[0], x2.shape[1], gy2.shape[1]
             lib = _lib.lib()
-            need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
-            ws = _wgrad_ws.get(x2.device)
-            if ws is None or ws.numel() < need:
-                ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x2.device)
-                _wgrad_ws[x2.device] = ws
             gw = torch.empty(N, K, device=x2.device, dtype=torch.float32)
-            # (inline: on the side stream the ~10 small launches of an RGB step cost more in forks than they hide -- step as a graph 2.24 -> 2.45 ms)
-            _lib.check(lib.sn_linear_wgrad(_lib.dev(x2, "x"), _lib.dev(gy2, "grad_output"), M, K, N, _lib.dev(gw, "grad_weight"),
-                                           ws.data_ptr(), ws.numel(), _lib.stream()), "sn_linear_wgrad")
+            if M == 0:
+                gw.zero_()
+            elif N > LINEAR_WGRAD_MAX_OUT:
+                linear_wgrad_general(x2, gy2, gw)
+            else:
+                need = int(lib.sn_linear_wgrad_workspace_bytes(M, K, N))
+                ws = _wgrad_ws.get(x2.device)
+                if ws is None or ws.numel() < need:
+                    ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x2.device)
+                    _wgrad_ws[x2.device] = ws
+                # (inline: on the side stream the ~10 small launches of an RGB step cost more in forks than they hide -- step as a graph 2.24 -> 2.45 ms)
+                _lib.check(lib.sn_linear_wgrad(_lib.dev(x2, "x"), _lib.dev(gy2, "grad_output"), M, K, N, _lib.dev(gw, "grad_weight"),
+                                               ws.data_ptr(), ws.numel(), _lib.stream()), "sn_linear_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
         return gx, gw, gb
@@ -810,7 +864,7 @@ class _wide_mlp_train(Function):
             _lib.check(_lib.lib().sn_mlp_wide_forward_train(C.byref(desc), _lib.dev(x2, "x"), rows, hid, _lib.dev(h, "out"), _lib.stream()),
                        "sn_mlp_wide_forward_train")
         else:
-            h = x
+            h = x                        # (WIDE_MLP_FORWARD_F16X3 = WIDE_MLP_FORWARD_NATIVE = False: the BLAS forward, an explicit A/B switch)
             for i, w in enumerate(weights):
                 h = torch.nn.functional.linear(h, w)
                 if i + 1 < len(weights):
@@ -907,9 +961,15 @@ def wide_mlp_train(x: torch.Tensor, layers, leaky: bool) -> torch.Tensor:
 
 
 def small_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
-    """layer(x); with autograd on a large CUDA batch of an fp32 layer of <= 256 outputs the weight gradient uses the HIP kernel."""
+    """layer(x) for the layers no fused kernel covers.  fp32 CUDA tensors run the library's own matrix product (sn_gemm_f32) in both
+    directions and the deterministic weight-gradient kernel; other tensors (CPU twins of the tests, autocast) run the torch layer."""
     w = layer.weight
     rows = x.numel() // max(x.shape[-1], 1)
+    needs_grad = torch.is_grad_enabled() and (w.requires_grad or x.requires_grad or (layer.bias is not None and layer.bias.requires_grad))
+    if gemm_ok(x, w, layer.bias) and rows > 0:
+        if needs_grad:
+            return _small_linear.apply(x, w, layer.bias)
+        return linear_forward(x, w, layer.bias)
     if (torch.is_grad_enabled() and w.requires_grad and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
             and w.shape[0] <= LINEAR_WGRAD_MAX_OUT and rows >= LINEAR_WGRAD_MIN_ROWS):
         return _small_linear.apply(x, w, layer.bias)

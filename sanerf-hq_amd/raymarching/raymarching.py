@@ -301,7 +301,7 @@ def _proposal_loss_launch(bins, w, ref_bins, ref_w, scale, scale_dev, per_ray_pt
     workspace (at most 64 MiB) -- the same kernel arithmetic either way, nothing falls back to torch."""
     N, T, Tr = w.shape[0], w.shape[1], ref_w.shape[1]
     lib = _lib.lib()
-    nbytes = int(lib.sn_rm_proposal_loss_workspace_bytes(N, T, Tr, 0 if grad_ptr is None else 1))
+    nbytes = 0 if max(T, Tr) <= 512 else int(lib.sn_rm_proposal_loss_workspace_bytes(N, T, Tr, 0 if grad_ptr is None else 1))
     ws = torch.empty((nbytes + 7) // 8, device=w.device, dtype=torch.float64) if nbytes else None
     _lib.check(lib.sn_rm_proposal_loss_long(_lib.dev(bins, "bins"), _lib.dev(w, "weights"), _lib.dev(ref_bins, "ref_bins"), _lib.dev(ref_w, "ref_weights"),
                                             N, T, Tr, float(scale), scale_dev, per_ray_ptr, grad_ptr, ws.data_ptr() if ws is not None else None,

@@ -8,7 +8,7 @@ out=$root/ab/$name; mkdir -p $out
 cd $root/sanerf-hq_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function"
 vf=${VARIANT_FILE:-render}
-for f in grid grid_binned encoders raymarch render heads mlp mlp_small optim; do
+for f in grid grid_binned encoders raymarch render heads mlp mlp_small linear optim; do
   [ "$f" = "$vf" ] && continue
   [ -f $root/sanerf-hq_amd/csrc/$f.o ] && cp $root/sanerf-hq_amd/csrc/$f.o $out/$f.o || /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $out/$f.o
 done
