@@ -185,10 +185,27 @@ template <typename T, int KIND, int l>
 constexpr bool xswap_level() {
     return KIND == 1 && l >= 0;
 }
+#ifndef SN_XSWAP_MODE
+#define SN_XSWAP_MODE 0      // which lanes trade the two x-corners of a cell (A/B, tools/xswap_ab.sh, profiles/r06/xswap_ab.txt; all bit-identical): 0 = the wave's
+                             // halves (v_permlane32_swap; 6.21-6.27 ms); 1 = neighbours (lanes 2i, 2i+1: both corners of a ray in ONE quad of the address unit, 13 %
+                             // fewer quad-line pairs but 40 % more distinct lines per instruction and a select per swap: 6.43-6.45 ms); 2 = 16-lane rows
+                             // (v_permlane16_swap: 6.19-6.20 ms, inside the noise of the default)
+#endif
 __device__ __forceinline__ void half_wave_swap(uint32_t &a, uint32_t &b) {
+#if SN_XSWAP_MODE == 0
     // a' = [a.lanes0-31 | b.lanes0-31], b' = [a.lanes32-63 | b.lanes32-63]
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0]; b = r[1];
+#elif SN_XSWAP_MODE == 1
+    // lane 2i: a' = a, b' = a of lane 2i+1;  lane 2i+1: a' = b of lane 2i, b' = b  (its own inverse, like the half-wave swap)
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    const uint32_t na = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true);
+    const bool odd = (threadIdx.x & 1u) != 0u;
+    a = odd ? nb : a; b = odd ? b : na;
+#else
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+#endif
 }
 
 // Dense levels re-laid out for the final stage (k_pack_pairs, once per render call, a few MB): pair row i of a level
