@@ -428,6 +428,9 @@ def main():
         # configurations by the same formula).  binding_frac = texture-address floor / kernel time (ta_address_rate below); mfma_frac = matrix-pipe
         # busy fraction = fp16 MFMA FLOPs issued (layers 1-2 as three split products; layer 3 is off the matrix cores) / time / 2.5 PFLOP/s
         "binding_frac": round(ta_floor / final_ms, 4) if ta_floor else None,
+        # how busy the binding unit IS (counter TA_TA_BUSY of the same kernel sources / kernel cycles): a gather of the hashed levels touches many
+        # lines and holds the address unit ~25 cycles, not the 17.8 of the coherent gather binding_frac is priced with -- that ceiling is not reachable
+        "binding_busy_frac": round(counters["TA_busy_pct"] / 100.0, 4) if counters and counters.get("TA_busy_pct") is not None else None,
         "mfma_frac": round(n_local * steps[-1] * 2 * (32 * 64 + 64 * 64) * 3 / (final_ms * 1e-3) / MFMA_F16_PEAK, 4),
         # what actually binds: NOT HBM.  The four fields above are the contract's ALGORITHMIC figure (every corner fetch once, no
         # cache credit: cache-absorbed, can exceed 1); the kernel is co-limited by the texture-address rate, vector-ALU issue and the
