@@ -172,7 +172,11 @@ __device__ __forceinline__ floatx16 mfma3h(const uint4 &ah, const uint4 &al, con
 // vmcnt(N) waits conservative (the counter retires in order), never early.
 __device__ __forceinline__ void dma16(const void *gptr, uint32_t lds_byte_offset_uniform) {
     const uint32_t base = __builtin_amdgcn_readfirstlane(lds_byte_offset_uniform);
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(base) : "memory");
+    // M0 = LDS destination base.  The SALU write of M0 needs ONE wait state before an LDS-DMA reads it (ISA "manually inserted wait states": S_MOV M0 ->
+    // LDS-direct / buffer...lds): without the s_nop the request can go out with the PREVIOUS base -- the other ring buffer -- whenever the wave
+    // issues the two instructions back to back, i.e. depending on what its SIMD neighbour is doing.  M0 is the compiler's: saved and restored.
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gptr), "s"(base) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 
@@ -764,8 +768,10 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { st
 // addresses -- ~100 cycles of issue per k-step on an in-order wave)
 __device__ __forceinline__ void dma16x4(const void *gptr, uint32_t lds_byte_offset_uniform) {
     const uint32_t base = __builtin_amdgcn_readfirstlane(lds_byte_offset_uniform);
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" : : "v"(gptr), "s"(base) : "memory");
+    uint32_t keep;            // (wait state after the M0 write, M0 saved and restored: see dma16)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(base) : "memory");
 }
 
 template <int XMODE, bool N1 = false, int SAVE = 0>   // SAVE 1 (sn_mlp_wide_forward_train_f16x3): every hidden layer's post-activation output is also written to
