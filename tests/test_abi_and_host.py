@@ -65,6 +65,30 @@ def test_round6_entry_points_validate_their_arguments():
     assert l.sn_rm_ray_composite(None, dummy, dummy, dummy, 4, 8, dummy, dummy, dummy, None) == -1
 
 
+def test_abi12_entry_points_validate_their_arguments():
+    """sn_gemm_f32, sn_rm_proposal_loss_long and the length checks of the long-ray kernels answer bad arguments with error codes before any launch."""
+    from sanerf_hq_amd import _lib
+    l = _lib.lib()
+    dummy = ctypes.c_void_p(16)
+    assert l.sn_gemm_f32(dummy, 3, 2, dummy, 1, 8, None, 0, 4, 4, 8, dummy, 4, None) == -1 and b"one stride" in l.sn_last_error()      # neither stride of a is 1
+    assert l.sn_gemm_f32(dummy, 8, 1, dummy, 1, 8, None, 3, 4, 4, 8, dummy, 4, None) == -1 and b"activation" in l.sn_last_error()
+    assert l.sn_gemm_f32(dummy, 8, 1, dummy, 1, 8, None, 0, 4, 4, 8, dummy, 3, None) == -1 and b"row stride" in l.sn_last_error()
+    assert l.sn_gemm_f32(None, 8, 1, dummy, 1, 8, None, 0, 4, 4, 8, dummy, 4, None) == -1
+    assert l.sn_gemm_f32(None, 8, 1, None, 1, 8, None, 0, 0, 4, 8, None, 4, None) == 0                                                  # no rows: nothing to launch
+    # proposal loss: up to 512 samples per ray no workspace, beyond that the size the library states (at most 64 MiB)
+    assert l.sn_rm_proposal_loss_workspace_bytes(4096, 128, 32, 1) == 0 and l.sn_rm_proposal_loss_workspace_bytes(0, 4000, 4000, 1) == 0
+    need = l.sn_rm_proposal_loss_workspace_bytes(4096, 600, 700, 1)
+    assert 0 < need <= (64 << 20) and need % 8 == 0
+    assert l.sn_rm_proposal_loss_workspace_bytes(4, 600, 700, 0) < l.sn_rm_proposal_loss_workspace_bytes(4, 600, 700, 1) < need
+    assert l.sn_rm_proposal_loss_long(dummy, dummy, dummy, dummy, 4096, 600, 700, 1.0, None, None, dummy, None, 0, None) == -1 and b"workspace" in l.sn_last_error()
+    assert l.sn_rm_proposal_loss_long(dummy, dummy, dummy, dummy, 4096, 600, 700, 1.0, None, None, dummy, ctypes.c_void_p(12), need, None) == -1      # misaligned
+    assert l.sn_rm_proposal_loss_long(dummy, dummy, dummy, dummy, 4096, 600, 700, 1.0, None, dummy, dummy, dummy, need, None) == -1                    # both outputs
+    assert l.sn_rm_proposal_loss_scaled(dummy, dummy, dummy, dummy, 4096, 600, 700, 1.0, None, None, dummy, None) == -1 and b"sn_rm_proposal_loss_long" in l.sn_last_error()
+    assert l.sn_rm_proposal_loss_long(dummy, dummy, dummy, dummy, 0, 600, 700, 1.0, None, None, dummy, None, 0, None) == 0
+    assert l.sn_rm_weights_from_sigma_backward(dummy, dummy, dummy, 4, 200000, 1, dummy, None) == -1 and b"131072" in l.sn_last_error()
+    assert l.sn_rm_distort_loss(dummy, dummy, 4, 0, dummy, dummy, None) == -1
+
+
 def test_library_reports_missing_device_loudly():
     from sanerf_hq_amd import _lib
     if torch.cuda.is_available():
