@@ -713,6 +713,24 @@ def test_general_fp32_matrix_product(gpu, M, N, K, bias, act):
     assert float((gw - refw.float()).abs().max()) <= 1e-5 * max(1.0, float(refw.abs().max()))     # (an M-long fp32 chain)
 
 
+def test_general_fp32_matrix_product_random_shapes_and_layouts(gpu):
+    """sn_gemm_f32 on 40 random shapes (1..300 per dimension, ragged against the 64 x 64 x 32 tiling) in all four operand layouts (each operand row- or
+    column-major), with and without bias, against fp64 torch."""
+    from sanerf_hq_amd import ops
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        M, N, K = (int(rng.integers(1, 301)) for _ in range(3))
+        ta, tb, bias = bool(trial & 1), bool(trial & 2), bool(trial & 4)
+        a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+        b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+        bv = rng.standard_normal(N).astype(np.float32) if bias else None
+        at, bt = T(a, gpu), T(b, gpu)
+        out = torch.empty(M, N, device=gpu)
+        ops._gemm(at, 1 if ta else K, M if ta else 1, bt, 1 if tb else N, K if tb else 1, T(bv, gpu) if bias else None, ops.ACT_NONE, M, N, K, out)
+        ref = (at.double().t() if ta else at.double()) @ (bt.double().t() if tb else bt.double()) + (T(bv, gpu).double() if bias else 0.0)
+        assert float((out - ref.float()).abs().max()) <= 3e-6 * max(1.0, float(ref.abs().max())), (M, N, K, ta, tb, bias)
+
+
 def test_layers_of_other_widths_run_the_library_product_under_autograd(gpu):
     """ops.small_linear on shapes no fused kernel covers (a 40-128-128-3 head with biases, a 300-wide layer): forward, input gradient, weight and
     bias gradients through sn_gemm_f32 / sn_linear_wgrad equal the torch layer's (rocBLAS) within fp32 round-off -- with and without autograd,
