@@ -64,5 +64,8 @@ python tools/bench_configs.py 2>/dev/null | tail -1 > $out/bench_configs.json
 python tools/train_bench.py both 2>/dev/null | tail -1 > $out/train_bench.json
 python tools/mlp_modes_ab.py 2>/dev/null | tail -1 > $out/mlp_modes_ab_final.json
 python tools/feat_patch_ab.py 2>/dev/null | tail -1 > $out/feat_patch_ab_final.json
+python tools/prop_pair_ab.py 2>/dev/null | tail -1 > $out/prop_pair_ab.json
+python tools/band_small_ab.py 2>/dev/null | tail -1 > $out/band_small_ab.json
+python tools/gemm_f32_bench.py 2>/dev/null | tail -1 > $out/gemm_f32_bench.json
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 ls -la $out
