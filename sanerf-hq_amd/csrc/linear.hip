@@ -10,7 +10,8 @@
 // Shape: 64 x 64 output tile per 256-thread workgroup, K in chunks of 32 through LDS (rows padded to 33 floats: the operand reads of 32
 // consecutive rows hit 32 different banks), each wave one 32 x 32 quadrant on v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulation, ONE
 // k-ascending chain per output element (deterministic, equal to the fmaf chain of the oracle's dense layers).  Tiles are loaded element-wise
-// with the unit stride along the fast thread index whichever operand is transposed.  This is the cold path: it is not tuned beyond that
+// with the unit stride along the fast thread index whichever operand is transposed, one chunk ahead (the next chunk's elements are in flight
+// under this chunk's matrix instructions).  This is the cold path: it is not tuned beyond that
 // (measured: tests/test_gpu_ops.py prints nothing; tools/gemm_f32_bench.py does).
 #include "sn_common.h"
 
@@ -34,25 +35,43 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     const uint32_t m0 = blockIdx.x * GM_T, n0 = blockIdx.y * GM_T;
     const uint32_t wm = (wave & 1u) * 32u, wn = (wave >> 1) * 32u;
     const bool a_kfast = g.a_col == 1, b_kfast = g.b_row == 1;
+    constexpr uint32_t PER = (GM_T * GM_KB) / 256u;              // elements of each tile per thread
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (uint32_t k0 = 0; k0 < g.K; k0 += GM_KB) {
+    // the elements this thread stages: fixed (row, k) slots, the unit stride along the fast thread index whichever operand is transposed
+    float ra[PER], rb[PER];
+    auto fetch = [&](uint32_t k0) {
 #pragma unroll
-        for (uint32_t r = 0; r < (GM_T * GM_KB) / 256u; ++r) {
+        for (uint32_t r = 0; r < PER; ++r) {
             const uint32_t e = tid + 256u * r;
-            {   // A tile
+            {
                 const uint32_t i = a_kfast ? e / GM_KB : e % GM_T, k = a_kfast ? e % GM_KB : e / GM_T;
                 const bool in = m0 + i < g.M && k0 + k < g.K;
-                as[i * GM_LD + k] = in ? g.a[(int64_t)(m0 + i) * g.a_row + (int64_t)(k0 + k) * g.a_col] : 0.0f;
+                ra[r] = in ? g.a[(int64_t)(m0 + i) * g.a_row + (int64_t)(k0 + k) * g.a_col] : 0.0f;
             }
-            {   // B tile
+            {
                 const uint32_t j = b_kfast ? e / GM_KB : e % GM_T, k = b_kfast ? e % GM_KB : e / GM_T;
                 const bool in = n0 + j < g.N && k0 + k < g.K;
-                bs[j * GM_LD + k] = in ? g.b[(int64_t)(k0 + k) * g.b_row + (int64_t)(n0 + j) * g.b_col] : 0.0f;
+                rb[r] = in ? g.b[(int64_t)(k0 + k) * g.b_row + (int64_t)(n0 + j) * g.b_col] : 0.0f;
             }
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t e = tid + 256u * r;
+            const uint32_t i = a_kfast ? e / GM_KB : e % GM_T, ka = a_kfast ? e % GM_KB : e / GM_T;
+            const uint32_t j = b_kfast ? e / GM_KB : e % GM_T, kb = b_kfast ? e % GM_KB : e / GM_T;
+            as[i * GM_LD + ka] = ra[r];
+            bs[j * GM_LD + kb] = rb[r];
+        }
+    };
+    if (g.K) fetch(0u);
+    for (uint32_t k0 = 0; k0 < g.K; k0 += GM_KB) {
+        stage();
         __syncthreads();
+        if (k0 + GM_KB < g.K) fetch(k0 + GM_KB);       // the next chunk's elements fly under this chunk's matrix instructions
         // (rows of zeros beyond K: fma(0, 0, acc) = acc, the chain of an output is unchanged)
         const float *ap = as + (wm + (lane & 31u)) * GM_LD + (lane >> 5), *bp = bs + (wn + (lane & 31u)) * GM_LD + (lane >> 5);
 #pragma unroll
