@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from ..activation import trunc_exp
 from ..encoding import get_encoder
-from ..ops import (SMALL_ACT_SIGMOID_BG, SMALL_ACT_TRUNC_EXP0, small_linear, small_mlp_fusable, small_mlp_train,
+from ..ops import (ACT_LEAKY, ACT_NONE, ACT_RELU, SMALL_ACT_SIGMOID_BG, SMALL_ACT_TRUNC_EXP0, small_linear, small_mlp_fusable, small_mlp_train,
                    wide_mlp_fusable, wide_mlp_train)
 from .renderer import NeRFRenderer
 
@@ -45,7 +45,7 @@ class MLP(nn.Module):
             return small_mlp_train(x, list(self.net))[0]
         *hidden, last = self.net
         for layer in hidden:
-            x = F.relu(small_linear(x, layer), inplace=True)
+            x = small_linear(x, layer, ACT_RELU)
         return small_linear(x, last)
 
     def forward_trunc_exp(self, x):
@@ -80,9 +80,7 @@ class SkipConnMLP(nn.Module):
         for i, layer in enumerate(self.net):
             if i in self.skip_layers:
                 h = torch.cat([h, x], dim=-1)
-            h = small_linear(h, layer)
-            if i != self.num_layers - 1:
-                h = F.leaky_relu(h, inplace=True)
+            h = small_linear(h, layer, ACT_LEAKY if i != self.num_layers - 1 else ACT_NONE)
         return h
 
 

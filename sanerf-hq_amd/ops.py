@@ -960,17 +960,26 @@ def wide_mlp_train(x: torch.Tensor, layers, leaky: bool) -> torch.Tensor:
     return _wide_mlp_train.apply(x, leaky, *[l.weight for l in layers])
 
 
-def small_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
-    """layer(x) for the layers no fused kernel covers.  fp32 CUDA tensors run the library's own matrix product (sn_gemm_f32) in both
-    directions and the deterministic weight-gradient kernel; other tensors (CPU twins of the tests, autocast) run the torch layer."""
+def _act_torch(h: torch.Tensor, act: int) -> torch.Tensor:
+    if act == ACT_RELU:
+        return torch.nn.functional.relu(h, inplace=True)
+    if act == ACT_LEAKY:
+        return torch.nn.functional.leaky_relu(h, inplace=True)
+    return h
+
+
+def small_linear(x: torch.Tensor, layer: torch.nn.Linear, act: int = ACT_NONE) -> torch.Tensor:
+    """act(layer(x)) for the layers no fused kernel covers.  fp32 CUDA tensors run the library's own matrix product (sn_gemm_f32) in both
+    directions and the deterministic weight-gradient kernel -- without autograd the activation (ACT_RELU / ACT_LEAKY) rides in the product's
+    epilogue; other tensors (CPU twins of the tests, autocast) run the torch layer."""
     w = layer.weight
     rows = x.numel() // max(x.shape[-1], 1)
     needs_grad = torch.is_grad_enabled() and (w.requires_grad or x.requires_grad or (layer.bias is not None and layer.bias.requires_grad))
     if gemm_ok(x, w, layer.bias) and rows > 0:
         if needs_grad:
-            return _small_linear.apply(x, w, layer.bias)
-        return linear_forward(x, w, layer.bias)
+            return _act_torch(_small_linear.apply(x, w, layer.bias), act)
+        return linear_forward(x, w, layer.bias, act)
     if (torch.is_grad_enabled() and w.requires_grad and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
             and w.shape[0] <= LINEAR_WGRAD_MAX_OUT and rows >= LINEAR_WGRAD_MIN_ROWS):
-        return _small_linear.apply(x, w, layer.bias)
-    return layer(x)
+        return _act_torch(_small_linear.apply(x, w, layer.bias), act)
+    return _act_torch(layer(x), act)
